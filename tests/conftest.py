@@ -1,0 +1,30 @@
+"""pytest configuration: markers and shared fixtures.
+
+`-m "not gpu"` : oracle vs golden vectors, host logic, C-ABI symbol checks.
+`-m gpu`       : parity of the HIP path (through the C-ABI) against the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """ctypes handle on oracle/liboracle.so (the CPU checker), built on demand."""
+    so = os.path.join(REPO, "oracle", "liboracle.so")
+    src = os.path.join(REPO, "oracle", "ibd_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    import oracle_lib
+    return oracle_lib.Oracle(so)
