@@ -1,0 +1,627 @@
+// ibdg_api.cpp -- the C ABI of include/ibdgem_hip.h: host-side table building,
+// validation, device memory and kernel sequencing.  No CPU implementation of
+// the likelihood path lives here: without a HIP device every compute entry
+// point fails with an error.
+#include "../../include/ibdgem_hip.h"
+#include "ibdg_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+// libm pow through a volatile pointer: the compiler must not rewrite
+// pow(x, 2.0) as x*x -- glibc's pow differs from x*x in the last bit for some
+// inputs and the reference (src/ibd-math.c:93-95) calls the real pow.
+double (*volatile libm_pow)(double, double) = std::pow;
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct ibdg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::string err;
+
+    double eps = 0.02;
+    unsigned max_cov = 20;
+    std::vector<double> lut_h;
+    DevBuf lut, pow_tab;
+
+    // panel
+    DevBuf panel, alt_count;
+    size_t n_rows = 0;
+    unsigned n_ids = 0;
+    uint32_t n_chunks = 0, stride = 0, n_groups = 0;
+    int cpw = 0;
+    bool counts_valid = false;
+
+    // sites of the current comparison
+    DevBuf rec_all, rec_cov, cov_site, fo;
+    bool have_fo = false;
+    size_t n_sites = 0;
+    uint32_t n_cov = 0, window = 0, n_win = 0;
+    std::vector<uint32_t> cov_site_h;
+
+    // run state / results
+    DevBuf targets, weight, nrefpanel, af, site_ll, win_ll;
+    size_t n_targets = 0;
+    bool have_results = false;
+    float ms[5] = {0, 0, 0, 0, 0};
+
+    // options
+    long opt_count_in_run = 0;
+    long opt_cpw = 0;      // 0 = auto
+    long opt_waves = 8;
+    long opt_variant = 0;
+};
+
+namespace {
+
+int fail(ibdg_ctx *c, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_error = buf;
+    return 1;
+}
+
+#define HIP_TRY(c, call)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), "[::] ERROR in %s: %s: %s", __func__, #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(ibdg_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes == 0)
+        bytes = 16;
+    if (b.cap >= bytes)
+        return 0;
+    if (b.p) {
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// src/ibd-math.c:5-23: C(i,j) = (i*C(i-1,j-1))/j in unsigned long; 0 for j>i.
+std::vector<unsigned long> nck_table(unsigned n)
+{
+    size_t d = (size_t)n + 1;
+    std::vector<unsigned long> t(d * d);
+    for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < d; ++j)
+            t[i * d + j] = j == 0 ? 1ul
+                                  : (i == 0 ? 0ul : ((unsigned long)(unsigned)i * t[(i - 1) * d + (j - 1)]) / (unsigned)j);
+    return t;
+}
+
+// src/ibd-math.c:46-81 over the whole reachable (n_ref, n_alt) grid.
+void build_pdg_table(double eps, unsigned M, double *out)
+{
+    const size_t d = (size_t)M + 1;
+    std::vector<unsigned long> nck = nck_table(M);
+    for (size_t r = 0; r < d; ++r) {
+        for (size_t a = 0; a < d; ++a) {
+            double *o = out + (r * d + a) * 3;
+            if (r + a > M) {       // never reached: rows with n_ref+n_alt > M are filtered (ibdgem.c:623)
+                o[0] = o[1] = o[2] = std::nan("");
+                continue;
+            }
+            if (r == 0 && a == 0) {
+                o[0] = o[1] = o[2] = 1.0;
+                continue;
+            }
+            const unsigned long c = nck[(r + a) * d + r];
+            const unsigned ur = (unsigned)r, ua = (unsigned)a;
+            double p00 = (double)c * libm_pow(1 - eps, ur) * libm_pow(eps, ua);
+            double p01 = (double)c * libm_pow(0.5, ur) * libm_pow(0.5, ua);
+            double p11 = (double)c * libm_pow(1 - eps, ua) * libm_pow(eps, ur);
+            o[0] = p00 == 0.0 ? DBL_MIN : p00;
+            o[1] = p01 == 0.0 ? DBL_MIN : p01;
+            o[2] = p11 == 0.0 ? DBL_MIN : p11;
+        }
+    }
+}
+
+int pick_cpw(uint32_t n_chunks, long opt)
+{
+    if (opt >= 1 && opt <= 5)
+        return (int)opt;
+    if (n_chunks >= 5)
+        return 5;
+    return (int)n_chunks;   // 1..4
+}
+
+// Lay the panel geometry out for n_ids individuals and allocate device rows.
+int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
+{
+    if (n_ids == 0)
+        return fail(c, "[::] ERROR in ibdg_upload_panel: n_ids must be >= 1");
+    c->n_ids = n_ids;
+    c->n_rows = n_rows;
+    c->n_chunks = (n_ids + 63) / 64;
+    c->cpw = pick_cpw(c->n_chunks, c->opt_cpw);
+    c->n_groups = (c->n_chunks + c->cpw - 1) / c->cpw;
+    c->stride = 2u * c->cpw * c->n_groups;
+    c->counts_valid = false;
+    c->have_results = false;
+    if (ensure(c, c->panel, n_rows * (size_t)c->stride * 8) || ensure(c, c->alt_count, n_rows * 4))
+        return 1;
+    // pow(1-f,2.0), pow(f,2.0) for every possible alt count (src/ibd-math.c:93-95 with
+    // f = k/(2N), src/ibd-parse.c:98)
+    const size_t K = 2 * (size_t)n_ids + 1;
+    std::vector<double> pt(2 * K);
+    for (size_t k = 0; k < K; ++k) {
+        const double f = (double)k / (double)(int)(2u * n_ids);
+        pt[2 * k] = libm_pow(1 - f, 2.0);
+        pt[2 * k + 1] = libm_pow(f, 2.0);
+    }
+    if (ensure(c, c->pow_tab, pt.size() * 8))
+        return 1;
+    HIP_TRY(c, hipMemcpyAsync(c->pow_tab.p, pt.data(), pt.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
+{
+    const size_t rw = ibdg_row_words(c->n_ids) * 8, dw = (size_t)c->stride * 8;
+    if (n_rows == 0)
+        return 0;
+    if (rw != dw)
+        HIP_TRY(c, hipMemsetAsync(c->panel.p, 0, n_rows * dw, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->panel.p, dw, src, rw, rw, n_rows, kind, c->stream));
+    if (!c->opt_count_in_run) {
+        ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, n_rows, (uint32_t *)c->alt_count.p,
+                               c->stream);
+        HIP_TRY(c, hipGetLastError());
+        c->counts_valid = true;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibdg_abi_version(void) { return IBDG_ABI_VERSION; }
+
+int ibdg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *ibdg_last_error(const ibdg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ibdg_pdg_table(double epsilon, unsigned max_cov, double *out)
+{
+    if (!out || max_cov < 1 || max_cov > 127)
+        return 1;
+    build_pdg_table(epsilon, max_cov, out);
+    return 0;
+}
+
+ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
+{
+    g_create_error.clear();
+    if (max_cov < 1 || max_cov > 127) {   // -M >= 1 (ibdgem.c:978); pileup rows have cov < 128 (pileup.c:223)
+        fail(nullptr, "[::] ERROR: Invalid maximum estimated coverage (-M) of %u (must be 1..127).", max_cov);
+        return nullptr;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(nullptr, "[::] ERROR in ibdg_create: no HIP device available (%s); this engine has no CPU path",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(nullptr, "[::] ERROR in ibdg_create: device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    ibdg_ctx *c = new ibdg_ctx;
+    c->device = device;
+    c->eps = epsilon;
+    c->max_cov = max_cov;
+    auto bail = [&](const char *what, hipError_t err) {
+        fail(nullptr, "[::] ERROR in ibdg_create: %s: %s", what, hipGetErrorString(err));
+        ibdg_destroy(c);
+        return (ibdg_ctx *)nullptr;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    const size_t d = (size_t)max_cov + 1;
+    c->lut_h.resize(d * d * 3);
+    build_pdg_table(epsilon, max_cov, c->lut_h.data());
+    if (ensure(c, c->lut, c->lut_h.size() * 8)) {
+        g_create_error = c->err;
+        ibdg_destroy(c);
+        return nullptr;
+    }
+    if ((e = hipMemcpy(c->lut.p, c->lut_h.data(), c->lut_h.size() * 8, hipMemcpyHostToDevice)) != hipSuccess)
+        return bail("hipMemcpy(lut)", e);
+    return c;
+}
+
+void ibdg_destroy(ibdg_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
+                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll})
+        release(*b);
+    for (auto &ev : c->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t ibdg_row_words(unsigned n_ids) { return 2 * (((size_t)n_ids + 63) / 64); }
+
+void ibdg_pack_alleles(const uint8_t *alleles, unsigned n_ids, uint64_t *row)
+{
+    const size_t words = ibdg_row_words(n_ids);
+    memset(row, 0, words * 8);
+    for (unsigned n = 0; n < n_ids; ++n) {
+        const size_t w = 2 * (size_t)(n >> 6);
+        const uint64_t bit = 1ull << (n & 63);
+        if (alleles[2 * n] == 1) row[w] |= bit;
+        if (alleles[2 * n + 1] == 1) row[w + 1] |= bit;
+    }
+}
+
+int ibdg_pack_hap_text(const char *line, unsigned n_ids, uint64_t *row)
+{
+    const size_t words = ibdg_row_words(n_ids);
+    memset(row, 0, words * 8);
+    const size_t need = 4 * (size_t)n_ids - 1;
+    if (strnlen(line, need) < need)
+        return 1;
+    int bad = 0;
+    for (unsigned n = 0; n < n_ids; ++n) {
+        const char c0 = line[4 * (size_t)n], c1 = line[4 * (size_t)n + 2];
+        const size_t w = 2 * (size_t)(n >> 6);
+        const uint64_t bit = 1ull << (n & 63);
+        if (c0 == '1') row[w] |= bit; else if (c0 != '0') bad = 1;
+        if (c1 == '1') row[w + 1] |= bit; else if (c1 != '0') bad = 1;
+    }
+    return bad;
+}
+
+int ibdg_upload_panel(ibdg_ctx *c, const uint64_t *rows, size_t n_rows, unsigned n_ids)
+{
+    if (!c) return 1;
+    if (!rows && n_rows) return fail(c, "[::] ERROR in ibdg_upload_panel: rows is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (prepare_panel(c, n_rows, n_ids)) return 1;
+    return copy_rows(c, rows, n_rows, hipMemcpyHostToDevice);
+}
+
+int ibdg_upload_panel_dev(ibdg_ctx *c, const void *dev_rows, size_t n_rows, unsigned n_ids)
+{
+    if (!c) return 1;
+    if (!dev_rows && n_rows) return fail(c, "[::] ERROR in ibdg_upload_panel_dev: rows is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (prepare_panel(c, n_rows, n_ids)) return 1;
+    // the source may have been produced on another stream (e.g. torch's): make it visible first
+    HIP_TRY(c, hipDeviceSynchronize());
+    return copy_rows(c, dev_rows, n_rows, hipMemcpyDeviceToDevice);
+}
+
+int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_ref, const uint8_t *n_alt,
+                      const double *f_override, size_t n_sites, unsigned window)
+{
+    if (!c) return 1;
+    if (!c->panel.p || c->n_ids == 0) return fail(c, "[::] ERROR in ibdg_upload_sites: no panel uploaded");
+    if (window < 1) return fail(c, "[::] ERROR: Invalid window size (-w) of %u (must be >= 1).", window);
+    if (n_sites && (!row_index || !n_ref || !n_alt))
+        return fail(c, "[::] ERROR in ibdg_upload_sites: NULL input array");
+    if (n_sites > 0xffffffffull)
+        return fail(c, "[::] ERROR in ibdg_upload_sites: more than 2^32-1 rows in one call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const unsigned d = c->max_cov + 1;
+    std::vector<uint2> rec_all(n_sites), rec_cov;
+    rec_cov.reserve(n_sites);
+    c->cov_site_h.clear();
+    c->cov_site_h.reserve(n_sites);
+    for (size_t s = 0; s < n_sites; ++s) {
+        const unsigned r = n_ref[s], a = n_alt[s];
+        if (row_index[s] >= c->n_rows)
+            return fail(c, "[::] ERROR in ibdg_upload_sites: row_index[%zu]=%u outside the panel (%zu rows)", s,
+                        row_index[s], c->n_rows);
+        if (r + a > c->max_cov)
+            return fail(c, "[::] ERROR in ibdg_upload_sites: site %zu has n_ref+n_alt=%u > max_cov=%u", s, r + a,
+                        c->max_cov);
+        uint2 rc;
+        rc.x = row_index[s];
+        rc.y = (r * d + a) * 24u;
+        rec_all[s] = rc;
+        if (r + a >= 1) {
+            rec_cov.push_back(rc);
+            c->cov_site_h.push_back((uint32_t)s);
+        }
+    }
+    c->n_sites = n_sites;
+    c->n_cov = (uint32_t)rec_cov.size();
+    c->window = window;
+    c->n_win = (c->n_cov + window - 1) / window;
+    c->have_results = false;
+    if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, rec_cov.size() * 8) ||
+        ensure(c, c->cov_site, rec_cov.size() * 4))
+        return 1;
+    if (n_sites)
+        HIP_TRY(c, hipMemcpyAsync(c->rec_all.p, rec_all.data(), n_sites * 8, hipMemcpyHostToDevice, c->stream));
+    if (c->n_cov) {
+        HIP_TRY(c, hipMemcpyAsync(c->rec_cov.p, rec_cov.data(), rec_cov.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->cov_site.p, c->cov_site_h.data(), rec_cov.size() * 4, hipMemcpyHostToDevice,
+                                  c->stream));
+    }
+    c->have_fo = false;
+    std::vector<double> fo;
+    if (f_override) {
+        fo.resize(3 * n_sites);
+        for (size_t s = 0; s < n_sites; ++s) {
+            const double f = f_override[s];
+            fo[3 * s] = f;
+            if (f == f) {
+                fo[3 * s + 1] = libm_pow(1 - f, 2.0);
+                fo[3 * s + 2] = libm_pow(f, 2.0);
+                c->have_fo = true;
+            } else {
+                fo[3 * s + 1] = fo[3 * s + 2] = 0.0;
+            }
+        }
+        if (c->have_fo) {
+            if (ensure(c, c->fo, fo.size() * 8)) return 1;
+            HIP_TRY(c, hipMemcpyAsync(c->fo.p, fo.data(), fo.size() * 8, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+size_t ibdg_num_sites(const ibdg_ctx *c) { return c ? c->n_sites : 0; }
+size_t ibdg_num_windows(const ibdg_ctx *c) { return c ? c->n_win : 0; }
+
+int ibdg_get_windows(const ibdg_ctx *c, uint32_t *first, uint32_t *last, uint32_t *n_covered)
+{
+    if (!c) return 1;
+    for (uint32_t w = 0; w < c->n_win; ++w) {
+        const uint32_t b = w * c->window;
+        const uint32_t e = std::min<uint64_t>((uint64_t)b + c->window, c->n_cov);
+        if (first) first[w] = c->cov_site_h[b];
+        if (last) last[w] = c->cov_site_h[e - 1];
+        if (n_covered) n_covered[w] = e - b;
+    }
+    return 0;
+}
+
+int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_count, int pu_id, int ld_mode)
+{
+    if (!c) return 1;
+    if (!c->panel.p || c->n_ids == 0) return fail(c, "[::] ERROR in ibdg_run: no panel uploaded");
+    if (!c->rec_all.p) return fail(c, "[::] ERROR in ibdg_run: no sites uploaded");
+    if (T == 0 || !targets) return fail(c, "[::] ERROR in ibdg_run: no targets");
+    if (T > 65535) return fail(c, "[::] ERROR in ibdg_run: at most 65535 targets per call");
+    for (size_t t = 0; t < T; ++t)
+        if (targets[t] >= c->n_ids)
+            return fail(c, "[::] ERROR in ibdg_run: target %u is not a panel individual (n_ids=%u)", targets[t],
+                        c->n_ids);
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    const size_t lanes = (size_t)c->n_groups * c->cpw * 64;
+    if (ensure(c, c->targets, T * 4) || ensure(c, c->af, c->n_sites * 8) ||
+        ensure(c, c->site_ll, T * c->n_sites * 24) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
+        return 1;
+    HIP_TRY(c, hipMemcpyAsync(c->targets.p, targets, T * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<double> wt;
+    std::vector<int> nref;
+    if (ld_mode) {
+        // background multiplicity per individual; the target and the -N sample contribute nothing
+        // (src/ibdgem.c:714, :742-750)
+        wt.assign(T * lanes, 0.0);
+        nref.assign(T, 0);
+        for (size_t t = 0; t < T; ++t) {
+            int cnt = 0;
+            for (unsigned n = 0; n < c->n_ids; ++n) {
+                const unsigned k = bg_count ? bg_count[n] : 1u;
+                if ((int)n == pu_id || n == targets[t] || k == 0)
+                    continue;
+                wt[t * lanes + n] = (double)k;
+                cnt += (int)k;
+            }
+            nref[t] = cnt;
+        }
+        if (ensure(c, c->weight, wt.size() * 8) || ensure(c, c->nrefpanel, T * 4))
+            return 1;
+        HIP_TRY(c, hipMemcpyAsync(c->weight.p, wt.data(), wt.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->nrefpanel.p, nref.data(), T * 4, hipMemcpyHostToDevice, c->stream));
+    }
+
+    const bool recount = c->opt_count_in_run || !c->counts_valid;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (recount) {
+        ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
+                               c->stream);
+        c->counts_valid = true;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+    ibdg::SiteArgs sa;
+    sa.panel = (const uint64_t *)c->panel.p;
+    sa.stride = c->stride;
+    sa.n_ids = c->n_ids;
+    sa.rec_all = (const uint2 *)c->rec_all.p;
+    sa.n_sites = c->n_sites;
+    sa.lut = (const double *)c->lut.p;
+    sa.alt_count = (const uint32_t *)c->alt_count.p;
+    sa.pow_tab = (const double *)c->pow_tab.p;
+    sa.fo = c->have_fo ? (const double *)c->fo.p : nullptr;
+    sa.targets = (const uint32_t *)c->targets.p;
+    sa.af = (double *)c->af.p;
+    sa.site_ll = (double *)c->site_ll.p;
+    ibdg::launch_site(sa, (unsigned)T, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+
+    if (ld_mode) {
+        ibdg::LdArgs la;
+        la.panel = sa.panel;
+        la.stride = c->stride;
+        la.rec_cov = (const uint2 *)c->rec_cov.p;
+        la.n_cov = c->n_cov;
+        la.window = c->window;
+        la.n_win = c->n_win;
+        la.n_groups = c->n_groups;
+        la.lut = sa.lut;
+        la.targets = sa.targets;
+        la.weight = (const double *)c->weight.p;
+        la.n_refpanel = (const int *)c->nrefpanel.p;
+        la.win_ll = (double *)c->win_ll.p;
+        if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
+            return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+
+    ibdg::WinArgs wa;
+    wa.site_ll = sa.site_ll;
+    wa.n_sites = c->n_sites;
+    wa.cov_site = (const uint32_t *)c->cov_site.p;
+    wa.n_cov = c->n_cov;
+    wa.window = c->window;
+    wa.n_win = c->n_win;
+    wa.ld_mode = ld_mode ? 1 : 0;
+    wa.win_ll = (double *)c->win_ll.p;
+    ibdg::launch_window_prod(wa, (unsigned)T, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    float v;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[0], c->ev[4])); c->ms[0] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[0], c->ev[1])); c->ms[1] = recount ? v : 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[1], c->ev[2])); c->ms[2] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[2], c->ev[3])); c->ms[3] = ld_mode ? v : 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[3], c->ev[4])); c->ms[4] = v;
+    c->n_targets = T;
+    c->have_results = true;
+    return 0;
+}
+
+static int fetch(ibdg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int ibdg_get_site_af(ibdg_ctx *c, double *af)
+{
+    if (!c) return 1;
+    if (!c->have_results) return fail(c, "[::] ERROR in ibdg_get_site_af: no results (call ibdg_run)");
+    return fetch(c, af, c->af.p, c->n_sites * 8);
+}
+
+int ibdg_get_site_ll(ibdg_ctx *c, size_t t, double *out)
+{
+    if (!c) return 1;
+    if (!c->have_results || t >= c->n_targets) return fail(c, "[::] ERROR in ibdg_get_site_ll: no results for target %zu", t);
+    return fetch(c, out, (const char *)c->site_ll.p + t * c->n_sites * 24, c->n_sites * 24);
+}
+
+int ibdg_get_window_ll(ibdg_ctx *c, size_t t, double *out)
+{
+    if (!c) return 1;
+    if (!c->have_results || t >= c->n_targets) return fail(c, "[::] ERROR in ibdg_get_window_ll: no results for target %zu", t);
+    return fetch(c, out, (const char *)c->win_ll.p + t * (size_t)c->n_win * 24, (size_t)c->n_win * 24);
+}
+
+int ibdg_get_alt_counts(ibdg_ctx *c, size_t first_row, size_t n, uint32_t *out)
+{
+    if (!c) return 1;
+    if (!c->counts_valid) return fail(c, "[::] ERROR in ibdg_get_alt_counts: counts not computed yet");
+    if (first_row + n > c->n_rows) return fail(c, "[::] ERROR in ibdg_get_alt_counts: range outside the panel");
+    return fetch(c, out, (const char *)c->alt_count.p + first_row * 4, n * 4);
+}
+
+int ibdg_last_run_ms(const ibdg_ctx *c, float out[5])
+{
+    if (!c || !out) return 1;
+    for (int i = 0; i < 5; ++i) out[i] = c->ms[i];
+    return 0;
+}
+
+int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
+{
+    if (!c || !name) return 1;
+    if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
+    if (!strcmp(name, "chunks_per_wave")) {
+        if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");
+        c->opt_cpw = value; return 0;
+    }
+    if (!strcmp(name, "waves_per_block")) {
+        if (value < 1 || value > 8) return fail(c, "[::] ERROR in ibdg_set_option: waves_per_block must be 1..8");
+        c->opt_waves = value; return 0;
+    }
+    if (!strcmp(name, "ld_variant")) { c->opt_variant = value; return 0; }
+    return fail(c, "[::] ERROR in ibdg_set_option: unknown option '%s'", name);
+}
+
+int ibdg_sync(ibdg_ctx *c)
+{
+    if (!c) return 1;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

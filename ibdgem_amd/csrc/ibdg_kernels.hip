@@ -1,0 +1,322 @@
+// ibdg_kernels.hip -- gfx950 (MI355X) kernels of the IBD-likelihood engine.
+//
+// Every kernel cites the reference lines whose result it reproduces
+// (paths relative to /root/reference).  Arithmetic is IEEE fp64 mul/add in the
+// reference's association order; the file is compiled with -ffp-contract=off
+// because the reference (x86-64, -O0) never fuses.  No pow() on the device: all
+// powers come from host-built tables (glibc pow, like the reference).
+//
+// Data layout:
+//   panel   [n_rows][stride] u64, word 2c = first haplotypes of individuals
+//           64c..64c+63, word 2c+1 = their second haplotypes (bit = n%64)
+//   lut     [(M+1)^2][3] f64 = P(D|G) for G=00,01,11, index n_ref*(M+1)+n_alt
+//   rec     {row_index u32, lut byte offset u32}; offset 0 <=> zero coverage
+#include "ibdg_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace ibdg {
+
+// ---------------------------------------------------------------------------
+// K0: alt-allele count of every panel row = popcount of the packed row.
+// Replaces find_f_impute / find_f_vcf (src/ibd-parse.c:91-110): the count over
+// ALL 2*n_ids alleles of the row; the division happens where f is used.
+// One wave per row per iteration, 16 B per lane.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alt_count(const uint64_t *__restrict__ panel,
+                                                   uint32_t stride, size_t n_rows,
+                                                   uint32_t *__restrict__ alt_count)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t pairs = stride >> 1;          // stride is even: 16-byte units per row
+    for (size_t r = wave; r < n_rows; r += n_waves) {
+        const ulonglong2 *row = reinterpret_cast<const ulonglong2 *>(panel + r * stride);
+        unsigned c = 0;
+        for (uint32_t i = lane; i < pairs; i += 64) {
+            ulonglong2 v = row[i];
+            c += __popcll(v.x) + __popcll(v.y);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            c += __shfl_xor(c, off);
+        if (lane == 0)
+            alt_count[r] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: per-site LIBD0/LIBD1/LIBD2 (tab columns), one thread per (site, target).
+//   f          src/ibd-parse.c:98 (count / (2*n_ids)) or the -A override
+//   ibd0       find_pDgf      src/ibd-math.c:84-101
+//   ibd1       find_pDgIBD1   src/ibd-math.c:104-142
+//   ibd2       src/ibdgem.c:643-651
+// pow(1-f,2.0) and pow(f,2.0) come from pow_tab (indexed by alt count) or, with
+// an -A override, from the per-site fo array {f, pow(1-f,2), pow(f,2)}.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_site(SiteArgs a)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sites)
+        return;
+    const unsigned t = blockIdx.y;
+    const uint2 rc = a.rec_all[s];
+    const uint64_t *row = a.panel + (size_t)rc.x * a.stride;
+    const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc.y);
+    const double p00 = L[0], p01 = L[1], p11 = L[2];
+
+    const uint32_t k = a.alt_count[rc.x];
+    double f = (double)k / (double)(int)(2u * a.n_ids);
+    double pw1 = a.pow_tab[2 * k], pw2 = a.pow_tab[2 * k + 1];
+    if (a.fo) {
+        const double fo = a.fo[3 * s];
+        if (fo == fo) {          // not NaN: -A override (src/ibdgem.c:609-614)
+            f = fo;
+            pw1 = a.fo[3 * s + 1];
+            pw2 = a.fo[3 * s + 2];
+        }
+    }
+    const uint32_t tgt = a.targets[t];
+    const unsigned A0 = (unsigned)(row[2 * (tgt >> 6)] >> (tgt & 63)) & 1u;
+    const unsigned A1 = (unsigned)(row[2 * (tgt >> 6) + 1] >> (tgt & 63)) & 1u;
+    const unsigned g = A0 + A1;
+
+    const double omf = 1 - f;
+    double ibd0 = 1.0;
+    if (!(p00 == 1 || p01 == 1 || p11 == 1)) {
+        const double t1 = pw1 * p00;
+        const double t2 = ((2 * omf) * f) * p01;
+        const double t3 = pw2 * p11;
+        ibd0 = (t1 + t2) + t3;
+        if (ibd0 == 0.0)
+            ibd0 = 2.2250738585072014e-308;      // DBL_MIN
+    }
+    double ibd1;
+    if (g == 0)
+        ibd1 = (f * p01) + (omf * p00);
+    else if (g == 1)
+        ibd1 = ((0.5 * p01) + ((0.5 * omf) * p00)) + ((0.5 * f) * p11);
+    else
+        ibd1 = (omf * p01) + (f * p11);
+    if (ibd1 == 0.0)
+        ibd1 = 2.2250738585072014e-308;
+    const double ibd2 = g == 0 ? p00 : (g == 1 ? p01 : p11);
+
+    if (t == 0)
+        a.af[s] = f;
+    double *o = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
+    o[0] = ibd0;
+    o[1] = ibd1;
+    o[2] = ibd2;
+}
+
+// ---------------------------------------------------------------------------
+// K3: window products S0,S1,S2 over the covered rows of a window, in row order
+// (src/ibdgem.c:562, :665-667, :755).  One wave per (window, target); lanes
+// stage the rows' three values through LDS, lanes 0..2 multiply sequentially.
+// In --LD mode only LIBD2 = S2 is written (src/ibdgem.c:752); LIBD0/LIBD1 of
+// the window come from the LD kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_window_prod(WinArgs a)
+{
+    __shared__ double buf[64 * 3];
+    const unsigned w = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const uint32_t begin = w * a.window;
+    const uint32_t end = min(begin + a.window, a.n_cov);
+    const double *ll = a.site_ll + (size_t)t * a.n_sites * 3;
+    double acc = 1.0;
+    for (uint32_t base = begin; base < end; base += 64) {
+        const uint32_t n = min(64u, end - base);
+        if (lane < n) {
+            const double *src = ll + (size_t)a.cov_site[base + lane] * 3;
+            buf[lane * 3] = src[0];
+            buf[lane * 3 + 1] = src[1];
+            buf[lane * 3 + 2] = src[2];
+        }
+        __syncthreads();
+        if (lane < 3)
+            for (uint32_t j = 0; j < n; ++j)
+                acc *= buf[j * 3 + lane];
+        __syncthreads();
+    }
+    if (lane < 3 && (!a.ld_mode || lane == 2))
+        a.win_ll[((size_t)t * a.n_win + w) * 3 + lane] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// K2: the --LD background-panel loop (src/ibdgem.c:669-722) and the window
+// average (src/ibdgem.c:736-753).
+//
+// One workgroup per (window, target).  A wave owns CPW chunks of 64 background
+// individuals at a time (one individual per lane) and keeps the reference's
+// five running products per individual in registers:
+//     P2  = prod pDg[h0+h1]          (sum_ibd2_ref[n])
+//     Q00 = prod pDg[A0+h0], Q01 = prod pDg[A0+h1],
+//     Q10 = prod pDg[A1+h0], Q11 = prod pDg[A1+h1]   (sum_ibd1_ref[4n..4n+3])
+// multiplied site by site in row order starting from 1.0, exactly like the
+// reference, so each individual's products are bit-identical to it.
+//
+// The panel words of a chunk ARE the lane masks: word 2c bit l = first
+// haplotype of the lane-l individual.  They arrive through the scalar path
+// (s_load) and drive v_cndmask directly (inverse ballot), so picking
+// pDg[x+y] costs two v_cndmask_b32 per double and no per-lane bit twiddling.
+//
+// After the last site each lane adds  count[n] * product  (count = times the
+// individual is listed as background, 0 when it is the target or the -N
+// sample: src/ibdgem.c:714, :742-750), lanes and waves are reduced in a fixed
+// order, and thread 0 divides by n_refpanel resp. 4*n_refpanel.
+// The sum order differs from the reference's n-ascending loop (tree instead of
+// serial): within ~1e-15 relative, the documented tolerance is 1e-10.
+// ---------------------------------------------------------------------------
+// One site for CPW chunks, branch-free.  The target's alleles A0,A1 at the site are
+// wave-uniform, so the allele-dependent choices are made once per site on the scalar
+// side and the per-lane work is twelve v_cndmask_b32 and five v_mul_f64 per chunk:
+//   (u0,v0) = pDg[A0+0], pDg[A0+1];  (u1,v1) likewise for A1
+//   f00 = h0 ? v0 : u0   f01 = h1 ? v0 : u0   f10 = h0 ? v1 : u1   f11 = h1 ? v1 : u1
+//   pDg[h0+h1] = (h1 xor A0) ? Y : f00  with  Y = h0 ? vy : uy  and (uy,vy) the pair of
+//   the allele 1-A0 (for a heterozygous target that is (u1,v1), i.e. Y = f10).
+// (A four-way switch on (A0,A1) needs fewer selects, but hipcc then copies every
+// accumulator twice per site across the arms.)
+template <int CPW>
+__device__ __forceinline__ void ld_site(const uint64_t *__restrict__ m, unsigned A0, unsigned A1,
+                                        double p00, double p01, double p11, double (&P2)[CPW],
+                                        double (&Q00)[CPW], double (&Q01)[CPW],
+                                        double (&Q10)[CPW], double (&Q11)[CPW])
+{
+    const double u0 = A0 ? p01 : p00, v0 = A0 ? p11 : p01;
+    const double u1 = A1 ? p01 : p00, v1 = A1 ? p11 : p01;
+    const double uy = A0 ? p00 : p01, vy = A0 ? p01 : p11;
+    const uint64_t flip = 0ull - (uint64_t)A0;   // all ones when A0 == 1 (scalar)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const uint64_t m0 = m[2 * c], m1 = m[2 * c + 1];
+        const bool b0 = __builtin_amdgcn_inverse_ballot_w64(m0);
+        const bool b1 = __builtin_amdgcn_inverse_ballot_w64(m1);
+        const bool b1f = __builtin_amdgcn_inverse_ballot_w64(m1 ^ flip);
+        const double f00 = b0 ? v0 : u0;
+        const double f01 = b1 ? v0 : u0;
+        const double f10 = b0 ? v1 : u1;
+        const double f11 = b1 ? v1 : u1;
+        const double y = b0 ? vy : uy;
+        P2[c] *= b1f ? y : f00;           // pDg[h0+h1]
+        Q00[c] *= f00;
+        Q01[c] *= f01;
+        Q10[c] *= f10;
+        Q11[c] *= f11;
+    }
+}
+
+template <int CPW>
+__global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
+{
+    __shared__ double red[2][8];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned n_waves = blockDim.x >> 6;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned w = blockIdx.x, t = blockIdx.y;
+
+    const uint32_t begin = w * a.window;
+    const uint32_t end = min(begin + a.window, a.n_cov);
+    const uint32_t tgt = a.targets[t];
+    const uint32_t tw = 2 * (tgt >> 6), tb = tgt & 63;
+    const double *wt = a.weight + (size_t)t * a.n_groups * CPW * 64;
+
+    double s0 = 0.0, s1 = 0.0;
+    for (unsigned g = wave; g < a.n_groups; g += n_waves) {
+        double P2[CPW], Q00[CPW], Q01[CPW], Q10[CPW], Q11[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+            P2[c] = Q00[c] = Q01[c] = Q10[c] = Q11[c] = 1.0;
+
+        for (uint32_t j = begin; j < end; ++j) {
+            const uint2 rc = a.rec_cov[j];
+            const uint64_t *row = a.panel + (size_t)rc.x * a.stride;
+            const double *L = reinterpret_cast<const double *>(
+                reinterpret_cast<const char *>(a.lut) + rc.y);
+            const double p00 = L[0], p01 = L[1], p11 = L[2];
+            const unsigned A0 = __builtin_amdgcn_readfirstlane((unsigned)(row[tw] >> tb) & 1u);
+            const unsigned A1 = __builtin_amdgcn_readfirstlane((unsigned)(row[tw + 1] >> tb) & 1u);
+            const uint64_t *m = row + 2 * CPW * g;
+            ld_site<CPW>(m, A0, A1, p00, p01, p11, P2, Q00, Q01, Q10, Q11);
+        }
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const double cnt = wt[(g * CPW + c) * 64 + lane];
+            s0 += cnt * P2[c];
+            s1 += cnt * (((Q00[c] + Q01[c]) + Q10[c]) + Q11[c]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off);
+        s1 += __shfl_xor(s1, off);
+    }
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (unsigned i = 0; i < n_waves; ++i) {
+            t0 += red[0][i];
+            t1 += red[1][i];
+        }
+        const int nref = a.n_refpanel[t];
+        double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
+        o[0] = t0 / (double)nref;               // src/ibdgem.c:752
+        o[1] = t1 / (double)(nref * 4);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
+                      hipStream_t st)
+{
+    if (n_rows == 0)
+        return;
+    size_t blocks = (n_rows + 3) / 4;
+    if (blocks > 256 * 32)
+        blocks = 256 * 32;
+    hipLaunchKernelGGL(k_alt_count, dim3((unsigned)blocks), dim3(256), 0, st, panel, stride, n_rows,
+                       alt_count);
+}
+
+void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st)
+{
+    if (a.n_sites == 0 || n_targets == 0)
+        return;
+    dim3 grid((unsigned)((a.n_sites + 255) / 256), n_targets);
+    hipLaunchKernelGGL(k_site, grid, dim3(256), 0, st, a);
+}
+
+void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st)
+{
+    if (a.n_win == 0 || n_targets == 0)
+        return;
+    hipLaunchKernelGGL(k_window_prod, dim3(a.n_win, n_targets), dim3(64), 0, st, a);
+}
+
+int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st)
+{
+    if (a.n_win == 0 || n_targets == 0)
+        return 0;
+    if (waves < 1) waves = 1;
+    if (waves > 8) waves = 8;
+    if (waves > a.n_groups) waves = a.n_groups;
+    dim3 grid(a.n_win, n_targets), block(64 * waves);
+    switch (cpw) {
+    case 1: hipLaunchKernelGGL(k_ld_window<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_ld_window<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_ld_window<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_ld_window<4>, grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_ld_window<5>, grid, block, 0, st, a); break;
+    default: return 1;
+    }
+    return 0;
+}
+
+}  // namespace ibdg

@@ -1,0 +1,156 @@
+/*
+ * include/ibdgem_hip.h -- C ABI of the MI355X IBD-likelihood engine.
+ *
+ * Drop-in boundary for ONE path of Paleogenomics/IBDGem: the per-SNP
+ * P(D|IBD0,1,2) arithmetic of src/ibd-math.c and the window / --LD
+ * background-panel loop that the reference writes inline in
+ * compare_impute()/compare_vcf() (src/ibdgem.c:558-760 and :247-462).
+ *
+ * The reference has no FFI for this path: the host program
+ * calls find_pDgG/find_pDgf/find_pDgIBD1 (src/ibd-math.h:14-63) once per row
+ * and runs the LD loop in place.  This header is the seam a maintainer binds
+ * instead (INTEGRATION.md shows the patch to compare_impute): the host keeps
+ * parsing and row filtering (integer work, src/ibdgem.c:573-630), hands the
+ * engine the rows that survive, and prints what comes back.
+ *
+ * Conventions (mirroring the reference's, src/ibdgem.c:947-1041):
+ *   - every call returns 0 on success, non-zero on error; the message is
+ *     available from ibdg_last_error(); the library never exits the process
+ *     and never falls back to a CPU implementation;
+ *   - the caller owns all host buffers; the context owns all device memory;
+ *   - one context per device, used from one host thread at a time.
+ *
+ * Plain C: pointers and sizes only.
+ */
+#ifndef IBDGEM_HIP_H
+#define IBDGEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBDG_ABI_VERSION 1
+
+typedef struct ibdg_ctx ibdg_ctx;
+
+int ibdg_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int ibdg_device_count(void);
+
+/* Create an engine on `device`.  Replaces init_nCk() + the per-row
+ * find_pDgG() calls (src/ibdgem.c:1168, :632-634; src/ibd-math.c:13-81):
+ * the (max_cov+1)^2 x 3 table of P(D|G) is built here on the host with libm
+ * pow(), exactly as the reference evaluates it, and kept on the device.
+ * epsilon = -e, max_cov = -M.  Returns NULL on failure (see
+ * ibdg_last_error(NULL)). */
+ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov);
+
+/* Replaces destroy_nCk() (src/ibd-math.c:34-43) and frees all device memory. */
+void ibdg_destroy(ibdg_ctx *ctx);
+
+/* Last error message of `ctx` (or of the last failed ibdg_create when ctx is
+ * NULL).  Never NULL; empty string when there was no error. */
+const char *ibdg_last_error(const ibdg_ctx *ctx);
+
+/* Host-side helper: the P(D|G) table the context uses, as
+ * out[(n_ref*(max_cov+1)+n_alt)*3 + g], g = 0:(0,0) 1:het 2:(1,1)
+ * (src/ibd-math.c:46-81).  out holds (max_cov+1)^2*3 doubles. */
+int ibdg_pdg_table(double epsilon, unsigned max_cov, double *out);
+
+/* ---- phased panel (the .hap rows / VCF GT columns) ---------------------- */
+
+/* A packed row is ibdg_row_words(n_ids) 64-bit words: for individual n,
+ * chunk = n/64, bit = n%64; word[2*chunk] holds the first haplotype
+ * (reference hap_buf[4n], src/ibdgem.c:638), word[2*chunk+1] the second
+ * (hap_buf[4n+2], :639).  Unused high bits are zero. */
+size_t ibdg_row_words(unsigned n_ids);
+
+/* Pack one row of 2*n_ids alleles (0/1 bytes, [2n]=first, [2n+1]=second). */
+void ibdg_pack_alleles(const uint8_t *alleles, unsigned n_ids, uint64_t *row);
+
+/* Pack one IMPUTE .hap text row ("0 1 1 0 ...", the reference's hap_buf):
+ * characters at even offsets are alleles.  Returns 0, or 1 if the row is
+ * shorter than 4*n_ids-1 characters or holds a character other than '0'/'1'
+ * at an allele offset. */
+int ibdg_pack_hap_text(const char *hap_line, unsigned n_ids, uint64_t *row);
+
+/* Upload n_rows packed rows (host memory, row-major, ibdg_row_words each).
+ * Also computes the per-row alternate-allele counts on the device
+ * (find_f_impute/find_f_vcf, src/ibd-parse.c:91-110) unless deferred to
+ * ibdg_run (see ibdg_set_option "count_in_run"). */
+int ibdg_upload_panel(ibdg_ctx *ctx, const uint64_t *rows, size_t n_rows, unsigned n_ids);
+
+/* Same, from memory that is already on this context's device
+ * (e.g. a torch tensor's data_ptr()); copied device-to-device. */
+int ibdg_upload_panel_dev(ibdg_ctx *ctx, const void *dev_rows, size_t n_rows, unsigned n_ids);
+
+/* ---- the rows of one comparison ------------------------------------------ */
+
+/* The rows that passed the reference's filter chain (src/ibdgem.c:584-626)
+ * in file order: row_index into the uploaded panel, read counts after -D
+ * culling (src/ibdgem.c:620-628; n_ref+n_alt <= max_cov), optional -A
+ * frequency (NaN = use the panel's own; pointer may be NULL), window = -w.
+ * Rows with n_ref+n_alt == 0 get per-site values but join no window
+ * (src/ibdgem.c:657-663).  Windows are consecutive runs of `window` covered
+ * rows; the last may be shorter (src/ibdgem.c:572-578, :736). */
+int ibdg_upload_sites(ibdg_ctx *ctx, const uint32_t *row_index, const uint8_t *n_ref,
+                      const uint8_t *n_alt, const double *f_override, size_t n_sites,
+                      unsigned window);
+
+size_t ibdg_num_sites(const ibdg_ctx *ctx);
+size_t ibdg_num_windows(const ibdg_ctx *ctx);
+
+/* Per window: index (into the uploaded site list) of its first and last
+ * covered row, and NUM_SITES (src/ibdgem.c:723-730, :751-756).  Any pointer
+ * may be NULL. */
+int ibdg_get_windows(const ibdg_ctx *ctx, uint32_t *first, uint32_t *last, uint32_t *n_covered);
+
+/* ---- run ------------------------------------------------------------------- */
+
+/* Evaluate n_targets comparisons (the reference's loop over data->uids,
+ * src/ibdgem.c:522) in one call.
+ *   targets[t]  individual index of the compared sample (cmp_idx/2)
+ *   bg_count    NULL = every individual is background once
+ *               (src/ibdgem.c:517-520), else n_ids bytes: how many times the
+ *               individual appears in the -B list (read_rf keeps duplicates,
+ *               src/ibd-parse.c:262-308)
+ *   pu_id       individual whose name equals -N, or -1 (src/ibdgem.c:501-506)
+ *   ld_mode     --LD: LIBD0/LIBD1 of each window are the background averages
+ *               of src/ibdgem.c:736-753; otherwise the plain products (:755).
+ * Results stay on the device until fetched. */
+int ibdg_run(ibdg_ctx *ctx, const uint32_t *targets, size_t n_targets, const uint8_t *bg_count,
+             int pu_id, int ld_mode);
+
+/* AF column: alt-allele fraction per uploaded site (or the -A override). */
+int ibdg_get_site_af(ibdg_ctx *ctx, double *af);
+/* LIBD0, LIBD1, LIBD2 per site of target t: out[n_sites][3] (tab columns 12-14). */
+int ibdg_get_site_ll(ibdg_ctx *ctx, size_t t, double *out);
+/* LIBD0, LIBD1, LIBD2 per window of target t: out[n_windows][3] (summary columns 4-6). */
+int ibdg_get_window_ll(ibdg_ctx *ctx, size_t t, double *out);
+/* Alt-allele count of panel rows [first_row, first_row+n): out[n] (for tests). */
+int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out);
+
+/* ---- measurement / tuning --------------------------------------------------- */
+
+/* Device time of the last ibdg_run, from HIP events on the engine's stream:
+ * out[0] total, out[1] alt-count kernel (0 if not run), out[2] per-site
+ * kernel, out[3] LD window kernel, out[4] window-product kernel (ms). */
+int ibdg_last_run_ms(const ibdg_ctx *ctx, float out[5]);
+
+/* Options: "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
+ * so the timed region covers it), "chunks_per_wave" (LD kernel tiling, before
+ * ibdg_upload_panel), "waves_per_block", "ld_variant".  Returns non-zero for an unknown
+ * name or a value out of range. */
+int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
+
+/* Block until all work queued on the engine's stream is done. */
+int ibdg_sync(ibdg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBDGEM_HIP_H */

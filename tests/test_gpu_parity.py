@@ -1,0 +1,284 @@
+"""GPU parity: the HIP path, called through the C ABI, against the oracle and
+the committed golden vectors.
+
+Bars (BASELINE.json north_star):
+  * integer results (alt counts, window boundaries, NUM_SITES): bit-exact;
+  * per-site LIBD0/1/2 (tab columns): bit-exact doubles (same operation order,
+    host-built pow tables, no FMA contraction);
+  * window LIBD2 and non-LD LIBD0/1: bit-exact (sequential product, same order);
+  * --LD window LIBD0/LIBD1: relative 1e-10 wherever |ref| >= 1e-290, "both
+    below 1e-290" otherwise (the sum over the background is a tree on the
+    GPU and a serial loop in the reference; observed differences are ~1e-15).
+"""
+import numpy as np
+import pytest
+
+import golden_io as G
+from ibdgem_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+LD_RTOL = 1e-10
+TINY = 1e-290
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits(got, want, what):
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    assert got.shape == want.shape, what
+    same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        i = tuple(np.argwhere(~same)[0])
+        raise AssertionError(f"{what}: {(~same).sum()}/{same.size} differ, first at {i}: "
+                             f"{got[i]!r} ({got[i].hex()}) vs {want[i]!r} ({want[i].hex()})")
+
+
+def assert_ld_close(got, want, what):
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    assert got.shape == want.shape, what
+    nan = np.isnan(want)
+    assert (np.isnan(got) == nan).all(), f"{what}: NaN pattern"
+    tiny = (np.abs(want) < TINY) & ~nan
+    assert (np.abs(got[tiny]) < TINY).all(), f"{what}: tiny values"
+    big = ~tiny & ~nan
+    rel = np.abs(got[big] - want[big]) / np.abs(want[big])
+    assert rel.size == 0 or rel.max() <= LD_RTOL, f"{what}: max rel err {rel.max():.3e}"
+    return 0.0 if rel.size == 0 else float(rel.max())
+
+
+def bg_counts(refids, n_ids):
+    if refids is None:
+        return None
+    c = np.zeros(n_ids, dtype=np.uint8)
+    for k in refids:
+        c[k] += 1
+    return c
+
+
+@pytest.fixture(scope="module")
+def eng():
+    with E.Engine(0, 0.02, 20) as e:
+        yield e
+
+
+# --------------------------------------------------------------------------- fixtures of the reference
+def test_reference_fixture_files(eng):
+    panel = G.load_fixture_panel()
+    eng.upload_panel(E.pack_alleles(panel.alleles), len(panel.names))
+    for k in (1, 2, 3):
+        tabs = {t: G.fixture_outputs(f"sample{k}", f"sample{t}") for t in (1, 2, 3)}
+        tab0 = tabs[1][0]
+        rows = np.array([panel.row_of_pos[int(p)] for p in tab0.pos], dtype=np.uint32)
+        eng.upload_sites(rows, tab0.n_ref, tab0.n_alt, 100)
+        eng.run([0, 1, 2], ld=False)
+        af = eng.site_af()
+        first, last, ncov = eng.windows()
+        for t in (1, 2, 3):
+            tab, summ = tabs[t]
+            assert (tab.pos == tab0.pos).all()
+            ll = eng.site_ll(t - 1)
+            win = eng.window_ll(t - 1)
+            for i in range(len(rows)):
+                assert "%f" % af[i] == tab.af_txt[i]
+                assert ["%e" % v for v in ll[i]] == tab.ll_txt[i], (k, t, i)
+            assert len(win) == len(summ.ll)
+            for w in range(len(win)):
+                assert ["%e" % v for v in win[w]] == summ.ll_txt[w], (k, t, w)
+            assert (ncov == summ.nsites).all()
+            assert (tab.pos[first] == summ.start).all() and (tab.pos[last] == summ.end).all()
+
+
+# --------------------------------------------------------------------------- 17-digit reference outputs
+def _syn_cases():
+    return [(tag, case) for tag in ("synA", "synB") for case in G.cases(tag)["cases"]]
+
+
+@pytest.mark.parametrize("tag,case", _syn_cases())
+def test_reference_17digit_outputs(tag, case, oracle):
+    flags, panel, names, refids, pu_id, per_target = G.case_setup(tag, case)
+    n_ids = len(panel.names)
+    with E.Engine(0, flags["eps"], flags["max_cov"]) as eng:
+        eng.upload_panel(E.pack_alleles_fast(panel.alleles), n_ids)
+        cnt = eng.alt_counts(0, len(panel.pos))
+        assert (cnt == panel.alleles.sum(axis=1)).all()
+        for name in names:
+            tab, summ, alle, fo, rows = per_target[name]
+            t = panel.index(name)
+            eng.upload_sites(rows, tab.n_ref, tab.n_alt, flags["window"], f_override=fo)
+            eng.run([t], ld=flags["ld"], bg_count=bg_counts(refids, n_ids), pu_id=pu_id)
+            assert eng.n_sites == len(tab.pos) == tab.processed
+            assert_bits(eng.site_ll(0), tab.ll, f"{tag}/{case}/{name} per-site")
+            af = eng.site_af()
+            assert ["%f" % x for x in af] == tab.af_txt
+            win = eng.window_ll(0)
+            assert len(win) == len(summ.ll)
+            first, last, ncov = eng.windows()
+            assert (ncov == summ.nsites).all()
+            if len(win):
+                assert (tab.pos[first] == summ.start).all() and (tab.pos[last] == summ.end).all()
+            assert_bits(win[:, 2], summ.ll[:, 2], f"{tag}/{case}/{name} window LIBD2")
+            if flags["ld"]:
+                assert_ld_close(win[:, :2], summ.ll[:, :2], f"{tag}/{case}/{name} LD window")
+            else:
+                assert_bits(win, summ.ll, f"{tag}/{case}/{name} window")
+            # and the oracle says the same as the reference's file (sanity of the checker)
+            res = oracle.compare(alle, tab.n_ref, tab.n_alt, t, window=flags["window"], eps=flags["eps"],
+                                 max_cov=flags["max_cov"], refids=refids, pu_id=pu_id, ld=flags["ld"],
+                                 f_override=fo)
+            assert_bits(res["win"], summ.ll, "oracle vs golden")
+
+
+# --------------------------------------------------------------------------- seeded random vs oracle
+def synth(seed, L, N, cov_mean=2.0):
+    rng = np.random.default_rng(seed)
+    f = np.clip(rng.beta(0.3, 1.0, size=L), 1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    cov = np.minimum(rng.poisson(cov_mean, size=L), 20)
+    n_alt = rng.binomial(cov, f)
+    return alle, (cov - n_alt).astype(np.uint8), n_alt.astype(np.uint8)
+
+
+@pytest.mark.parametrize("N,L,W", [(3, 257, 100), (64, 500, 100), (65, 300, 7), (100, 1500, 100),
+                                   (320, 700, 64), (321, 400, 100), (2504, 1200, 100), (700, 350, 350)])
+def test_random_panels_against_oracle(oracle, N, L, W):
+    alle, nr, na = synth(1000 + N, L, N)
+    targets = sorted({0, N // 2, N - 1})
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, W)
+        for pu in (-1, targets[-1]):
+            eng.run(targets, ld=True, pu_id=pu)
+            for i, t in enumerate(targets):
+                res = oracle.compare(alle, nr, na, t, window=W, ld=True, pu_id=pu)
+                assert_bits(eng.site_ll(i), res["site"], f"N={N} t={t} site")
+                assert_bits(eng.site_af(), res["af"], "af")
+                win = eng.window_ll(i)
+                assert_bits(win[:, 2], res["win"][:, 2], "LIBD2")
+                assert_ld_close(win[:, :2], res["win"][:, :2], f"N={N} t={t} pu={pu} LD")
+                first, last, ncov = eng.windows()
+                assert (first == res["first"]).all() and (last == res["last"]).all()
+                assert (ncov == res["nsites"]).all()
+        eng.run(targets[:1], ld=False)
+        res = oracle.compare(alle, nr, na, targets[0], window=W, ld=False)
+        assert_bits(eng.window_ll(0), res["win"], "non-LD windows")
+
+
+def test_row_indirection_and_zero_coverage(oracle):
+    """Sites reference panel rows through row_index (filtered rows are never touched)."""
+    N, Lp = 130, 900
+    alle, nr, na = synth(7, Lp, N)
+    rng = np.random.default_rng(8)
+    keep = np.sort(rng.choice(Lp, size=500, replace=False))
+    nr, na = nr[keep].copy(), na[keep].copy()
+    nr[::7] = 0
+    na[::7] = 0                                     # zero-coverage rows: printed, not windowed
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(keep, nr, na, 50)
+        eng.run([5], ld=True)
+        res = oracle.compare(alle[keep], nr, na, 5, window=50, ld=True)
+        assert_bits(eng.site_ll(0), res["site"], "site")
+        assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "LD")
+        assert (eng.windows()[2] == res["nsites"]).all()
+        zero = (nr.astype(int) + na) == 0
+        assert (eng.site_ll(0)[zero, 0] == 1.0).all() and (eng.site_ll(0)[zero, 2] == 1.0).all()
+
+
+def test_tiling_options_do_not_change_results(oracle):
+    N, L = 700, 450
+    alle, nr, na = synth(11, L, N)
+    ref = None
+    for cpw in (1, 2, 3, 4, 5):
+        for waves in (1, 3, 8):
+            with E.Engine() as eng:
+                eng.set_option("chunks_per_wave", cpw)
+                eng.set_option("waves_per_block", waves)
+                eng.upload_panel(E.pack_alleles_fast(alle), N)
+                eng.upload_sites(np.arange(L), nr, na, 100)
+                eng.run([3, 699], ld=True)
+                got = np.stack([eng.window_ll(0), eng.window_ll(1)])
+            if ref is None:
+                ref = got
+                res = oracle.compare(alle, nr, na, 3, window=100, ld=True)
+                assert_ld_close(got[0][:, :2], res["win"][:, :2], "cpw=1")
+            else:
+                assert_ld_close(got[..., :2], ref[..., :2], f"cpw={cpw} waves={waves}")
+                assert_bits(got[..., 2], ref[..., 2], "LIBD2")
+
+
+def test_background_subsets_duplicates_and_empty(oracle):
+    N, L = 90, 400
+    alle, nr, na = synth(21, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        for refids in ([1, 2, 3, 70, 89], [5, 5, 6, 88, 5], [4], list(range(0, 90, 3))):
+            eng.run([4], ld=True, bg_count=bg_counts(refids, N), pu_id=6)
+            res = oracle.compare(alle, nr, na, 4, window=100, ld=True, refids=refids, pu_id=6)
+            assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"bg={refids[:5]}")
+        # background = {target}: n_refpanel = 0 -> NaN like the reference's 0/0
+        eng.run([4], ld=True, bg_count=bg_counts([4], N))
+        assert np.isnan(eng.window_ll(0)[:, :2]).all()
+        assert not np.isnan(eng.window_ll(0)[:, 2]).any()
+
+
+def test_counting_inside_run_and_determinism():
+    N, L = 200, 600
+    alle, nr, na = synth(31, L, N)
+    outs = []
+    for opt in (0, 1):
+        with E.Engine() as eng:
+            eng.set_option("count_in_run", opt)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, 100)
+            for _ in range(2):
+                eng.run([0, 1], ld=True)
+                outs.append((eng.site_ll(1), eng.window_ll(1), eng.site_af()))
+            ms = eng.last_run_ms()
+            assert (ms["alt_count"] > 0) == bool(opt) and ms["ld"] > 0 and ms["total"] >= ms["ld"]
+            assert (eng.alt_counts(0, L) == alle.sum(axis=1)).all()
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert_bits(a, b, "run-to-run / option determinism")
+
+
+def test_error_behaviour():
+    alle, nr, na = synth(41, 50, 10)
+    with E.Engine() as eng:
+        with pytest.raises(E.EngineError, match="no panel"):
+            eng.upload_sites(np.arange(5), nr[:5], na[:5], 100)
+        eng.upload_panel(E.pack_alleles_fast(alle), 10)
+        with pytest.raises(E.EngineError, match="no sites"):
+            eng.run([0])
+        with pytest.raises(E.EngineError, match="outside the panel"):
+            eng.upload_sites([50], [1], [1], 100)
+        with pytest.raises(E.EngineError, match="max_cov"):
+            eng.upload_sites([0], [15], [6], 100)
+        with pytest.raises(E.EngineError, match="window"):
+            eng.upload_sites([0], [1], [1], 0)
+        eng.upload_sites(np.arange(50), nr, na, 100)
+        with pytest.raises(E.EngineError, match="not a panel individual"):
+            eng.run([10])
+        with pytest.raises(E.EngineError, match="unknown option"):
+            eng.set_option("nope", 1)
+        # empty site list: zero windows, no crash
+        eng.upload_sites(np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros(0, np.uint8), 100)
+        eng.run([0])
+        assert eng.n_windows == 0 and eng.window_ll(0).shape == (0, 3)
+    with pytest.raises(E.EngineError, match="-M"):
+        E.Engine(0, 0.02, 0)
+    with pytest.raises(E.EngineError, match="out of range"):
+        E.Engine(99)
+
+
+def test_all_sites_zero_coverage():
+    alle, nr, na = synth(51, 30, 70)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), 70)
+        eng.upload_sites(np.arange(30), np.zeros(30, np.uint8), np.zeros(30, np.uint8), 100)
+        eng.run([1], ld=True)
+        assert eng.n_windows == 0
+        assert (eng.site_ll(0)[:, [0, 2]] == 1.0).all()
