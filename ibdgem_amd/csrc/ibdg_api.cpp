@@ -59,6 +59,15 @@ struct ibdg_ctx {
     uint32_t n_cov = 0, window = 0, n_win = 0;
     std::vector<uint32_t> cov_site_h;
 
+    // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
+    DevBuf t32, segs, wconst, wtarget, pow1, pow2, partial;
+    uint32_t n_tiles = 0, n_segs = 0, ct_max = 0;
+    int planes = 0;
+    bool pop_lut_ok = false;     // P(D|G) table is the unclamped binomial form
+    bool pop_sites_ok = false;   // site rows strictly increasing, segments built
+    std::vector<unsigned long> nck_h;
+    int last_variant = 0;
+
     // run state / results
     DevBuf targets, weight, nrefpanel, af, site_ll, win_ll;
     size_t n_targets = 0;
@@ -69,7 +78,8 @@ struct ibdg_ctx {
     long opt_count_in_run = 0;
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
-    long opt_variant = 0;
+    long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
+    long opt_wpg = 32;     // windows per wave in the fast kernel
 };
 
 namespace {
@@ -159,6 +169,59 @@ void build_pdg_table(double eps, unsigned M, double *out)
     }
 }
 
+// x = m * 2^e, m in [0.5,1): extended-precision mantissa so that tables of b^n stay accurate
+// to ~1e-19 for any n (plain pow underflows long before n*log2(b) leaves the int range).
+struct ME {
+    long double m;
+    long long e;
+};
+
+ME me_norm(long double x, long long e)
+{
+    int k = 0;
+    long double m = frexpl(x, &k);
+    return ME{m, e + k};
+}
+
+ME me_pow(double base, uint64_t n)
+{
+    ME r = me_norm(1.0L, 0), b = me_norm((long double)base, 0);
+    while (n) {
+        if (n & 1)
+            r = me_norm(r.m * b.m, r.e + b.e);
+        b = me_norm(b.m * b.m, 2 * b.e);
+        n >>= 1;
+    }
+    return r;
+}
+
+// The fast --LD kernel replaces products of table entries by K*(1-e)^E1*e^E2*2^-E3.  That is
+// only the same number when every reachable entry IS C*(1-e)^r*e^a etc. to rounding: no
+// DBL_MIN clamp (src/ibd-math.c:77-79), no overflowed coefficient, 0 < e < 1.
+bool lut_is_binomial(const std::vector<double> &lut, const std::vector<unsigned long> &nck, double eps,
+                     unsigned M)
+{
+    if (!(eps > 0.0 && eps < 1.0) || M > 50)
+        return false;
+    const size_t d = (size_t)M + 1;
+    const long double b = (long double)(double)(1 - eps), e = (long double)eps;
+    for (size_t r = 0; r < d; ++r)
+        for (size_t a = 0; a + r <= M; ++a) {
+            if (r + a == 0)
+                continue;
+            const long double c = (long double)nck[(r + a) * d + r];
+            const long double want[3] = {c * powl(b, (long double)r) * powl(e, (long double)a),
+                                         c * powl(0.5L, (long double)(r + a)),
+                                         c * powl(b, (long double)a) * powl(e, (long double)r)};
+            for (int g = 0; g < 3; ++g) {
+                const long double got = lut[(r * d + a) * 3 + g];
+                if (!(want[g] > 1e-280L) || fabsl(got - want[g]) > 1e-14L * want[g])
+                    return false;
+            }
+        }
+    return true;
+}
+
 int pick_cpw(uint32_t n_chunks, long opt)
 {
     if (opt >= 1 && opt <= 5)
@@ -181,7 +244,11 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
     c->stride = 2u * c->cpw * c->n_groups;
     c->counts_valid = false;
     c->have_results = false;
+    c->pop_sites_ok = false;
+    c->n_tiles = (uint32_t)((n_rows + 31) / 32);
     if (ensure(c, c->panel, n_rows * (size_t)c->stride * 8) || ensure(c, c->alt_count, n_rows * 4))
+        return 1;
+    if (c->pop_lut_ok && ensure(c, c->t32, (size_t)c->n_chunks * c->n_tiles * 64 * 8))
         return 1;
     // pow(1-f,2.0), pow(f,2.0) for every possible alt count (src/ibd-math.c:93-95 with
     // f = k/(2N), src/ibd-parse.c:98)
@@ -213,7 +280,87 @@ int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
         HIP_TRY(c, hipGetLastError());
         c->counts_valid = true;
     }
+    if (c->pop_lut_ok) {
+        // second resident layout of the same bits for the fast --LD kernel
+        ibdg::launch_transpose32((const uint64_t *)c->panel.p, c->stride, n_rows, c->n_chunks, c->n_tiles,
+                                 (uint32_t *)c->t32.p, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Segments, per-window constants and power tables of the fast --LD kernel
+// (host integer work over the covered rows, once per ibdg_upload_sites).
+int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t *n_ref, const uint8_t *n_alt)
+{
+    c->pop_sites_ok = false;
+    if (!c->pop_lut_ok || c->n_cov == 0)
+        return 0;
+    for (size_t j = 1; j < rec_cov.size(); ++j)
+        if (rec_cov[j].x <= rec_cov[j - 1].x)
+            return 0;                      // not in file order: only the strict kernel applies
+    const size_t d = (size_t)c->max_cov + 1;
+    std::vector<ibdg::Seg> segs;
+    std::vector<ibdg::WinConst> wc(c->n_win + 1);
+    segs.reserve(c->n_cov / 8 + c->n_win + 16);
+    uint32_t ct_max = 0;
+    for (uint32_t w = 0; w < c->n_win; ++w) {
+        const uint32_t b = w * c->window, e = (uint32_t)std::min<uint64_t>((uint64_t)b + c->window, c->n_cov);
+        ME K = me_norm(1.0L, 0);
+        uint32_t ct = 0, at = 0;
+        wc[w].seg_begin = (uint32_t)segs.size();
+        for (uint32_t j = b; j < e; ++j) {
+            const uint32_t s = c->cov_site_h[j];
+            const unsigned r = n_ref[s], a = n_alt[s], cv = r + a;
+            const uint32_t row = rec_cov[j].x, tile = row >> 5, bit = 1u << (row & 31);
+            if (segs.size() == wc[w].seg_begin || segs.back().tile != tile) {
+                ibdg::Seg sg;
+                memset(&sg, 0, sizeof sg);
+                sg.tile = tile;
+                sg.win = w;
+                segs.push_back(sg);
+            }
+            ibdg::Seg &sg = segs.back();
+            for (int k = 0; k < 8; ++k) {
+                if ((cv >> k) & 1) sg.cov[k] |= bit;
+                if ((a >> k) & 1) sg.alt[k] |= bit;
+            }
+            ct += cv;
+            at += a;
+            K = me_norm(K.m * (long double)c->nck_h[(size_t)cv * d + r], K.e);
+        }
+        segs.back().last = 1;
+        wc[w].mK = (double)K.m;
+        wc[w].eK = (int32_t)K.e;
+        wc[w].cov_total = ct;
+        wc[w].alt_total = at;
+        ct_max = std::max(ct_max, ct);
+    }
+    wc[c->n_win].seg_begin = (uint32_t)segs.size();
+    wc[c->n_win].mK = 0;
+    wc[c->n_win].eK = 0;
+    wc[c->n_win].cov_total = wc[c->n_win].alt_total = 0;
+    c->n_segs = (uint32_t)segs.size();
+    c->ct_max = ct_max;
+    std::vector<ibdg::PowEntry> p1(ct_max + 1), p2(ct_max + 1);
+    const double b1 = 1 - c->eps;
+    for (uint32_t n = 0; n <= ct_max; ++n) {
+        const ME x = me_pow(b1, n), y = me_pow(c->eps, n);
+        if (x.e < -2000000000LL || y.e < -2000000000LL)
+            return 0;
+        p1[n].m = (double)x.m; p1[n].e = (int32_t)x.e; p1[n].pad = 0;
+        p2[n].m = (double)y.m; p2[n].e = (int32_t)y.e; p2[n].pad = 0;
+    }
+    if (ensure(c, c->segs, segs.size() * sizeof(ibdg::Seg)) || ensure(c, c->wconst, wc.size() * sizeof(ibdg::WinConst)) ||
+        ensure(c, c->pow1, p1.size() * sizeof(ibdg::PowEntry)) || ensure(c, c->pow2, p2.size() * sizeof(ibdg::PowEntry)))
+        return 1;
+    HIP_TRY(c, hipMemcpyAsync(c->segs.p, segs.data(), segs.size() * sizeof(ibdg::Seg), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->wconst.p, wc.data(), wc.size() * sizeof(ibdg::WinConst), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pow1.p, p1.data(), p1.size() * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pow2.p, p2.data(), p2.size() * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pop_sites_ok = true;
     return 0;
 }
 
@@ -276,6 +423,11 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     const size_t d = (size_t)max_cov + 1;
     c->lut_h.resize(d * d * 3);
     build_pdg_table(epsilon, max_cov, c->lut_h.data());
+    c->nck_h = nck_table(max_cov);
+    c->pop_lut_ok = lut_is_binomial(c->lut_h, c->nck_h, epsilon, max_cov);
+    c->planes = 1;
+    while ((1u << c->planes) <= max_cov)
+        ++c->planes;
     if (ensure(c, c->lut, c->lut_h.size() * 8)) {
         g_create_error = c->err;
         ibdg_destroy(c);
@@ -294,7 +446,8 @@ void ibdg_destroy(ibdg_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
-                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll})
+                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
+                      &c->segs, &c->wconst, &c->wtarget, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &ev : c->ev)
         if (ev)
@@ -425,7 +578,7 @@ int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_r
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return build_segments(c, rec_cov, n_ref, n_alt);
 }
 
 size_t ibdg_num_sites(const ibdg_ctx *c) { return c ? c->n_sites : 0; }
@@ -511,7 +664,45 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     ibdg::launch_site(sa, (unsigned)T, c->stream);
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
 
+    bool use_pop = false;
     if (ld_mode) {
+        const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
+        if (c->opt_variant == 2 && !can)
+            return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
+                           "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
+        use_pop = can && c->opt_variant != 1;
+    }
+    c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
+    if (use_pop) {
+        if (ensure(c, c->wtarget, T * (size_t)c->n_win * sizeof(ibdg::WinTarget)) ||
+            ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
+            return 1;
+        ibdg::PopArgs pa;
+        pa.t32 = (const uint32_t *)c->t32.p;
+        pa.n_tiles = c->n_tiles;
+        pa.n_chunks = c->n_chunks;
+        pa.segs = (const ibdg::Seg *)c->segs.p;
+        pa.wconst = (const ibdg::WinConst *)c->wconst.p;
+        pa.n_win = c->n_win;
+        pa.win_per_group = (uint32_t)c->opt_wpg;
+        pa.wtarget = (const ibdg::WinTarget *)c->wtarget.p;
+        pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
+        pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
+        pa.targets = sa.targets;
+        pa.weight = (const double *)c->weight.p;
+        pa.lanes = (uint32_t)lanes;
+        pa.partial = (double *)c->partial.p;
+        ibdg::launch_win_target(pa, (unsigned)T, c->stream);
+        if (ibdg::launch_ld_popcount(pa, (unsigned)T, c->planes, c->stream))
+            return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
+        ibdg::PopFinalArgs fa;
+        fa.partial = pa.partial;
+        fa.n_win = c->n_win;
+        fa.n_chunks = c->n_chunks;
+        fa.n_refpanel = (const int *)c->nrefpanel.p;
+        fa.win_ll = (double *)c->win_ll.p;
+        ibdg::launch_ld_finalize(fa, (unsigned)T, c->stream);
+    } else if (ld_mode) {
         ibdg::LdArgs la;
         la.panel = sa.panel;
         la.stride = c->stride;
@@ -600,6 +791,8 @@ int ibdg_last_run_ms(const ibdg_ctx *c, float out[5])
     return 0;
 }
 
+int ibdg_last_ld_variant(const ibdg_ctx *c) { return c ? c->last_variant : 0; }
+
 int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 {
     if (!c || !name) return 1;
@@ -612,7 +805,14 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         if (value < 1 || value > 8) return fail(c, "[::] ERROR in ibdg_set_option: waves_per_block must be 1..8");
         c->opt_waves = value; return 0;
     }
-    if (!strcmp(name, "ld_variant")) { c->opt_variant = value; return 0; }
+    if (!strcmp(name, "ld_variant")) {
+        if (value < 0 || value > 2) return fail(c, "[::] ERROR in ibdg_set_option: ld_variant must be 0 (auto), 1 (strict) or 2 (exponent counting)");
+        c->opt_variant = value; return 0;
+    }
+    if (!strcmp(name, "windows_per_wave")) {
+        if (value < 1 || value > 65536) return fail(c, "[::] ERROR in ibdg_set_option: windows_per_wave must be 1..65536");
+        c->opt_wpg = value; return 0;
+    }
     return fail(c, "[::] ERROR in ibdg_set_option: unknown option '%s'", name);
 }
 

@@ -48,6 +48,70 @@ struct LdArgs {
     double *win_ll;             // [T][n_win][3]
 };
 
+// ---- fast --LD variant: exponent counting on the tile-transposed panel -------------------
+// One segment = the covered rows of ONE window that fall into ONE 32-row tile.
+// cov[k]/alt[k]: bit j set <=> row 32*tile+j is such a row and bit k of its
+// n_ref+n_alt (resp. n_alt) is set.
+struct Seg {
+    uint32_t tile;
+    uint32_t win;        // window index
+    uint32_t last;       // 1 = last segment of its window
+    uint32_t pad;
+    uint32_t cov[8];
+    uint32_t alt[8];
+};                       // 80 bytes
+
+// (1-eps)^E or eps^E as m * 2^e with m in [0.5,1]
+struct PowEntry {
+    double m;
+    int32_t e;
+    int32_t pad;
+};
+
+// per window, target independent
+struct WinConst {
+    double mK;           // prod of the binomial coefficients C(cov,n_ref) = mK * 2^eK
+    int32_t eK;
+    uint32_t cov_total;  // sum of n_ref+n_alt over the window's rows
+    uint32_t alt_total;  // sum of n_alt
+    uint32_t seg_begin;  // first segment of the window
+};                       // 24 bytes
+
+// per (target, window)
+struct WinTarget {
+    uint32_t a0cov, a1cov, a0alt, a1alt;   // <target haplotype, cov> and <target haplotype, alt>
+};
+
+struct PopArgs {
+    const uint32_t *t32;        // [n_chunks_pad][n_tiles][64][2] tile-transposed panel
+    uint32_t n_tiles;
+    uint32_t n_chunks;          // chunks that hold individuals
+    const Seg *segs;
+    const WinConst *wconst;     // [n_win + 1] (the extra entry carries seg_begin = n_segs)
+    uint32_t n_win;
+    uint32_t win_per_group;
+    const WinTarget *wtarget;   // [T][n_win]
+    const PowEntry *pow_1me;    // [(max cov_total)+1]
+    const PowEntry *pow_eps;
+    const uint32_t *targets;    // [T]
+    const double *weight;       // [T][lanes] background multiplicity (0 = excluded)
+    uint32_t lanes;             // stride of weight per target
+    double *partial;            // [T][n_win][n_chunks][2]
+};
+
+struct PopFinalArgs {
+    const double *partial;
+    uint32_t n_win, n_chunks;
+    const int *n_refpanel;
+    double *win_ll;
+};
+
+void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
+                        uint32_t n_tiles, uint32_t *t32, hipStream_t st);
+void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st);
+int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st);
+void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st);
+
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st);
 void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st);

@@ -141,10 +141,17 @@ int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out
  * kernel, out[3] LD window kernel, out[4] window-product kernel (ms). */
 int ibdg_last_run_ms(const ibdg_ctx *ctx, float out[5]);
 
+/* Which --LD kernel the last ibdg_run used: 0 none (non-LD), 1 the strict
+ * kernel (sequential fp64 products in the reference's order), 2 the
+ * exponent-counting kernel (same values to ~1e-14). */
+int ibdg_last_ld_variant(const ibdg_ctx *ctx);
+
 /* Options: "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
- * so the timed region covers it), "chunks_per_wave" (LD kernel tiling, before
- * ibdg_upload_panel), "waves_per_block", "ld_variant".  Returns non-zero for an unknown
- * name or a value out of range. */
+ * so the timed region covers it); "ld_variant" (0 = pick automatically,
+ * 1 = strict, 2 = exponent counting, an error if not applicable);
+ * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
+ * "waves_per_block" (strict kernel), "windows_per_wave" (exponent-counting
+ * kernel).  Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
 
 /* Block until all work queued on the engine's stream is done. */

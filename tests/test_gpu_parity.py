@@ -96,11 +96,16 @@ def _syn_cases():
     return [(tag, case) for tag in ("synA", "synB") for case in G.cases(tag)["cases"]]
 
 
+VARIANTS = [1, 2]      # 1 = strict fp64 products, 2 = exponent counting (see include/ibdgem_hip.h)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("tag,case", _syn_cases())
-def test_reference_17digit_outputs(tag, case, oracle):
+def test_reference_17digit_outputs(tag, case, variant, oracle):
     flags, panel, names, refids, pu_id, per_target = G.case_setup(tag, case)
     n_ids = len(panel.names)
     with E.Engine(0, flags["eps"], flags["max_cov"]) as eng:
+        eng.set_option("ld_variant", variant)
         eng.upload_panel(E.pack_alleles_fast(panel.alleles), n_ids)
         cnt = eng.alt_counts(0, len(panel.pos))
         assert (cnt == panel.alleles.sum(axis=1)).all()
@@ -110,6 +115,7 @@ def test_reference_17digit_outputs(tag, case, oracle):
             eng.upload_sites(rows, tab.n_ref, tab.n_alt, flags["window"], f_override=fo)
             eng.run([t], ld=flags["ld"], bg_count=bg_counts(refids, n_ids), pu_id=pu_id)
             assert eng.n_sites == len(tab.pos) == tab.processed
+            assert eng.last_ld_variant() == (variant if flags["ld"] else 0)
             assert_bits(eng.site_ll(0), tab.ll, f"{tag}/{case}/{name} per-site")
             af = eng.site_af()
             assert ["%f" % x for x in af] == tab.af_txt
@@ -141,12 +147,14 @@ def synth(seed, L, N, cov_mean=2.0):
     return alle, (cov - n_alt).astype(np.uint8), n_alt.astype(np.uint8)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("N,L,W", [(3, 257, 100), (64, 500, 100), (65, 300, 7), (100, 1500, 100),
                                    (320, 700, 64), (321, 400, 100), (2504, 1200, 100), (700, 350, 350)])
-def test_random_panels_against_oracle(oracle, N, L, W):
+def test_random_panels_against_oracle(oracle, N, L, W, variant):
     alle, nr, na = synth(1000 + N, L, N)
     targets = sorted({0, N // 2, N - 1})
     with E.Engine() as eng:
+        eng.set_option("ld_variant", variant)
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(np.arange(L), nr, na, W)
         for pu in (-1, targets[-1]):
@@ -166,7 +174,8 @@ def test_random_panels_against_oracle(oracle, N, L, W):
         assert_bits(eng.window_ll(0), res["win"], "non-LD windows")
 
 
-def test_row_indirection_and_zero_coverage(oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_row_indirection_and_zero_coverage(oracle, variant):
     """Sites reference panel rows through row_index (filtered rows are never touched)."""
     N, Lp = 130, 900
     alle, nr, na = synth(7, Lp, N)
@@ -176,6 +185,7 @@ def test_row_indirection_and_zero_coverage(oracle):
     nr[::7] = 0
     na[::7] = 0                                     # zero-coverage rows: printed, not windowed
     with E.Engine() as eng:
+        eng.set_option("ld_variant", variant)
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(keep, nr, na, 50)
         eng.run([5], ld=True)
@@ -209,10 +219,12 @@ def test_tiling_options_do_not_change_results(oracle):
                 assert_bits(got[..., 2], ref[..., 2], "LIBD2")
 
 
-def test_background_subsets_duplicates_and_empty(oracle):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_background_subsets_duplicates_and_empty(oracle, variant):
     N, L = 90, 400
     alle, nr, na = synth(21, L, N)
     with E.Engine() as eng:
+        eng.set_option("ld_variant", variant)
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(np.arange(L), nr, na, 100)
         for refids in ([1, 2, 3, 70, 89], [5, 5, 6, 88, 5], [4], list(range(0, 90, 3))):
@@ -282,3 +294,85 @@ def test_all_sites_zero_coverage():
         eng.run([1], ld=True)
         assert eng.n_windows == 0
         assert (eng.site_ll(0)[:, [0, 2]] == 1.0).all()
+
+
+# --------------------------------------------------------------------------- kernel selection
+def test_kernel_selection_and_fallback(oracle):
+    """Auto picks the exponent-counting kernel when the P(D|G) table is the plain binomial
+    form and the rows are in file order; otherwise the strict kernel (never an error)."""
+    N, L = 150, 500
+    alle, nr, na = synth(61, L, N)
+    with E.Engine(0, 0.02, 20) as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 2
+        fast = eng.window_ll(0)
+        eng.set_option("ld_variant", 1)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 1
+        assert_ld_close(fast[:, :2], eng.window_ll(0)[:, :2], "fast vs strict")
+        assert_bits(fast[:, 2], eng.window_ll(0)[:, 2], "LIBD2")
+        # rows out of file order: only the strict kernel applies
+        eng.set_option("ld_variant", 0)
+        perm = np.arange(L)
+        perm[[3, 4]] = perm[[4, 3]]
+        eng.upload_sites(perm, nr[perm], na[perm], 100)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 1
+        res = oracle.compare(alle[perm], nr[perm], na[perm], 1, window=100, ld=True)
+        assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "permuted rows")
+        eng.set_option("ld_variant", 2)
+        with pytest.raises(E.EngineError, match="not applicable"):
+            eng.run([1], ld=True)
+    # epsilon so small that e^a underflows: the reference clamps P(D|G) to DBL_MIN
+    # (src/ibd-math.c:77-79); the product form does not hold, strict kernel is used
+    with E.Engine(0, 1e-30, 20) as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 1
+        res = oracle.compare(alle, nr, na, 1, window=100, ld=True, eps=1e-30)
+        assert_bits(eng.site_ll(0), res["site"], "site eps=1e-30")
+        assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "eps=1e-30")
+
+
+@pytest.mark.parametrize("eps,M,cov", [(0.02, 20, 9.0), (0.2, 7, 3.0), (0.001, 40, 15.0), (0.45, 3, 1.0)])
+def test_exponent_counting_other_error_rates_and_depths(oracle, eps, M, cov):
+    N, L = 200, 900
+    rng = np.random.default_rng(int(cov * 10))
+    f = np.clip(rng.beta(0.3, 1.0, size=L), 1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    with E.Engine(0, eps, M) as eng:
+        eng.set_option("ld_variant", 2)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        for W in (100, 33):
+            eng.upload_sites(np.arange(L), nr, na, W)
+            eng.run([0, 199], ld=True, pu_id=5)
+            for i, t in enumerate((0, 199)):
+                res = oracle.compare(alle, nr, na, t, window=W, ld=True, eps=eps, max_cov=M, pu_id=5)
+                assert_bits(eng.site_ll(i), res["site"], "site")
+                assert_ld_close(eng.window_ll(i)[:, :2], res["win"][:, :2], f"eps={eps} M={M} W={W}")
+
+
+def test_windows_per_wave_option(oracle):
+    N, L = 130, 2000
+    alle, nr, na = synth(71, L, N)
+    ref = None
+    for wpw in (1, 2, 7, 32, 1000):
+        with E.Engine() as eng:
+            eng.set_option("ld_variant", 2)
+            eng.set_option("windows_per_wave", wpw)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, 50)
+            eng.run([2], ld=True)
+            got = eng.window_ll(0)
+        if ref is None:
+            ref = got
+            res = oracle.compare(alle, nr, na, 2, window=50, ld=True)
+            assert_ld_close(got[:, :2], res["win"][:, :2], "wpw=1")
+        else:
+            assert_bits(got, ref, f"windows_per_wave={wpw}")
