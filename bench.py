@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="ld_variant option of the engine")
     ap.add_argument("--cpw", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -245,6 +246,9 @@ def main():
         eng.set_option("chunks_per_wave", args.cpw)
     if args.waves is not None:
         eng.set_option("waves_per_block", args.waves)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
     sample_rows = min(args.cpu_sample_rows, panel.shape[0])
     sample_words = panel[:sample_rows].cpu().numpy().view(np.uint64) if rank == 0 else None

@@ -60,8 +60,10 @@ struct ibdg_ctx {
     std::vector<uint32_t> cov_site_h;
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
-    DevBuf t32, segs, wconst, wtarget, pow1, pow2, partial;
-    uint32_t n_tiles = 0, n_segs = 0, ct_max = 0;
+    DevBuf t32, segs, wconst, wtarget, twords, pow1, pow2, partial;
+    uint32_t wpg = 0, max_seg = 0;     // windows per workgroup run and its largest segment count
+    int tab_in_lds = 0;
+    uint32_t n_pairs = 0, n_segs = 0, ct_max = 0;
     int planes = 0;
     bool pop_lut_ok = false;     // P(D|G) table is the unclamped binomial form
     bool pop_sites_ok = false;   // site rows strictly increasing, segments built
@@ -79,7 +81,9 @@ struct ibdg_ctx {
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
-    long opt_wpg = 32;     // windows per wave in the fast kernel
+    long opt_wpg = 16;     // windows per wave in the fast kernel
+    long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
+    long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
 
 namespace {
@@ -245,10 +249,10 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
     c->counts_valid = false;
     c->have_results = false;
     c->pop_sites_ok = false;
-    c->n_tiles = (uint32_t)((n_rows + 31) / 32);
+    c->n_pairs = (uint32_t)(((n_rows + 255) / 256) * 4);     // 64-row tile pairs, padded to whole 8-tile octs
     if (ensure(c, c->panel, n_rows * (size_t)c->stride * 8) || ensure(c, c->alt_count, n_rows * 4))
         return 1;
-    if (c->pop_lut_ok && ensure(c, c->t32, (size_t)c->n_chunks * c->n_tiles * 64 * 8))
+    if (c->pop_lut_ok && ensure(c, c->t32, (size_t)c->n_chunks * c->n_pairs * 64 * 16))
         return 1;
     // pow(1-f,2.0), pow(f,2.0) for every possible alt count (src/ibd-math.c:93-95 with
     // f = k/(2N), src/ibd-parse.c:98)
@@ -282,7 +286,7 @@ int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
     }
     if (c->pop_lut_ok) {
         // second resident layout of the same bits for the fast --LD kernel
-        ibdg::launch_transpose32((const uint64_t *)c->panel.p, c->stride, n_rows, c->n_chunks, c->n_tiles,
+        ibdg::launch_transpose32((const uint64_t *)c->panel.p, c->stride, n_rows, c->n_chunks, c->n_pairs,
                                  (uint32_t *)c->t32.p, c->stream);
         HIP_TRY(c, hipGetLastError());
     }
@@ -337,7 +341,36 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         wc[w].alt_total = at;
         ct_max = std::max(ct_max, ct);
     }
+    for (size_t i = 0; i < segs.size(); ++i) {
+        ibdg::Seg &sg = segs[i];
+        uint32_t nc = 0, na = 0;
+        for (int k = 0; k < 8; ++k) {
+            if (sg.cov[k]) nc = k + 1;
+            if (sg.alt[k]) na = k + 1;
+        }
+        const uint32_t delta = i + 1 < segs.size() ? segs[i + 1].tile - sg.tile : 0;
+        if (delta > 0xffff)
+            return 0;                      // rows too far apart for the record format: strict kernel
+        sg.flags = nc | (na << 8) | (delta << 16);
+    }
     wc[c->n_win].seg_begin = (uint32_t)segs.size();
+    // windows per workgroup run: as many as keep the run's records within the LDS budget
+    {
+        uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
+        for (;; g = (g + 1) / 2) {
+            uint32_t mx = 0;
+            for (uint32_t w = 0; w < c->n_win; w += g)
+                mx = std::max(mx, wc[std::min(w + g, c->n_win)].seg_begin - wc[w].seg_begin);
+            if ((size_t)mx * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1) {
+                c->wpg = g;
+                c->max_seg = mx;
+                break;
+            }
+        }
+        c->tab_in_lds = (size_t)(ct_max + 1) * 32 <= 24 * 1024;
+        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, (int)c->opt_ring) > 150 * 1024)
+            return 0;                      // a single window with thousands of tiles: strict kernel
+    }
     wc[c->n_win].mK = 0;
     wc[c->n_win].eK = 0;
     wc[c->n_win].cov_total = wc[c->n_win].alt_total = 0;
@@ -447,7 +480,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->wconst, &c->wtarget, &c->pow1, &c->pow2, &c->partial})
+                      &c->segs, &c->wconst, &c->wtarget, &c->twords, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &ev : c->ev)
         if (ev)
@@ -675,16 +708,20 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     if (use_pop) {
         if (ensure(c, c->wtarget, T * (size_t)c->n_win * sizeof(ibdg::WinTarget)) ||
+            ensure(c, c->twords, T * (size_t)c->n_segs * 8) ||
             ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
             return 1;
         ibdg::PopArgs pa;
         pa.t32 = (const uint32_t *)c->t32.p;
-        pa.n_tiles = c->n_tiles;
+        pa.n_pairs = c->n_pairs;
         pa.n_chunks = c->n_chunks;
         pa.segs = (const ibdg::Seg *)c->segs.p;
+        pa.n_segs = c->n_segs;
+        pa.max_seg = c->max_seg;
+        pa.twords = (const uint2 *)c->twords.p;
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
-        pa.win_per_group = (uint32_t)c->opt_wpg;
+        pa.win_per_group = c->wpg;
         pa.wtarget = (const ibdg::WinTarget *)c->wtarget.p;
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
@@ -692,6 +729,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.weight = (const double *)c->weight.p;
         pa.lanes = (uint32_t)lanes;
         pa.partial = (double *)c->partial.p;
+        pa.ring_slots = (uint32_t)c->opt_ring;
+        pa.tab_len = c->ct_max + 1;
+        pa.tab_in_lds = (uint32_t)c->tab_in_lds;
+        pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;
         ibdg::launch_win_target(pa, (unsigned)T, c->stream);
         if (ibdg::launch_ld_popcount(pa, (unsigned)T, c->planes, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
@@ -808,6 +849,14 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "ld_variant")) {
         if (value < 0 || value > 2) return fail(c, "[::] ERROR in ibdg_set_option: ld_variant must be 0 (auto), 1 (strict) or 2 (exponent counting)");
         c->opt_variant = value; return 0;
+    }
+    if (!strcmp(name, "ring_slots")) {
+        if (value != 4 && value != 8) return fail(c, "[::] ERROR in ibdg_set_option: ring_slots must be 4 or 8");
+        c->opt_ring = value; return 0;
+    }
+    if (!strcmp(name, "record_lds_bytes")) {
+        if (value < 1024 || value > 96 * 1024) return fail(c, "[::] ERROR in ibdg_set_option: record_lds_bytes must be 1024..98304");
+        c->opt_recbytes = value; return 0;
     }
     if (!strcmp(name, "windows_per_wave")) {
         if (value < 1 || value > 65536) return fail(c, "[::] ERROR in ibdg_set_option: windows_per_wave must be 1..65536");

@@ -56,7 +56,8 @@ struct Seg {
     uint32_t tile;
     uint32_t win;        // window index
     uint32_t last;       // 1 = last segment of its window
-    uint32_t pad;
+    uint32_t flags;      // bits 0-7: number of cov planes to visit (highest non-zero + 1),
+                         // bits 8-15: same for alt, bits 16-31: (next segment's tile) - tile
     uint32_t cov[8];
     uint32_t alt[8];
 };                       // 80 bytes
@@ -83,10 +84,13 @@ struct WinTarget {
 };
 
 struct PopArgs {
-    const uint32_t *t32;        // [n_chunks_pad][n_tiles][64][2] tile-transposed panel
-    uint32_t n_tiles;
+    const uint32_t *t32;        // [n_chunks][n_pairs][64] uint4: tile-transposed panel (see k_transpose32)
+    uint32_t n_pairs;           // tile pairs per chunk, a multiple of 4 (whole octs)
     uint32_t n_chunks;          // chunks that hold individuals
     const Seg *segs;
+    uint32_t n_segs;
+    uint32_t max_seg;           // most segments in one run of win_per_group windows (LDS sizing)
+    const uint2 *twords;        // [T][n_segs] the target's haplotype words of each segment's tile
     const WinConst *wconst;     // [n_win + 1] (the extra entry carries seg_begin = n_segs)
     uint32_t n_win;
     uint32_t win_per_group;
@@ -97,6 +101,10 @@ struct PopArgs {
     const double *weight;       // [T][lanes] background multiplicity (0 = excluded)
     uint32_t lanes;             // stride of weight per target
     double *partial;            // [T][n_win][n_chunks][2]
+    uint32_t ring_slots;        // 4 or 8 tile pairs of LDS ring per wave
+    uint32_t tab_len;           // entries per power table = (max cov_total) + 1
+    uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
+    uint32_t debug;             // timing experiments only (env IBDG_DEBUG): 1 skip window math, 2 skip counting
 };
 
 struct PopFinalArgs {
@@ -107,9 +115,11 @@ struct PopFinalArgs {
 };
 
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
-                        uint32_t n_tiles, uint32_t *t32, hipStream_t st);
+                        uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st);
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st);
+size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
+                             int ring_slots);
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st);
 
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,

@@ -34,55 +34,74 @@
 
 #include <hip/hip_runtime.h>
 
+// -DIBDG_TIMING_EXPERIMENT=1 builds the ablation switches read from PopArgs::debug
+// (env IBDG_DEBUG: 1 = skip the window math, 2 = skip the counting); never in a product build.
+#ifndef IBDG_TIMING_EXPERIMENT
+#define IBDG_TIMING_EXPERIMENT 0
+#endif
+
 namespace ibdg {
 
 // ---------------------------------------------------------------------------
-// Panel transposition (once per upload): site-major rows -> t32[chunk][tile][lane][plane],
-// bit j of a word = row 32*tile + j.  One wave per (tile, chunk); the row words are
-// wave-uniform, each lane extracts its own individual's bit.
+// Panel transposition (once per upload): site-major rows ->
+//     t32[chunk][tile_pair][lane] = uint4 { x0(tile 2q), x1(2q), x0(2q+1), x1(2q+1) }
+// x0/x1 = first/second haplotype of individual 64*chunk+lane, bit j = row 32*tile + j.
+// A wave reads one tile pair as one fully coalesced 1 KiB global_load_dwordx4, and the four
+// pairs of an 8-tile "oct" are 4 KiB contiguous.  Tiles are padded to whole octs (zero bits).
+// One wave per (tile pair, chunk); the row words are wave-uniform, each lane extracts its
+// own individual's bit.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_transpose32(const uint64_t *__restrict__ panel,
                                                      uint32_t stride, size_t n_rows,
-                                                     uint32_t n_chunks, uint32_t n_tiles,
-                                                     uint32_t *__restrict__ t32)
+                                                     uint32_t n_chunks, uint32_t n_pairs,
+                                                     uint4 *__restrict__ t32)
 {
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     const unsigned c = blockIdx.y * 4 + wave;
     if (c >= n_chunks)
         return;
-    const uint32_t tile = blockIdx.x;
-    uint32_t x0 = 0, x1 = 0;
-    const size_t r0 = (size_t)tile * 32;
+    const uint32_t pair = blockIdx.x;
+    uint32_t x[4] = {0, 0, 0, 0};
+    const size_t r0 = (size_t)pair * 64;
 #pragma unroll 8
-    for (unsigned j = 0; j < 32; ++j) {
+    for (unsigned j = 0; j < 64; ++j) {
         const size_t r = r0 + j;
         if (r < n_rows) {
             const uint64_t w0 = panel[r * stride + 2 * c], w1 = panel[r * stride + 2 * c + 1];
-            x0 |= (uint32_t)((w0 >> lane) & 1u) << j;
-            x1 |= (uint32_t)((w1 >> lane) & 1u) << j;
+            const uint32_t b0 = (uint32_t)((w0 >> lane) & 1u) << (j & 31);
+            const uint32_t b1 = (uint32_t)((w1 >> lane) & 1u) << (j & 31);
+            if (j < 32) { x[0] |= b0; x[1] |= b1; } else { x[2] |= b0; x[3] |= b1; }
         }
     }
-    uint2 *dst = reinterpret_cast<uint2 *>(t32) + ((size_t)c * n_tiles + tile) * 64 + lane;
-    *dst = make_uint2(x0, x1);
+    t32[((size_t)c * n_pairs + pair) * 64 + lane] = make_uint4(x[0], x[1], x[2], x[3]);
+}
+
+// the two haplotype words of one individual for one tile (wave-uniform address -> scalar load)
+__device__ __forceinline__ uint2 tile_words(const uint4 *__restrict__ base, uint32_t tile)
+{
+    const uint2 *p = reinterpret_cast<const uint2 *>(base + (size_t)(tile >> 1) * 64);
+    return p[tile & 1];
 }
 
 // ---------------------------------------------------------------------------
 // Per (window, target): <t0,cov>, <t1,cov>, <t0,alt>, <t1,alt> over the window's rows.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_win_target(PopArgs a, WinTarget *__restrict__ out)
+__global__ __launch_bounds__(256) void k_win_target(PopArgs a, WinTarget *__restrict__ out,
+                                                    uint2 *__restrict__ twords)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.n_win)
         return;
     const unsigned t = blockIdx.y;
     const uint32_t tgt = a.targets[t];
-    const uint2 *tt = reinterpret_cast<const uint2 *>(a.t32) + (size_t)(tgt >> 6) * a.n_tiles * 64 + (tgt & 63);
+    const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
     WinTarget r = {0, 0, 0, 0};
     const uint32_t s1 = a.wconst[w + 1].seg_begin;
     for (uint32_t s = a.wconst[w].seg_begin; s < s1; ++s) {
         const Seg &S = a.segs[s];
-        const uint2 at = tt[(size_t)S.tile * 64];
+        const uint2 at = tile_words(tt, S.tile);
+        twords[(size_t)t * a.n_segs + s] = at;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             r.a0cov += (uint32_t)__popc(at.x & S.cov[k]) << k;
@@ -93,39 +112,6 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, WinTarget *__rest
     }
     out[(size_t)t * a.n_win + w] = r;
 }
-
-// K * (1-e)^E1 * e^E2 * 2^-E3
-__device__ __forceinline__ double ld_value(const PopArgs &a, double mK, int eK, uint32_t E1,
-                                           uint32_t E2, uint32_t E3)
-{
-    const PowEntry p1 = a.pow_1me[E1];
-    const PowEntry p2 = a.pow_eps[E2];
-    const double m = (mK * p1.m) * p2.m;
-    return __builtin_ldexp(m, eK + p1.e + p2.e - (int)E3);
-}
-
-// A segment record held in (scalar) registers: five 16-byte loads.
-struct SegRegs {
-    uint4 h, c0, c1, a0, a1;
-    __device__ __forceinline__ void load(const Seg *p)
-    {
-        const uint4 *q = reinterpret_cast<const uint4 *>(p);
-        h = q[0]; c0 = q[1]; c1 = q[2]; a0 = q[3]; a1 = q[4];
-    }
-    __device__ __forceinline__ uint32_t tile() const { return h.x; }
-    __device__ __forceinline__ uint32_t win() const { return h.y; }
-    __device__ __forceinline__ uint32_t last() const { return h.z; }
-    __device__ __forceinline__ uint32_t cov(int k) const
-    {
-        return k == 0 ? c0.x : k == 1 ? c0.y : k == 2 ? c0.z : k == 3 ? c0.w
-             : k == 4 ? c1.x : k == 5 ? c1.y : k == 6 ? c1.z : c1.w;
-    }
-    __device__ __forceinline__ uint32_t alt(int k) const
-    {
-        return k == 0 ? a0.x : k == 1 ? a0.y : k == 2 ? a0.z : k == 3 ? a0.w
-             : k == 4 ? a1.x : k == 5 ? a1.y : k == 6 ? a1.z : a1.w;
-    }
-};
 
 template <int KP>
 __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
@@ -138,38 +124,159 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 }
 
 // ---------------------------------------------------------------------------
-// The --LD loop.  A wave owns one chunk of 64 background individuals (one per lane) and a
-// run of consecutive windows; it streams that chunk's tiles (contiguous in memory, 8 bytes
-// per lane and tile) exactly once.  Segment records (wave-uniform) arrive through the scalar
-// path; all-zero bit-planes are skipped by uniform branches.
+// The --LD loop.
+//
+// Work split: a workgroup = 8 waves = 8 chunks of 64 background individuals (one individual
+// per lane) x one run of `win_per_group` consecutive windows.  Each wave streams its chunk's
+// tile pairs exactly once.
+//
+// Data movement (all of it asynchronous to the arithmetic):
+//   * once per workgroup the run's segment records (+ the target's haplotype words per
+//     segment), the per-window constants and the two power tables are copied to LDS;
+//   * the wave's tile pairs go HBM -> LDS by direct-to-LDS loads (global_load_lds_dwordx4,
+//     1 KiB per instruction, no VGPRs) into a private ring of NS slots, NS-1 loads in flight
+//     while a pair is consumed.  Landing is tracked with counted s_waitcnt vmcnt
+//     (vector-memory ops of a wave complete in issue order).
+//   * a segment's record is read with ONE ds_read_b32 (word l -> lane l; fields are then
+//     picked with v_readlane into SGPRs and used as wave-uniform masks) and the lane's own
+//     two tile words with one ds_read_b64.
+//   All LDS reads in the loop are asm: hipcc drains vmcnt(0) before any LDS read that follows
+//   a direct-to-LDS load, which would serialise the ring (and so would table look-ups from
+//   global memory at the end of every window -- hence the tables in LDS).
+// Arithmetic per segment: for every weight bit-plane up to the highest non-empty one 14 VALU
+// ops for the seven cov-weighted counts and 4 for the two alt-weighted ones.
 // At the end of each window the lane turns its counts into the five products, the wave sums
 // count[n]*product over its 64 individuals (fixed shuffle order) and lane 0 stores the
 // per-chunk partial; k_ld_finalize adds the chunks in ascending order and divides.
 // ---------------------------------------------------------------------------
-// t32/segs/wconst are passed as __restrict__ kernel arguments as well as inside `a`: only
-// then does hipcc know they cannot alias the stores to a.partial and keep the wave-uniform
-// loads (segment records, the target's haplotype words) on the scalar path.
-template <int KP>
-__global__ __launch_bounds__(512) void k_ld_popcount(const uint2 *__restrict__ t32,
+typedef __attribute__((address_space(3))) void lds_void;
+
+// LDS image of a segment: the 20 words of Seg followed by the target's two haplotype words.
+#define IBDG_REC_WORDS 22
+enum { RW_TILE = 0, RW_WIN = 1, RW_LAST = 2, RW_FLAGS = 3, RW_COV = 4, RW_ALT = 12, RW_TW = 20 };
+// LDS image of a window's constants
+#define IBDG_WC_WORDS 12
+enum { WC_MK = 0, WC_EK = 2, WC_CT = 3, WC_AT = 4, WC_A0COV = 5, WC_A1COV = 6, WC_A0ALT = 7, WC_A1ALT = 8 };
+
+// Issue and wait in ONE statement: an asm output must be final when the statement ends,
+// because hipcc is free to copy it to another register right afterwards (it did, with the
+// wait in a later statement: the copy read the register before the LDS data had landed).
+// The LDS latency is covered by the other resident waves of the SIMD instead.
+__device__ __forceinline__ void lds_fetch(uint32_t &recw, uint2 &x, uint32_t rec_addr, uint32_t x_addr)
+{
+    asm volatile("ds_read_b32 %0, %2\n\t"
+                 "ds_read_b64 %1, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(recw), "=&v"(x)
+                 : "v"(rec_addr), "v"(x_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// ten power-table entries (16 B each) for the five products of one window
+__device__ __forceinline__ void lds_read_pow10(uint4 (&p)[10], const uint32_t (&ad)[10])
+{
+    asm volatile("ds_read_b128 %0, %10\n\t"
+                 "ds_read_b128 %1, %11\n\t"
+                 "ds_read_b128 %2, %12\n\t"
+                 "ds_read_b128 %3, %13\n\t"
+                 "ds_read_b128 %4, %14\n\t"
+                 "ds_read_b128 %5, %15\n\t"
+                 "ds_read_b128 %6, %16\n\t"
+                 "ds_read_b128 %7, %17\n\t"
+                 "ds_read_b128 %8, %18\n\t"
+                 "ds_read_b128 %9, %19\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]),
+                   "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                   "v"(ad[8]), "v"(ad[9])
+                 : "memory");
+}
+
+// K * (1-e)^E1 * e^E2 * 2^-E3 from two table entries {m (2 words), e, pad}
+__device__ __forceinline__ double ld_value(double mK, int eK, const uint4 &p1, const uint4 &p2, uint32_t E3)
+{
+    const double m1 = __hiloint2double((int)p1.y, (int)p1.x), m2 = __hiloint2double((int)p2.y, (int)p2.x);
+    const double m = (mK * m1) * m2;
+    return __builtin_ldexp(m, eK + (int)p1.z + (int)p2.z - (int)E3);
+}
+
+template <int KP, int NS, bool TAB_LDS>
+__global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
+                                                     const uint2 *__restrict__ twords,
                                                      const WinConst *__restrict__ wconst,
                                                      const WinTarget *__restrict__ wtarget,
+                                                     const uint4 *__restrict__ pow_1me,
+                                                     const uint4 *__restrict__ pow_eps,
                                                      PopArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
-    const unsigned c = blockIdx.y * 8 + wave;
-    if (c >= a.n_chunks)
-        return;
     const unsigned t = blockIdx.z;
     const uint32_t w0 = blockIdx.x * a.win_per_group;
     const uint32_t w1 = min(w0 + a.win_per_group, a.n_win);
     const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
-    if (seg0 >= seg1)
+    const uint32_t nseg = seg1 - seg0;
+    if (nseg == 0)
         return;
-    const uint32_t tgt = a.targets[t];
-    const uint2 *xt = t32 + (size_t)c * a.n_tiles * 64 + lane;
-    const uint2 *tt = t32 + (size_t)(tgt >> 6) * a.n_tiles * 64 + (tgt & 63);
+
+    // ---- LDS carve-up (see ld_popcount_lds_bytes)
+    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][22]
+    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_REC_WORDS;               // [win_per_group][12]
+    uint4 *tab_lds = reinterpret_cast<uint4 *>(
+        smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
+    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
+    char *ring0 = smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
+
+    // ---- stage the run's records, window constants and tables (whole workgroup)
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(segs + seg0);
+        const uint2 *tws = twords + (size_t)t * a.n_segs + seg0;
+        for (uint32_t i = threadIdx.x; i < nseg * 32; i += blockDim.x) {
+            const uint32_t sg = i >> 5, wd = i & 31;
+            if (wd < 20)
+                rec_lds[sg * IBDG_REC_WORDS + wd] = src[sg * 20 + wd];
+            else if (wd == 20) {
+                const uint2 v = tws[sg];
+                rec_lds[sg * IBDG_REC_WORDS + RW_TW] = v.x;
+                rec_lds[sg * IBDG_REC_WORDS + RW_TW + 1] = v.y;
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 16; i += blockDim.x) {
+            const uint32_t wj = i >> 4, wd = i & 15;
+            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(wconst + w0 + wj);     // mK(2) eK ct at seg
+            const uint32_t *wts = reinterpret_cast<const uint32_t *>(wtarget + (size_t)t * a.n_win + w0 + wj);
+            if (wd < 5)
+                wc_lds[wj * IBDG_WC_WORDS + wd] = wcs[wd];
+            else if (wd < 9)
+                wc_lds[wj * IBDG_WC_WORDS + wd] = wts[wd - 5];
+        }
+        if (TAB_LDS)
+            for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
+                tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
+    }
+    __syncthreads();
+
+    const unsigned c = blockIdx.y * 8 + wave;
+    if (c >= a.n_chunks)
+        return;
+    char *ring = ring0 + (size_t)wave * NS * 1024;
+    const uint32_t rec_lane = (uint32_t)(uintptr_t)(lds_void *)rec_lds + min(lane, (unsigned)IBDG_REC_WORDS - 1) * 4;
+    const uint32_t wc_lane = (uint32_t)(uintptr_t)(lds_void *)wc_lds + min(lane, (unsigned)IBDG_WC_WORDS - 1) * 4;
+    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+    const uint32_t tab2 = tab1 + a.tab_len * 16;
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+
+    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
     const double wgt = a.weight[(size_t)t * a.lanes + c * 64 + lane];
 
     uint32_t c0[KP], c1[KP], ch[KP], g00[KP], g01[KP], g10[KP], g11[KP], A0[KP], A1[KP];
@@ -177,84 +284,146 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint2 *__restrict__ t
     for (int k = 0; k < KP; ++k)
         c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = A0[k] = A1[k] = 0;
 
-    // Software pipeline: segment records two ahead (scalar), tile words and the target's
-    // words one ahead, so no load is waited for in the iteration that issued it.
-    SegRegs r1, r2;
-    r1.load(segs + seg0);
-    r2.load(segs + min(seg0 + 1, seg1 - 1));
-    uint2 xn = xt[(size_t)r1.tile() * 64];
-    uint2 atn = tt[(size_t)r1.tile() * 64];
-    for (uint32_t s = seg0; s < seg1; ++s) {
-        const SegRegs S = r1;
-        const uint2 x = xn;
-        const uint2 at = atn;                              // the target's two haplotypes (uniform)
-        r1 = r2;
-        r2.load(segs + min(s + 2, seg1 - 1));
-        xn = xt[(size_t)r1.tile() * 64];
-        atn = tt[(size_t)r1.tile() * 64];
-        const uint32_t hom = x.x & x.y;
+    // ---- prime the ring: pairs qcur .. qcur+NS-1 (not past the run's last pair)
+    uint32_t tile = segs[seg0].tile;                 // tile of the segment being fetched
+    const uint32_t q_last = segs[seg1 - 1].tile >> 1;
+    uint32_t qcur = tile >> 1;                       // oldest pair still in the ring
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const uint32_t cov = S.cov(k);
-            if (cov) {
-                const uint32_t m0 = at.x & cov, m1 = at.y & cov;
-                c0[k] += __popc(x.x & cov);
-                c1[k] += __popc(x.y & cov);
-                ch[k] += __popc(hom & cov);
-                g00[k] += __popc(x.x & m0);
-                g01[k] += __popc(x.y & m0);
-                g10[k] += __popc(x.x & m1);
-                g11[k] += __popc(x.y & m1);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const uint32_t alt = S.alt(k);
-            if (alt) {
-                A0[k] += __popc(x.x & alt);
-                A1[k] += __popc(x.y & alt);
-            }
-        }
-        if (S.last()) {
-            const uint32_t w = S.win();
-            const WinConst wc = wconst[w];
-            const WinTarget wt = wtarget[(size_t)t * a.n_win + w];
-            const uint32_t C0 = planes_sum<KP>(c0), C1 = planes_sum<KP>(c1), CH = planes_sum<KP>(ch);
-            const uint32_t G00 = planes_sum<KP>(g00), G01 = planes_sum<KP>(g01);
-            const uint32_t G10 = planes_sum<KP>(g10), G11 = planes_sum<KP>(g11);
-            const uint32_t a0 = planes_sum<KP>(A0), a1 = planes_sum<KP>(A1);
-            const uint32_t CT = wc.cov_total, AT = wc.alt_total;
-            // pDg[x0+x1]   (sum_ibd2_ref, src/ibdgem.c:715)
-            uint32_t E3 = C0 + C1 - 2 * CH;
-            uint32_t E2 = AT - a0 - a1 + CH;
-            const double P2 = ld_value(a, wc.mK, wc.eK, CT - E2 - E3, E2, E3);
-            // pDg[A0+h0], pDg[A0+h1], pDg[A1+h0], pDg[A1+h1]   (sum_ibd1_ref, :716-719)
-            E3 = wt.a0cov + C0 - 2 * G00; E2 = AT - wt.a0alt - a0 + G00;
-            const double Q00 = ld_value(a, wc.mK, wc.eK, CT - E2 - E3, E2, E3);
-            E3 = wt.a0cov + C1 - 2 * G01; E2 = AT - wt.a0alt - a1 + G01;
-            const double Q01 = ld_value(a, wc.mK, wc.eK, CT - E2 - E3, E2, E3);
-            E3 = wt.a1cov + C0 - 2 * G10; E2 = AT - wt.a1alt - a0 + G10;
-            const double Q10 = ld_value(a, wc.mK, wc.eK, CT - E2 - E3, E2, E3);
-            E3 = wt.a1cov + C1 - 2 * G11; E2 = AT - wt.a1alt - a1 + G11;
-            const double Q11 = ld_value(a, wc.mK, wc.eK, CT - E2 - E3, E2, E3);
+    for (int i = 0; i < NS; ++i)
+        if (qcur + i <= q_last)
+            __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(qcur + i) * 64),
+                                             (lds_void *)(ring + ((qcur + i) % NS) * 1024), 16, 0, 0);
+    if (qcur + NS - 1 <= q_last)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-            double s0 = wgt * P2;                                   // :743
-            double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                s0 += __shfl_xor(s0, off);
-                s1 += __shfl_xor(s1, off);
+    for (uint32_t s = 0; s < nseg; ++s) {
+        // ---- advance the ring to the pair of this segment
+        const uint32_t q = tile >> 1;
+        if (q != qcur) {
+            while (qcur < q) {                       // the slot of qcur is free: refill it NS pairs ahead
+                if (qcur + NS <= q_last)
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(qcur + NS) * 64),
+                                                     (lds_void *)(ring + (qcur % NS) * 1024), 16, 0, 0);
+                ++qcur;
             }
-            if (lane == 0) {
-                double *o = a.partial + (((size_t)t * a.n_win + w) * a.n_chunks + c) * 2;
-                o[0] = s0;
-                o[1] = s1;
+            // pair q is followed by exactly NS-1 younger direct-to-LDS loads unless the run ends first
+            if (q + NS - 1 <= q_last)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        uint32_t recw;
+        uint2 x;
+        lds_fetch(recw, x, rec_lane + s * (IBDG_REC_WORDS * 4), ring_lane + (q % NS) * 1024 + (tile & 1) * 8);
+        const uint32_t flags = __builtin_amdgcn_readlane(recw, RW_FLAGS);
+        const uint32_t last = __builtin_amdgcn_readlane(recw, RW_LAST);
+        const uint2 at = make_uint2(__builtin_amdgcn_readlane(recw, RW_TW),
+                                    __builtin_amdgcn_readlane(recw, RW_TW + 1));   // target's haplotypes
+        tile += flags >> 16;                         // tile of the next segment
+
+#if IBDG_TIMING_EXPERIMENT
+        const uint32_t ncov = (a.debug & 2) ? 0 : (flags & 0xff), nalt = (a.debug & 2) ? 0 : ((flags >> 8) & 0xff);
+#else
+        const uint32_t ncov = flags & 0xff, nalt = (flags >> 8) & 0xff;
+#endif
+        const uint32_t hom = x.x & x.y;
+#define IBDG_COV_PLANE(k)                                                   \
+    {                                                                       \
+        const uint32_t cov = __builtin_amdgcn_readlane(recw, RW_COV + (k)); \
+        const uint32_t u0 = x.x & cov, u1 = x.y & cov;                      \
+        c0[k] += __popc(u0);                                                \
+        c1[k] += __popc(u1);                                                \
+        ch[k] += __popc(hom & cov);                                         \
+        g00[k] += __popc(u0 & at.x);                                        \
+        g01[k] += __popc(u1 & at.x);                                        \
+        g10[k] += __popc(u0 & at.y);                                        \
+        g11[k] += __popc(u1 & at.y);                                        \
+    }
+#define IBDG_ALT_PLANE(k)                                                   \
+    {                                                                       \
+        const uint32_t alt = __builtin_amdgcn_readlane(recw, RW_ALT + (k)); \
+        A0[k] += __popc(x.x & alt);                                         \
+        A1[k] += __popc(x.y & alt);                                         \
+    }
+        // one uniform skip per plane (a fall-through switch makes hipcc copy every
+        // accumulator at every case label)
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            if ((uint32_t)k < ncov)
+                IBDG_COV_PLANE(k)
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+            if ((uint32_t)k < nalt)
+                IBDG_ALT_PLANE(k)
+#undef IBDG_COV_PLANE
+#undef IBDG_ALT_PLANE
+
+        if (last) {
+            const uint32_t w = __builtin_amdgcn_readlane(recw, RW_WIN);
+#if IBDG_TIMING_EXPERIMENT
+            if (!(a.debug & 1))
+#endif
+            {
+                const uint32_t wcw = lds_read_b32(wc_lane + (w - w0) * (IBDG_WC_WORDS * 4));
+                const double mK = __hiloint2double((int)__builtin_amdgcn_readlane(wcw, WC_MK + 1),
+                                                   (int)__builtin_amdgcn_readlane(wcw, WC_MK));
+                const int eK = (int)__builtin_amdgcn_readlane(wcw, WC_EK);
+                const uint32_t CT = __builtin_amdgcn_readlane(wcw, WC_CT), AT = __builtin_amdgcn_readlane(wcw, WC_AT);
+                const uint32_t a0cov = __builtin_amdgcn_readlane(wcw, WC_A0COV), a1cov = __builtin_amdgcn_readlane(wcw, WC_A1COV);
+                const uint32_t a0alt = __builtin_amdgcn_readlane(wcw, WC_A0ALT), a1alt = __builtin_amdgcn_readlane(wcw, WC_A1ALT);
+                const uint32_t C0 = planes_sum<KP>(c0), C1 = planes_sum<KP>(c1), CH = planes_sum<KP>(ch);
+                const uint32_t G00 = planes_sum<KP>(g00), G01 = planes_sum<KP>(g01);
+                const uint32_t G10 = planes_sum<KP>(g10), G11 = planes_sum<KP>(g11);
+                const uint32_t a0 = planes_sum<KP>(A0), a1 = planes_sum<KP>(A1);
+                uint32_t E2[5], E3[5];
+                E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
+                E3[1] = a0cov + C0 - 2 * G00;  E2[1] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
+                E3[2] = a0cov + C1 - 2 * G01;  E2[2] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
+                E3[3] = a1cov + C0 - 2 * G10;  E2[3] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
+                E3[4] = a1cov + C1 - 2 * G11;  E2[4] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+                uint4 pw[10];
+                if (TAB_LDS) {
+                    uint32_t ad[10];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        ad[2 * i] = tab1 + (CT - E2[i] - E3[i]) * 16;
+                        ad[2 * i + 1] = tab2 + E2[i] * 16;
+                    }
+                    lds_read_pow10(pw, ad);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        pw[2 * i] = pow_1me[CT - E2[i] - E3[i]];
+                        pw[2 * i + 1] = pow_eps[E2[i]];
+                    }
+                }
+                const double P2 = ld_value(mK, eK, pw[0], pw[1], E3[0]);
+                const double Q00 = ld_value(mK, eK, pw[2], pw[3], E3[1]);
+                const double Q01 = ld_value(mK, eK, pw[4], pw[5], E3[2]);
+                const double Q10 = ld_value(mK, eK, pw[6], pw[7], E3[3]);
+                const double Q11 = ld_value(mK, eK, pw[8], pw[9], E3[4]);
+                double s0 = wgt * P2;                                   // :743
+                double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    s0 += __shfl_xor(s0, off);
+                    s1 += __shfl_xor(s1, off);
+                }
+                if (lane == 0) {
+                    double *o = a.partial + (((size_t)t * a.n_win + w) * a.n_chunks + c) * 2;
+                    o[0] = s0;
+                    o[1] = s1;
+                }
             }
 #pragma unroll
             for (int k = 0; k < KP; ++k)
                 c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = A0[k] = A1[k] = 0;
         }
     }
+    // leave no direct-to-LDS load in flight when the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Sum the per-chunk partials in ascending chunk order and take the background average
@@ -279,12 +448,12 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
 
 // ---------------------------------------------------------------------------
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
-                        uint32_t n_tiles, uint32_t *t32, hipStream_t st)
+                        uint32_t n_pairs, uint32_t *t32, hipStream_t st)
 {
-    if (n_tiles == 0)
+    if (n_pairs == 0)
         return;
-    hipLaunchKernelGGL(k_transpose32, dim3(n_tiles, (n_chunks + 3) / 4), dim3(256), 0, st, panel, stride,
-                       n_rows, n_chunks, n_tiles, t32);
+    hipLaunchKernelGGL(k_transpose32, dim3(n_pairs, (n_chunks + 3) / 4), dim3(256), 0, st, panel, stride,
+                       n_rows, n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
 }
 
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
@@ -292,7 +461,38 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
     if (a.n_win == 0)
         return;
     hipLaunchKernelGGL(k_win_target, dim3((a.n_win + 255) / 256, n_targets), dim3(256), 0, st, a,
-                       const_cast<WinTarget *>(a.wtarget));
+                       const_cast<WinTarget *>(a.wtarget), const_cast<uint2 *>(a.twords));
+}
+
+// LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
+size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
+                             int ring_slots)
+{
+    size_t head = ((size_t)max_seg * IBDG_REC_WORDS + (size_t)win_per_group * IBDG_WC_WORDS) * 4 + 15;
+    if (tab_in_lds)
+        head += (size_t)tab_len * 32;
+    return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024;
+}
+
+template <int KP, int NS, bool TAB>
+static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
+{
+    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS);
+    auto kern = k_ld_popcount<KP, NS, TAB>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return 1;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.twords, a.wconst,
+                       a.wtarget, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a);
+    return 0;
+}
+
+template <int KP>
+static int launch_pop_kp(const PopArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.ring_slots == 4)
+        return a.tab_in_lds ? launch_pop<KP, 4, true>(a, grid, st) : launch_pop<KP, 4, false>(a, grid, st);
+    return a.tab_in_lds ? launch_pop<KP, 8, true>(a, grid, st) : launch_pop<KP, 8, false>(a, grid, st);
 }
 
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st)
@@ -300,17 +500,10 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (a.n_win == 0)
         return 0;
     dim3 grid((a.n_win + a.win_per_group - 1) / a.win_per_group, (a.n_chunks + 7) / 8, n_targets);
-    dim3 block(512);
-    switch (planes) {
-    case 1: case 2: case 3:
-        hipLaunchKernelGGL(k_ld_popcount<3>, grid, block, 0, st, (const uint2 *)a.t32, a.segs, a.wconst, a.wtarget, a); break;
-    case 4: case 5:
-        hipLaunchKernelGGL(k_ld_popcount<5>, grid, block, 0, st, (const uint2 *)a.t32, a.segs, a.wconst, a.wtarget, a); break;
-    case 6: case 7:
-        hipLaunchKernelGGL(k_ld_popcount<7>, grid, block, 0, st, (const uint2 *)a.t32, a.segs, a.wconst, a.wtarget, a); break;
-    default: return 1;
-    }
-    return 0;
+    if (planes <= 3) return launch_pop_kp<3>(a, grid, st);
+    if (planes <= 5) return launch_pop_kp<5>(a, grid, st);
+    if (planes <= 7) return launch_pop_kp<7>(a, grid, st);
+    return 1;
 }
 
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st)
