@@ -1,0 +1,769 @@
+/*
+ * ibdgem.c -- host program of the MI355X IBD-likelihood engine: the reference's
+ * command line, input formats and output files, with the likelihood arithmetic done by
+ * libibdgem_hip.so (include/ibdgem_hip.h).
+ *
+ * What stays on the CPU is what the north star leaves there: option parsing, text parsing
+ * and the integer row filter chain of compare_impute (reference src/ibdgem.c:572-630).
+ * What the reference computes per row and per window in that loop (:632-667, :669-722,
+ * :736-756) is one ibdg_run per batch of comparison individuals.  There is no CPU
+ * implementation of that arithmetic here: without a HIP device the program stops with the
+ * engine's error, except for --plan (below), which never needs the engine.
+ *
+ * Differences from the reference, all outside the BASELINE configs:
+ *   - IMPUTE input only for now (-H/-L/-I); -V reports that VCF input is not built yet;
+ *   - no 30720-byte line limit (src/file-io.h:10); .hap rows with a character other than
+ *     '0'/'1' at an allele offset are counted as skipped instead of read as garbage;
+ *   - the genotype files are read once, not once per comparison individual
+ *     (src/ibdgem.c:771-772);
+ *   - extra long option --plan: print, per comparison individual, the rows that pass the
+ *     filter chain with their integer columns and the window boundaries, and exit.  It is the
+ *     hook the CPU-only tests use to check the host logic against the reference's outputs.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <getopt.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "../../include/ibdgem_hip.h"
+#include "lineio.h"
+#include "pileup.h"
+
+/* ---- options (names and defaults: reference src/ibdgem.c:21-66) ------------------- */
+static double opt_eps = 0.02, opt_min_qual = 0, opt_max_af = 1, opt_min_af = 0, opt_target_dp = 0;
+static unsigned opt_max_cov = 20;
+static int opt_window = 100;
+static const char *opt_sq = "UNKWN";
+static int opt_ld = 0, opt_plan = 0, in_impute = 0, in_vcf = 0;
+static int has_S = 0, has_s = 0, has_B = 0, has_A = 0, has_p = 0, has_v = 0, has_D = 0;
+
+static struct option longopts[] = {
+    {"LD", no_argument, &opt_ld, 1},
+    {"plan", no_argument, &opt_plan, 1},
+    {"rand-stream", required_argument, 0, 1000},
+    {"vcf", required_argument, 0, 'V'},
+    {"hap", required_argument, 0, 'H'},
+    {"legend", required_argument, 0, 'L'},
+    {"indv", required_argument, 0, 'I'},
+    {"pileup", required_argument, 0, 'P'},
+    {"pileup-name", required_argument, 0, 'N'},
+    {"window-size", required_argument, 0, 'w'},
+    {"allele-freqs", required_argument, 0, 'A'},
+    {"sample-list", required_argument, 0, 'S'},
+    {"sample", required_argument, 0, 's'},
+    {"background-list", required_argument, 0, 'B'},
+    {"max-cov", required_argument, 0, 'M'},
+    {"downsample-cov", required_argument, 0, 'D'},
+    {"out-dir", required_argument, 0, 'O'},
+    {"max-af", required_argument, 0, 'F'},
+    {"min-af", required_argument, 0, 'f'},
+    {"positions", required_argument, 0, 'p'},
+    {"min-qual", required_argument, 0, 'q'},
+    {"chromosome", required_argument, 0, 'c'},
+    {"error-rate", required_argument, 0, 'e'},
+    {"variable-sites-only", no_argument, 0, 'v'},
+    {"help", no_argument, 0, 'h'},
+    {0, 0, 0, 0}};
+
+static void usage(int code)
+{
+    fputs("ibdgem (MI355X engine): likelihood that low-coverage reads (pileup) and a genotyped\n"
+          "individual share 0, 1 or 2 chromosomes identical by descent, per SNP and per window.\n\n"
+          "Usage: ibdgem [--LD] -H hap -L legend -I indv -P pileup [options]\n"
+          "  --LD                      background-panel (linkage-aware) window likelihoods\n"
+          "  -H/--hap, -L/--legend, -I/--indv FILE   IMPUTE genotype input (plain or .gz)\n"
+          "  -V/--vcf FILE             VCF genotype input (not built yet in this engine)\n"
+          "  -P/--pileup FILE          samtools pileup of the unknown sample (required)\n"
+          "  -N/--pileup-name STR      name of the pileup sample (default UNKWN)\n"
+          "  -A/--allele-freqs FILE    CHROM POS AF table overriding the panel's own frequencies\n"
+          "  -S/--sample-list FILE     individuals to compare against, one per line\n"
+          "  -s/--sample STR           the same, comma separated\n"
+          "  -B/--background-list FILE individuals forming the --LD background panel\n"
+          "  -p/--positions FILE       restrict to these sites (CHROM POS or BED)\n"
+          "  -q/--min-qual FLOAT       minimum QUAL (VCF input only)\n"
+          "  -M/--max-cov INT          skip sites with more informative reads (default 20)\n"
+          "  -F/--max-af, -f/--min-af FLOAT   alternate-allele frequency range (default 0..1)\n"
+          "  -D/--downsample-cov FLOAT thin the reads to this mean depth\n"
+          "  -w/--window-size INT      covered sites per summary window (default 100)\n"
+          "  -O/--out-dir DIR          output directory (default: current directory)\n"
+          "  -c/--chromosome STR       use only this chromosome of the pileup / -A / -p files\n"
+          "  -e/--error-rate FLOAT     sequencing error rate (default 0.02)\n"
+          "  -v/--variable-sites-only  skip sites where the compared individual is 0/0\n"
+          "  --plan                    print the filtered rows and windows only (no device needed)\n"
+          "  -h/--help\n\n"
+          "Outputs <out>/<pileup-name>.<individual>.tab.txt with columns\n"
+          "CHR rsID POS REF ALT AF DP SQ_NREF SQ_NALT GT_A0 GT_A1 LIBD0 LIBD1 LIBD2\n"
+          "and <out>/<pileup-name>.<individual>.summary.txt with columns\n"
+          "SEGMENT START END LIBD0 LIBD1 LIBD2 NUM_SITES\n",
+          stderr);
+    exit(code);
+}
+
+/* ---- panel individuals -------------------------------------------------------------- */
+typedef struct {
+    char **names;
+    size_t n;
+} names_t;
+
+static void chomp1(char *s)
+{
+    size_t n = strlen(s);
+    if (n)
+        s[n - 1] = '\0';               /* the reference drops the last character (the newline) */
+}
+
+static int read_names(const char *fn, names_t *out)
+{
+    line_src *ls = ls_open(fn);
+    if (!ls)
+        return 1;
+    char *line;
+    size_t cap = 0;
+    out->n = 0;
+    out->names = NULL;
+    while ((line = ls_next(ls, NULL))) {
+        chomp1(line);
+        if (out->n == cap) {
+            cap = cap ? cap * 2 : 256;
+            out->names = realloc(out->names, cap * sizeof *out->names);
+        }
+        out->names[out->n++] = strdup(line);
+    }
+    ls_close(ls);
+    return 0;
+}
+
+static long find_name(const names_t *ids, const char *name)
+{
+    for (size_t i = 0; i < ids->n; ++i)
+        if (strcmp(ids->names[i], name) == 0)
+            return (long)i;
+    return -1;
+}
+
+/* a list of panel individuals (by index) in list order, unknown names reported and dropped
+ * (read_sf / read_rf, reference src/ibd-parse.c:176-219, :262-308) */
+typedef struct {
+    uint32_t *idx;
+    size_t n;
+} idlist_t;
+
+static int read_idlist_file(const char *fn, const names_t *ids, const char *what_missing, const char *err_fn,
+                            idlist_t *out)
+{
+    names_t l;
+    if (read_names(fn, &l))
+        return 1;
+    out->idx = malloc((l.n ? l.n : 1) * sizeof *out->idx);
+    out->n = 0;
+    for (size_t i = 0; i < l.n; ++i) {
+        long k = find_name(ids, l.names[i]);
+        if (k < 0) {
+            fprintf(stderr, what_missing, l.names[i]);
+            continue;
+        }
+        out->idx[out->n++] = (uint32_t)k;
+    }
+    for (size_t i = 0; i < l.n; ++i)
+        free(l.names[i]);
+    free(l.names);
+    if (out->n == 0) {
+        fprintf(stderr, "[::] ERROR in %s(): No matching samples found in %s.\n", err_fn, fn);
+        return 1;
+    }
+    return 0;
+}
+
+static int read_idlist_csv(const char *csv, const names_t *ids, idlist_t *out)
+{
+    char *buf = strdup(csv);
+    out->idx = malloc((strlen(csv) / 2 + 2) * sizeof *out->idx);
+    out->n = 0;
+    for (char *tok = strtok(buf, ","); tok; tok = strtok(NULL, ",")) {
+        long k = find_name(ids, tok);
+        if (k < 0) {
+            fprintf(stderr, "Sample %s not found in reference panel.\n", tok);
+            continue;
+        }
+        out->idx[out->n++] = (uint32_t)k;
+    }
+    free(buf);
+    if (out->n == 0) {
+        fprintf(stderr, "[::] ERROR in read_scmd(): No matching samples found.\n");
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- -A and -p tables (reference src/ibd-parse.c:311-421) --------------------------- */
+typedef struct {
+    unsigned long pos;
+    double f;
+} af_rec;
+
+static af_rec *af_tab;
+static size_t af_n;
+static unsigned long *pos_tab;
+static size_t pos_n;
+
+static int read_af_file(const char *fn, const char *chr)
+{
+    line_src *ls = ls_open(fn);
+    if (!ls)
+        return 1;
+    size_t cap = 0;
+    char *line, c[129];
+    while ((line = ls_next(ls, NULL))) {
+        af_rec r;
+        if (sscanf(line, "%128s %lu %lf", c, &r.pos, &r.f) != 3)
+            continue;
+        if (chr && strcmp(c, chr) != 0)
+            continue;
+        if (af_n == cap) {
+            cap = cap ? cap * 2 : 4096;
+            af_tab = realloc(af_tab, cap * sizeof *af_tab);
+        }
+        af_tab[af_n++] = r;
+    }
+    ls_close(ls);
+    if (af_n == 0) {
+        fprintf(stderr, "[::] ERROR in read_af(): Cannot parse lines from %s.\n", fn);
+        return 1;
+    }
+    return 0;
+}
+
+static const af_rec *find_af(unsigned long pos)      /* bsearch over the (sorted) table */
+{
+    size_t lo = 0, hi = af_n;
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        if (af_tab[mid].pos == pos)
+            return &af_tab[mid];
+        if (af_tab[mid].pos < pos)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return NULL;
+}
+
+static int read_pos_file(const char *fn, const char *chr)
+{
+    line_src *ls = ls_open(fn);
+    if (!ls)
+        return 1;
+    size_t cap = 0;
+    char *line, c[129];
+    while ((line = ls_next(ls, NULL))) {
+        unsigned long p;
+        /* BED (chr start end -> end) or chr pos */
+        if (!(sscanf(line, "%128s %*d %lu", c, &p) == 2 || sscanf(line, "%128s %lu", c, &p) == 2))
+            continue;
+        if (chr && strcmp(c, chr) != 0)
+            continue;
+        if (pos_n == cap) {
+            cap = cap ? cap * 2 : 4096;
+            pos_tab = realloc(pos_tab, cap * sizeof *pos_tab);
+        }
+        pos_tab[pos_n++] = p;
+    }
+    ls_close(ls);
+    if (pos_n == 0) {
+        fprintf(stderr, "[::] ERROR in read_pos(): Cannot parse lines from %s.\n", fn);
+        return 1;
+    }
+    return 0;
+}
+
+static int cmp_ul(const void *a, const void *b)
+{
+    unsigned long x = *(const unsigned long *)a, y = *(const unsigned long *)b;
+    return x < y ? -1 : x > y;
+}
+
+static int pos_listed(unsigned long pos)             /* membership (the reference scans linearly) */
+{
+    return bsearch(&pos, pos_tab, pos_n, sizeof *pos_tab, cmp_ul) != NULL;
+}
+
+/* ---- genotype rows -------------------------------------------------------------------- */
+typedef struct {
+    uint32_t id_off, ref_off, alt_off;   /* into the string arena */
+    unsigned long pos;
+    uint8_t legend_ok;                   /* the legend row had its 4 fields (src/ibdgem.c:589) */
+    uint8_t hap_ok;                      /* the .hap row packed cleanly */
+} row_t;
+
+static row_t *rows;
+static size_t n_rows;
+static char *arena;
+static size_t arena_len, arena_cap;
+static uint64_t *packed;
+static size_t row_words;
+
+static uint32_t arena_add(const char *s)
+{
+    size_t l = strlen(s) + 1;
+    if (arena_len + l > arena_cap) {
+        arena_cap = arena_cap ? arena_cap * 2 : (1 << 20);
+        while (arena_len + l > arena_cap)
+            arena_cap *= 2;
+        arena = realloc(arena, arena_cap);
+    }
+    memcpy(arena + arena_len, s, l);
+    arena_len += l;
+    return (uint32_t)(arena_len - l);
+}
+
+static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_ids)
+{
+    line_src *hap = ls_open(hap_fn), *leg = ls_open(legend_fn);
+    if (!hap || !leg) {
+        fprintf(stderr, "[::] ERROR parsing hap/legend/indv data; make sure inputs are valid.\n");
+        return 1;
+    }
+    row_words = ibdg_row_words(n_ids);
+    size_t cap = 0;
+    ls_next(leg, NULL);                                   /* legend header (src/ibdgem.c:555) */
+    for (;;) {
+        char *h = ls_next(hap, NULL);
+        if (!h)
+            break;
+        if (n_rows == cap) {
+            cap = cap ? cap * 2 : (1 << 16);
+            rows = realloc(rows, cap * sizeof *rows);
+            packed = realloc(packed, cap * row_words * 8);
+        }
+        row_t *r = &rows[n_rows];
+        memset(r, 0, sizeof *r);
+        r->hap_ok = ibdg_pack_hap_text(h, n_ids, packed + n_rows * row_words) == 0;
+        char *l = ls_next(leg, NULL);                     /* both files advance together (:573-578) */
+        if (!l)
+            break;
+        char id[129], ref[129], alt[129];
+        if (sscanf(l, "%128s %lu %128s %128s", id, &r->pos, ref, alt) == 4) {
+            r->legend_ok = 1;
+            r->id_off = arena_add(id);
+            r->ref_off = arena_add(ref);
+            r->alt_off = arena_add(alt);
+        }
+        n_rows++;
+    }
+    ls_close(hap);
+    ls_close(leg);
+    return 0;
+}
+
+static int is_snp(const char *ref, const char *alt)   /* one of A C G T each (src/ibdgem.c:113-119) */
+{
+    return ref[0] && !ref[1] && strchr("ACGT", ref[0]) && alt[0] && !alt[1] && strchr("ACGT", alt[0]);
+}
+
+static inline unsigned row_allele(size_t r, unsigned indiv, unsigned hap)
+{
+    return (unsigned)(packed[r * row_words + 2 * (indiv >> 6) + hap] >> (indiv & 63)) & 1u;
+}
+
+/* The reference thins reads with libc rand(), never seeded (src/ibdgem.c:132), so its output
+ * depends on glibc's default stream: the TYPE_3 additive-feedback generator of random_r.c
+ * (r[i] = r[i-3] + r[i-31], state seeded from 1 with the Lehmer step 16807 mod 2^31-1, first
+ * 310 values discarded, result = r >> 1).  The stream is restated here instead of calling
+ * rand(): the HIP runtime inside this process draws from libc's global generator too, which
+ * would shift the sequence.  tests/test_host_cli.py checks it against libc. */
+static uint32_t grand_state[34];
+static int grand_f = 3, grand_r = 0, grand_ready = 0;
+
+static void grand_seed(uint32_t seed)
+{
+    int32_t w = (int32_t)(seed ? seed : 1);
+    grand_state[0] = (uint32_t)w;
+    for (int i = 1; i < 31; ++i) {
+        const long hi = w / 127773, lo = w % 127773;
+        w = (int32_t)(16807 * lo - 2836 * hi);
+        if (w < 0)
+            w += 2147483647;
+        grand_state[i] = (uint32_t)w;
+    }
+    grand_f = 3;
+    grand_r = 0;
+    grand_ready = 1;
+    for (int i = 0; i < 310; ++i) {
+        grand_state[grand_f] += grand_state[grand_r];
+        grand_f = (grand_f + 1) % 31;
+        grand_r = (grand_r + 1) % 31;
+    }
+}
+
+static int glibc_rand(void)
+{
+    if (!grand_ready)
+        grand_seed(1);
+    const uint32_t v = grand_state[grand_f] += grand_state[grand_r];
+    grand_f = (grand_f + 1) % 31;
+    grand_r = (grand_r + 1) % 31;
+    return (int)(v >> 1);
+}
+
+/* cull_dp, reference src/ibdgem.c:126-137 */
+static unsigned cull(unsigned count, double cull_p)
+{
+    if (cull_p == 1.0)
+        return count;
+    unsigned kept = 0;
+    for (unsigned i = 0; i < count; ++i)
+        if ((glibc_rand() / (double)2147483647) < cull_p)
+            kept++;
+    return kept;
+}
+
+static void print_ll(FILE *fp, double v, char sep)
+{
+    if (isnan(v))
+        fputs("-nan", fp);                 /* what x86 printf shows for the reference's 0/0 */
+    else
+        fprintf(fp, "%e", v);
+    fputc(sep, fp);
+}
+
+#define DIE(...)                          \
+    do {                                  \
+        fprintf(stderr, __VA_ARGS__);     \
+        exit(1);                          \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    const clock_t t_start = clock();
+    const char *hap_fn = NULL, *legend_fn = NULL, *indv_fn = NULL, *pu_fn = NULL, *vcf_fn = NULL;
+    const char *sample_fn = NULL, *sample_csv = NULL, *bg_fn = NULL, *af_fn = NULL, *pos_fn = NULL;
+    const char *uchr = NULL, *out_dir = NULL;
+    char cwd[PATH_MAX];
+    if (argc == 1)
+        usage(0);
+    out_dir = getcwd(cwd, sizeof cwd) ? cwd : "./";
+
+    int o;
+    while ((o = getopt_long(argc, argv, ":V:H:L:I:P:w:N:A:S:s:B:p:q:M:F:f:D:O:c:e:vh", longopts, NULL)) != -1) {
+        switch (o) {
+        case 0: break;
+        case 'V': in_vcf = 1; vcf_fn = optarg; break;
+        case 'H': in_impute = 1; hap_fn = optarg; break;
+        case 'L': in_impute = 1; legend_fn = optarg; break;
+        case 'I': in_impute = 1; indv_fn = optarg; break;
+        case 'P': pu_fn = optarg; break;
+        case 'w': opt_window = atoi(optarg); break;
+        case 'N': opt_sq = optarg; break;
+        case 'S': has_S = 1; sample_fn = optarg; break;
+        case 's': has_s = 1; sample_csv = optarg; break;
+        case 'B': has_B = 1; bg_fn = optarg; break;
+        case 'A': has_A = 1; af_fn = optarg; break;
+        case 'M': opt_max_cov = (unsigned)atoi(optarg); break;
+        case 'F': opt_max_af = atof(optarg); break;
+        case 'f': opt_min_af = atof(optarg); break;
+        case 'p': has_p = 1; pos_fn = optarg; break;
+        case 'q': opt_min_qual = atof(optarg); break;
+        case 'c': uchr = optarg; break;
+        case 'e': opt_eps = atof(optarg); break;
+        case 'O': out_dir = optarg; break;
+        case 'D': opt_target_dp = atof(optarg); has_D = 1; break;
+        case 'v': has_v = 1; break;
+        case 'h': usage(0); break;
+        case 1000:                                  /* test hook: the first N values of the read-thinning stream */
+            for (long i = atol(optarg); i > 0; --i)
+                printf("%d\n", glibc_rand());
+            exit(0);
+        case ':': fprintf(stderr, "Option -%c missing required argument.\n", optopt); exit(0);
+        case '?':
+            if (isprint(optopt))
+                fprintf(stderr, "Invalid option -%c.\n", optopt);
+            else
+                fprintf(stderr, "Invalid option character.\n");
+            break;
+        default: fprintf(stderr, "[::] ERROR parsing command-line options.\n"); exit(0);
+        }
+    }
+    for (int i = optind; i < argc; ++i)
+        fprintf(stderr, "Given extra argument %s.\n", argv[i]);
+    /* range checks, messages and exit codes of reference src/ibdgem.c:966-989 */
+    if (has_D && opt_target_dp <= 0) { fprintf(stderr, "[::] ERROR: Invalid down-sample coverage (-D) of %.2f (must be > 0).\n", opt_target_dp); exit(0); }
+    if (opt_min_af < 0) { fprintf(stderr, "[::] ERROR: Invalid minimum alternate allele frequency (-f) of %.2f (must be >= 0).\n", opt_min_af); exit(0); }
+    if (opt_max_af > 1) { fprintf(stderr, "[::] ERROR: Invalid maximum alternate allele frequency (-F) of %.2f (must be <= 1).\n", opt_max_af); exit(0); }
+    if (opt_max_cov < 1) { fprintf(stderr, "[::] ERROR: Invalid maximum estimated coverage (-M) of %u (must be >= 1).\n", opt_max_cov); exit(0); }
+    if (opt_min_qual < 0) { fprintf(stderr, "[::] ERROR: Invalid genotype quality minimum (-q) of %.2f (must be >= 0).\n", opt_min_qual); exit(0); }
+    if (opt_window < 2) { fprintf(stderr, "[::] ERROR: Invalid window size (-w) of %d (must be >= 2).\n", opt_window); exit(0); }
+    if (opt_max_cov > 127) { fprintf(stderr, "[::] ERROR: Invalid maximum estimated coverage (-M) of %u (pileup lines hold at most 127 reads).\n", opt_max_cov); exit(0); }
+
+    /* the echoed command: argv joined by single spaces, with a trailing space (:992-997) */
+    size_t cmd_len = 2;
+    for (int i = 0; i < argc; ++i)
+        cmd_len += strlen(argv[i]) + 1;
+    char *user_cmd = malloc(cmd_len);
+    user_cmd[0] = 0;
+    for (int i = 0; i < argc; ++i) {
+        strcat(user_cmd, argv[i]);
+        strcat(user_cmd, " ");
+    }
+
+    if (!pu_fn)
+        DIE("[::] ERROR parsing Pileup data; make sure input is valid.\n");
+    pileup_t *pu = pileup_read(pu_fn, uchr);
+    if (!pu)
+        DIE("[::] ERROR parsing Pileup data; make sure input is valid.\n");
+    if (has_A && read_af_file(af_fn, uchr))
+        exit(1);
+    if (has_p) {
+        if (read_pos_file(pos_fn, uchr))
+            exit(1);
+        qsort(pos_tab, pos_n, sizeof *pos_tab, cmp_ul);
+    }
+    if (!in_vcf && !in_impute)
+        DIE("[::] ERROR: Missing genotype files.\n");
+    if (in_vcf && in_impute)
+        DIE("[::] ERROR: 2 types of genotype inputs detected. Please choose either IMPUTE or VCF format.\n");
+    if (in_vcf)
+        DIE("[::] ERROR: VCF input (%s) is not built in this engine yet; convert to IMPUTE (-H/-L/-I).\n", vcf_fn);
+    if (!hap_fn || !legend_fn || !indv_fn)
+        DIE("[::] ERROR parsing hap/legend/indv data; make sure inputs are valid.\n");
+
+    names_t ids;
+    if (read_names(indv_fn, &ids))
+        exit(1);
+    if (ids.n == 0)
+        DIE("[::] ERROR: No samples found in .indv file.\n");
+    const unsigned n_ids = (unsigned)ids.n;
+    idlist_t targets = {NULL, 0}, bg = {NULL, 0};
+    if (has_S) {                                            /* -S wins over -s (:1135-1155) */
+        if (read_idlist_file(sample_fn, &ids, "Sample %s not found in reference panel.\n", "read_sf", &targets))
+            exit(1);
+    } else if (has_s) {
+        if (read_idlist_csv(sample_csv, &ids, &targets))
+            exit(1);
+    } else {
+        targets.n = n_ids;
+        targets.idx = malloc(n_ids * sizeof *targets.idx);
+        for (unsigned i = 0; i < n_ids; ++i)
+            targets.idx[i] = i;
+    }
+    uint8_t *bg_count = NULL;
+    if (has_B) {
+        if (read_idlist_file(bg_fn, &ids, "Reference sample %s not found in input panel.\n", "read_rf", &bg))
+            exit(1);
+        bg_count = calloc(n_ids, 1);
+        for (size_t i = 0; i < bg.n; ++i)
+            if (bg_count[bg.idx[i]] < 255)
+                bg_count[bg.idx[i]]++;
+    }
+    const long pu_id = find_name(&ids, opt_sq);            /* is the pileup's own name in the panel? (:501-506) */
+
+    if (read_genotypes(hap_fn, legend_fn, n_ids))
+        exit(1);
+
+    /* input coverage distribution and cull ratio: find_cull_p (:83-106) */
+    unsigned long in_dist[128] = {0}, in_total = 0;
+    for (size_t i = 0; i < pu->n_lines; ++i)
+        if (pu->lines[i].cov <= opt_max_cov) {
+            in_total += pu->lines[i].cov;
+            in_dist[pu->lines[i].cov]++;
+        }
+    const double mean_cov = (double)in_total / pu->n_lines;
+    double cull_p = 1;
+    if (has_D) {
+        if (opt_target_dp > mean_cov)
+            fprintf(stderr, "Observed depth is lower than target depth -D. No culling will be done.\n");
+        else
+            cull_p = opt_target_dp / mean_cov;
+    }
+
+    /* ---- engine: panel upload, alt counts back for the AF filter ---------------------- */
+    ibdg_ctx *eng = NULL;
+    uint32_t *alt_count = malloc((n_rows ? n_rows : 1) * sizeof *alt_count);
+    if (!opt_plan) {
+        eng = ibdg_create(0, opt_eps, opt_max_cov);
+        if (!eng)
+            DIE("%s\n", ibdg_last_error(NULL));
+        if (ibdg_upload_panel(eng, packed, n_rows, n_ids) || ibdg_get_alt_counts(eng, 0, n_rows, alt_count))
+            DIE("%s\n", ibdg_last_error(eng));
+    } else {
+        for (size_t r = 0; r < n_rows; ++r) {           /* --plan: same integers, on the host */
+            unsigned c = 0;
+            for (size_t w = 0; w < row_words; ++w)
+                c += (unsigned)__builtin_popcountll(packed[r * row_words + w]);
+            alt_count[r] = c;
+        }
+    }
+
+    /* ---- target-independent part of the row filter chain (:589-626) ------------------- */
+    typedef struct { uint32_t row; uint32_t pu; uint8_t n_ref, n_alt; double f; int f_is_override; } cand_t;
+    cand_t *cand = malloc((n_rows ? n_rows : 1) * sizeof *cand);
+    uint8_t *row_fate = calloc(n_rows ? n_rows : 1, 1);   /* 0 skip-before-v, 1 candidate, 2 skipped after the -v test */
+    size_t n_cand = 0;
+    for (size_t r = 0; r < n_rows; ++r) {
+        const row_t *R = &rows[r];
+        row_fate[r] = 2;
+        if (!R->hap_ok) { row_fate[r] = 0; continue; }
+        if (!R->legend_ok) continue;
+        const char *ref = arena + R->ref_off, *alt = arena + R->alt_off;
+        if (!is_snp(ref, alt)) continue;
+        const pu_line *pl = pileup_find(pu, R->pos);
+        if (!pl) continue;
+        if (has_p && !pos_listed(R->pos)) continue;
+        double f = (double)alt_count[r] / (int)(n_ids * 2);
+        int ovr = 0;
+        if (has_A) {
+            const af_rec *a = find_af(R->pos);
+            if (a) { f = a->f; ovr = 1; }
+        }
+        if (f > opt_max_af || f < opt_min_af) continue;
+        const unsigned nr = pileup_count(pl, ref[0]), na = pileup_count(pl, alt[0]);
+        if (nr + na > opt_max_cov) continue;
+        cand_t *c = &cand[n_cand++];
+        c->row = (uint32_t)r; c->pu = (uint32_t)(pl - pu->lines); c->n_ref = (uint8_t)nr; c->n_alt = (uint8_t)na;
+        c->f = f; c->f_is_override = ovr;
+        row_fate[r] = 1;
+    }
+
+    /* ---- per comparison individual (:522-773) ------------------------------------------ */
+    uint32_t *s_row = malloc((n_cand ? n_cand : 1) * 4), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
+    uint8_t *s_nr = malloc(n_cand ? n_cand : 1), *s_na = malloc(n_cand ? n_cand : 1);
+    double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
+    double *site_af = malloc((n_cand ? n_cand : 1) * 8), *site_ll = malloc((n_cand ? n_cand : 1) * 24);
+    for (size_t ti = 0; ti < targets.n; ++ti) {
+        const uint32_t tgt = targets.idx[ti];
+        const char *tname = ids.names[tgt];
+        fprintf(stderr, "Running %s-vs-%s comparison...\n", opt_sq, tname);
+        unsigned long skipped = 0, final_total = 0, final_dist[128] = {0};
+        size_t n = 0;
+        for (size_t r = 0, ci = 0; r < n_rows; ++r) {
+            if (row_fate[r] == 0) { skipped++; continue; }
+            const int is_cand = row_fate[r] == 1;
+            const size_t my = ci;
+            if (is_cand) ci++;
+            if (has_v && row_allele(r, tgt, 0) == 0 && row_allele(r, tgt, 1) == 0) { skipped++; continue; }   /* :584 */
+            if (!is_cand) { skipped++; continue; }
+            const cand_t *c = &cand[my];
+            const unsigned nr = cull(c->n_ref, cull_p), na = cull(c->n_alt, cull_p);                          /* :627-628 */
+            final_total += nr + na;
+            final_dist[nr + na]++;
+            s_row[n] = c->row; s_cand[n] = (uint32_t)my; s_nr[n] = (uint8_t)nr; s_na[n] = (uint8_t)na;
+            if (s_fo) s_fo[n] = c->f_is_override ? c->f : NAN;
+            n++;
+        }
+        const unsigned long processed = n;
+
+        /* windows: runs of opt_window covered rows (:572, :657-663, :723-730) */
+        size_t n_win = 0;
+        uint32_t *w_first = NULL, *w_last = NULL, *w_ncov = NULL;
+        double *win_ll = NULL;
+        if (opt_plan) {
+            size_t covered = 0;
+            for (size_t i = 0; i < n; ++i)
+                covered += (s_nr[i] + s_na[i]) > 0;
+            n_win = (covered + opt_window - 1) / opt_window;
+            w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = calloc(n_win + 1, 4);
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (s_nr[i] + s_na[i] == 0) continue;
+                const size_t w = k / opt_window;
+                if (k % opt_window == 0) w_first[w] = (uint32_t)i;
+                w_last[w] = (uint32_t)i;
+                w_ncov[w]++;
+                k++;
+            }
+        } else {
+            uint32_t one = tgt;
+            if (ibdg_upload_sites(eng, s_row, s_nr, s_na, s_fo, n, (unsigned)opt_window) ||
+                ibdg_run(eng, &one, 1, bg_count, (int)pu_id, opt_ld))
+                DIE("%s\n", ibdg_last_error(eng));
+            n_win = ibdg_num_windows(eng);
+            w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = malloc((n_win + 1) * 4);
+            win_ll = malloc((n_win + 1) * 24);
+            if (ibdg_get_windows(eng, w_first, w_last, w_ncov) || ibdg_get_site_af(eng, site_af) ||
+                ibdg_get_site_ll(eng, 0, site_ll) || ibdg_get_window_ll(eng, 0, win_ll))
+                DIE("%s\n", ibdg_last_error(eng));
+        }
+
+        FILE *tab, *sum;
+        if (opt_plan) {
+            tab = stdout;
+            sum = stdout;
+            printf("## PLAN %s %s processed=%lu skipped=%lu windows=%zu cull_p=%f\n", opt_sq, tname, processed, skipped,
+                   n_win, cull_p);
+        } else {
+            char *tab_fn, *sum_fn;
+            if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
+                asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
+                exit(1);
+            tab = fopen(tab_fn, "w");
+            sum = fopen(sum_fn, "w");
+            if (!tab || !sum) {
+                fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
+                return 1;
+            }
+            free(tab_fn);
+            free(sum_fn);
+            fprintf(tab, "# Entered command: %s\n\n", user_cmd);
+        }
+        /* header block (:144-152, :547-548) */
+        fprintf(tab, "# INPUT COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
+        for (unsigned c = 0; c <= opt_max_cov; ++c)
+            fprintf(tab, "# %d %lu\n", c, in_dist[c]);
+        fprintf(tab, "# MEAN DEPTH = %lf\n# CULL DEPTH RATIO = %lf\n", mean_cov, cull_p);
+        fprintf(tab, "# CHR\trsID\tPOS\tREF\tALT\tAF\tDP\tSQ_NREF\tSQ_NALT\tGT_A0\tGT_A1\tLIBD0\tLIBD1\tLIBD2\n");
+        if (!opt_plan)
+            fprintf(sum, "# SEGMENT\tSTART\tEND\tLIBD0\tLIBD1\tLIBD2\tNUM_SITES\n");
+        for (size_t i = 0; i < n; ++i) {
+            const cand_t *c = &cand[s_cand[i]];
+            const row_t *R = &rows[c->row];
+            const pu_line *pl = &pu->lines[c->pu];
+            const double f = opt_plan ? c->f : site_af[i];
+            fprintf(tab, "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u", pu->chr_names[pl->chr], arena + R->id_off, R->pos,
+                    arena + R->ref_off, arena + R->alt_off, f, (unsigned)pl->cov, (unsigned)s_nr[i], (unsigned)s_na[i],
+                    row_allele(c->row, tgt, 0), row_allele(c->row, tgt, 1));
+            if (opt_plan) {
+                fputc('\n', tab);
+            } else {
+                fputc('\t', tab);
+                print_ll(tab, site_ll[3 * i], '\t');
+                print_ll(tab, site_ll[3 * i + 1], '\t');
+                print_ll(tab, site_ll[3 * i + 2], '\n');
+            }
+        }
+        for (size_t w = 0; w < n_win; ++w) {
+            const unsigned long start = rows[s_row[w_first[w]]].pos, end = rows[s_row[w_last[w]]].pos;
+            if (opt_plan) {
+                printf("## WINDOW %zu\t%lu\t%lu\t%u\n", w + 1, start, end, w_ncov[w]);
+            } else {
+                fprintf(sum, "%zu\t%lu\t%lu\t", w + 1, start, end);
+                print_ll(sum, win_ll[3 * w], '\t');
+                print_ll(sum, win_ll[3 * w + 1], '\t');
+                print_ll(sum, win_ll[3 * w + 2], '\t');
+                fprintf(sum, "%u\n", w_ncov[w]);
+            }
+        }
+        /* footer (:761-768) */
+        fprintf(tab, "# FINAL COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
+        for (unsigned c = 0; c <= opt_max_cov; ++c)
+            fprintf(tab, "# %d %lu\n", c, final_dist[c]);
+        fprintf(tab, "# FINAL MEAN DEPTH = %lf\n", (double)final_total / processed);
+        fprintf(tab, "## Number of sites processed: %lu\n", processed);
+        fprintf(tab, "## Number of sites skipped: %lu\n", skipped);
+        if (!opt_plan) {
+            fclose(tab);
+            fclose(sum);
+        }
+        free(w_first); free(w_last); free(w_ncov); free(win_ll);
+    }
+    if (eng)
+        ibdg_destroy(eng);
+    pileup_free(pu);
+    fprintf(stderr, "Run time: %f minutes.\n", ((double)(clock() - t_start) / CLOCKS_PER_SEC) / 60);
+    return EXIT_SUCCESS;
+}

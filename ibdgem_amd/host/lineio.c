@@ -1,0 +1,86 @@
+#include "lineio.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+struct line_src {
+    FILE *f;
+    gzFile gz;
+    char *buf;
+    size_t cap;
+};
+
+static int name_is_gz(const char *fn)
+{
+    size_t n = strlen(fn);
+    return n >= 3 && strcmp(fn + n - 3, ".gz") == 0;
+}
+
+line_src *ls_open(const char *fn)
+{
+    if (!fn)
+        return NULL;
+    line_src *ls = calloc(1, sizeof *ls);
+    if (!ls)
+        return NULL;
+    if (name_is_gz(fn)) {
+        ls->gz = gzopen(fn, "r");
+        if (ls->gz)
+            gzbuffer(ls->gz, 1 << 20);
+    } else {
+        ls->f = fopen(fn, "r");
+        if (!ls->f) {
+            fprintf(stderr, "Failed to open %s.\n", fn);
+            perror("Error");
+        }
+    }
+    if (!ls->f && !ls->gz) {
+        free(ls);
+        return NULL;
+    }
+    ls->cap = 1 << 16;
+    ls->buf = malloc(ls->cap);
+    return ls;
+}
+
+char *ls_next(line_src *ls, size_t *len)
+{
+    size_t have = 0;
+    for (;;) {
+        char *got = ls->gz ? gzgets(ls->gz, ls->buf + have, (int)(ls->cap - have))
+                           : fgets(ls->buf + have, (int)(ls->cap - have), ls->f);
+        if (!got)
+            break;
+        have += strlen(ls->buf + have);
+        if (have && ls->buf[have - 1] == '\n')
+            break;
+        if (have + 1 < ls->cap)
+            break;                      /* EOF without newline */
+        ls->cap *= 2;
+        ls->buf = realloc(ls->buf, ls->cap);
+    }
+    if (have == 0)
+        return NULL;
+    if (len)
+        *len = have;
+    return ls->buf;
+}
+
+int ls_rewind(line_src *ls)
+{
+    return ls->gz ? gzrewind(ls->gz) : fseek(ls->f, 0, SEEK_SET);
+}
+
+void ls_close(line_src *ls)
+{
+    if (!ls)
+        return;
+    if (ls->gz)
+        gzclose(ls->gz);
+    if (ls->f)
+        fclose(ls->f);
+    free(ls->buf);
+    free(ls);
+}

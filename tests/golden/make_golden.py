@@ -7,6 +7,9 @@ What this script commits under tests/golden/ is DATA:
                                 /root/reference/supplementary/ibdgem-test).
   syn*/input/                   small seeded synthetic IMPUTE panels + pileups
                                 (gzip text, reference file formats).
+  syn*/<case>/ref7/             the UNMODIFIED reference's output files for the same runs
+                                (oracle/_ref/ibdgem, "%e" = 7 digits): byte-for-byte targets
+                                for the host program.
   syn*/<case>/                  what the REFERENCE ITSELF printed for them: the
                                 reference sources compiled where they lie by
                                 oracle/Makefile into oracle/_ref/ibdgem_p17
@@ -37,6 +40,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 REFBIN = os.path.join(REPO, "oracle", "_ref", "ibdgem_p17")
+REFBIN7 = os.path.join(REPO, "oracle", "_ref", "ibdgem")      # unmodified: "%e" outputs, byte-for-byte targets
 REFMATH = os.path.join(REPO, "oracle", "_ref", "libibdmath_ref.so")
 BASES = "ACGT"
 
@@ -120,18 +124,19 @@ def synth(seed, n_ids, n_sites, truth_id, chrom="7"):
 
 
 def run_case(workdir, indir, name, args, outroot):
-    out = os.path.join(workdir, "out_" + name)
-    os.makedirs(out)
-    cmd = [REFBIN] + args + ["-O", out]
-    res = subprocess.run(cmd, cwd=indir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    if res.returncode != 0:
-        raise SystemExit(f"reference failed for {name}: {res.stderr}")
-    for fn in sorted(os.listdir(out)):
-        with open(os.path.join(out, fn)) as fh:
-            lines = fh.readlines()
-        if fn.endswith(".tab.txt"):
-            lines = lines[1:]               # drop '# Entered command:' (container paths)
-        gz_write(os.path.join(outroot, name, fn + ".gz"), "".join(lines))
+    for exe, sub in ((REFBIN, ""), (REFBIN7, "ref7")):
+        out = os.path.join(workdir, "out_" + name + sub)
+        os.makedirs(out)
+        cmd = [exe] + args + ["-O", out]
+        res = subprocess.run(cmd, cwd=indir, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if res.returncode != 0:
+            raise SystemExit(f"reference failed for {name}: {res.stderr}")
+        for fn in sorted(os.listdir(out)):
+            with open(os.path.join(out, fn)) as fh:
+                lines = fh.readlines()
+            if fn.endswith(".tab.txt"):
+                lines = lines[1:]               # drop '# Entered command:' (container paths)
+            gz_write(os.path.join(outroot, name, sub, fn + ".gz"), "".join(lines))
 
 
 def build_syn(tag, seed, n_ids, n_sites, truth_id, cases, extra_files):

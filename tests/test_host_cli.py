@@ -1,0 +1,204 @@
+"""The C host program (ibdgem_amd/host/ibdgem): reference CLI, parsers, row filter chain,
+window boundaries and output files.
+
+CPU part (`--plan`, no device): every integer column, the AF text, the processed/skipped
+counters, the coverage histograms and the window boundaries must equal the reference's
+files for all golden cases (flags -v -D -A -p -c -M -F -f -e -w -B -S -s -N exercised).
+GPU part: the full output files must be byte-identical to what the unmodified reference
+wrote (fixtures: its 18 shipped files; synthetic: tests/golden/syn*/<case>/ref7)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import golden_io as G
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(REPO, "ibdgem_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", os.path.join(REPO, "ibdgem_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    return EXE
+
+
+def parse_plan(text):
+    """stdout of --plan -> {target: dict(rows, comments, windows, processed, skipped)}"""
+    out, cur = {}, None
+    for line in text.splitlines():
+        if line.startswith("## PLAN "):
+            f = line.split()
+            cur = dict(rows=[], comments=[], windows=[], processed=int(f[4].split("=")[1]),
+                       skipped=int(f[5].split("=")[1]))
+            out[f[3]] = cur
+        elif line.startswith("## WINDOW "):
+            cur["windows"].append(line.split("\t")[1:])
+        elif line.startswith("#"):
+            cur["comments"].append(line)
+        elif line:
+            cur["rows"].append(line.split("\t"))
+    return out
+
+
+def check_plan_against(plan, tab, summ):
+    assert plan["processed"] == tab.processed and plan["skipped"] == tab.skipped
+    assert len(plan["rows"]) == len(tab.rows)
+    for got, want in zip(plan["rows"], tab.rows):
+        assert got == want[:11], (got, want)          # CHR rsID POS REF ALT AF DP SQ_NREF SQ_NALT GT_A0 GT_A1
+    want_c = [c for c in tab.comments if not c.startswith("# Entered command")]
+    assert plan["comments"] == want_c                  # histograms, mean depth, cull ratio, counters
+    assert len(plan["windows"]) == len(summ.start)
+    for w, (s, e, n) in enumerate(plan["windows"]):
+        assert (int(s), int(e), int(n)) == (summ.start[w], summ.end[w], summ.nsites[w])
+
+
+FIX_IN = os.path.join(G.GOLD, "ibdgem-test", "input")
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_plan_matches_reference_fixture_files(k):
+    res = subprocess.run([_exe(), "-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", f"test{k}.pileup",
+                          "-N", f"sample{k}", "--plan"], cwd=FIX_IN, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    plan = parse_plan(res.stdout)
+    assert sorted(plan) == ["sample1", "sample2", "sample3"]
+    for t in plan:
+        tab, summ = G.fixture_outputs(f"sample{k}", t)
+        check_plan_against(plan[t], tab, summ)
+    assert "Running sample%d-vs-sample1 comparison..." % k in res.stderr and "Run time:" in res.stderr
+
+
+def _syn_cases():
+    return [(tag, case) for tag in ("synA", "synB") for case in G.cases(tag)["cases"]]
+
+
+@pytest.mark.parametrize("tag,case", _syn_cases())
+def test_plan_matches_reference_on_synthetic_cases(tag, case):
+    meta = G.cases(tag)
+    args = meta["base_args"] + meta["cases"][case]
+    res = subprocess.run([_exe()] + args + ["--plan"], cwd=os.path.join(G.GOLD, tag, "input"), capture_output=True,
+                         text=True)
+    assert res.returncode == 0, res.stderr
+    plan = parse_plan(res.stdout)
+    flags = G.parse_flags(meta["cases"][case])
+    files = sorted(f for f in os.listdir(os.path.join(G.GOLD, tag, case)) if f.endswith(".tab.txt.gz"))
+    assert len(files) == len(plan) > 0
+    for fn in files:
+        name = fn.split(".")[1]
+        tab, summ = G.syn_outputs(tag, case, flags["sq"], name)
+        check_plan_against(plan[name], tab, summ)
+
+
+def test_option_errors_match_the_reference():
+    exe = _exe()
+
+    def run(*a):
+        return subprocess.run([exe, *a], cwd=FIX_IN, capture_output=True, text=True)
+    base = ["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "test1.pileup"]
+    r = run(*base, "-w", "1")
+    assert r.returncode == 0 and "[::] ERROR: Invalid window size (-w) of 1 (must be >= 2)." in r.stderr
+    r = run(*base, "-M", "0")
+    assert r.returncode == 0 and "(-M) of 0 (must be >= 1)" in r.stderr
+    r = run(*base, "-F", "1.5")
+    assert r.returncode == 0 and "(-F) of 1.50 (must be <= 1)" in r.stderr
+    r = run(*base, "-D", "-1")
+    assert r.returncode == 0 and "(-D) of -1.00 (must be > 0)" in r.stderr
+    r = run(*base, "-w")
+    assert r.returncode == 0 and "Option -w missing required argument." in r.stderr
+    r = run("-P", "test1.pileup")
+    assert r.returncode == 1 and "[::] ERROR: Missing genotype files." in r.stderr
+    r = run(*base, "-V", "x.vcf")
+    assert r.returncode == 1 and "2 types of genotype inputs detected" in r.stderr
+    r = run(*base, "-s", "nobody", "--plan")
+    assert r.returncode == 1 and "Sample nobody not found in reference panel." in r.stderr
+    r = run("-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "missing.pileup")
+    assert r.returncode == 1 and "ERROR parsing Pileup data" in r.stderr
+    r = run()
+    assert r.returncode == 0 and "Usage:" in r.stderr
+
+
+def test_read_thinning_stream_is_glibc_rand():
+    """-D thins reads with the reference's unseeded rand() stream (src/ibdgem.c:132); the host
+    restates glibc's generator so that the HIP runtime in the same process cannot disturb it."""
+    import ctypes
+    n = 20000
+    got = subprocess.run([_exe(), "--rand-stream", str(n)], capture_output=True, text=True).stdout.split()
+    code = ("import ctypes\nl = ctypes.CDLL(None)\nprint(' '.join(str(l.rand()) for _ in range(%d)))" % n)
+    want = subprocess.run(["python3", "-c", code], capture_output=True, text=True).stdout.split()   # fresh process
+    assert len(got) == n and got == want
+
+
+def test_pileup_parser_edge_cases(tmp_path):
+    """The byte-matching rule for read counts (reference src/pileup.c:253-415, src/ibdgem.c:620-621)."""
+    d = tmp_path
+    (d / "p.indv").write_text("a\nb\n")
+    (d / "p.legend").write_text("ID pos allele0 allele1\n" + "".join(f"r{i} {10 * i} A C\n" for i in range(1, 9)))
+    (d / "p.hap").write_text("0 1 1 0\n" * 8)
+    (d / "p.pileup").write_text(
+        "1\t10\tA\t4\t.,Cc\tIIII\tIIII\n"           # '.' ',' take the pileup's REF letter A -> 2 ref, 2 alt
+        "1\t20\ta\t3\t..C\tIII\tIII\n"               # lowercase REF column: '.' never matches 'A'
+        "1\t30\tN\t3\tA^]A$+2ACc-1g\tIII\tIII\n"    # read start/end markers and indels are skipped
+        "1\t40\tN\t2\tA*\tII\tII\n"                  # '*' counts towards DP only
+        "1\t50\tN\t2\tAA\tI\tI\n"                    # both quality strings of the wrong length: line dropped
+        "1\t60\tN\t3\tAA\tIII\tIII\n"                # fewer bases than DP: dropped
+        "1\t70\tN\t1\tA\tI\n"                        # six columns only: dropped
+        "1\t80\tN\t0\t*\t*\t*\n")
+    res = subprocess.run([_exe(), "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "a", "--plan"],
+                         cwd=d, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    rows = {int(r[2]): r for r in parse_plan(res.stdout)["a"]["rows"]}
+    assert sorted(rows) == [10, 20, 30, 40, 80]
+    assert rows[10][6:9] == ["4", "2", "2"]
+    assert rows[20][6:9] == ["3", "0", "1"]
+    assert rows[30][6:9] == ["3", "2", "1"]
+    assert rows[40][6:9] == ["2", "1", "0"]
+    assert rows[80][6:9] == ["0", "0", "0"]
+    assert "Incorrect number of bases read in" in res.stderr
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _run_full(args, cwd, out):
+    res = subprocess.run([_exe()] + args + ["-O", str(out)], cwd=cwd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return res
+
+
+def _read(path):
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as fh:
+        return fh.read().splitlines()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_cli_reproduces_the_reference_fixture_files(k, tmp_path):
+    _run_full(["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", f"test{k}.pileup", "-N", f"sample{k}"],
+              FIX_IN, tmp_path)
+    for t in (1, 2, 3):
+        for kind in ("tab", "summary"):
+            fn = f"sample{k}.sample{t}.{kind}.txt"
+            got = _read(str(tmp_path / fn))
+            want = _read(os.path.join(G.GOLD, "ibdgem-test", "output", fn))
+            if kind == "tab":
+                assert got[0].startswith("# Entered command: ") and got[0].endswith(" ")
+                got, want = got[1:], want[1:]
+            assert got == want, fn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,case", _syn_cases())
+def test_cli_reproduces_the_reference_on_synthetic_cases(tag, case, tmp_path):
+    meta = G.cases(tag)
+    _run_full(meta["base_args"] + meta["cases"][case], os.path.join(G.GOLD, tag, "input"), tmp_path)
+    ref = os.path.join(G.GOLD, tag, case, "ref7")
+    files = sorted(os.listdir(ref))
+    assert files and sorted(os.listdir(tmp_path)) == [f[:-3] for f in files]
+    for fn in files:
+        got = _read(str(tmp_path / fn[:-3]))
+        want = _read(os.path.join(ref, fn))
+        if fn.endswith(".tab.txt.gz"):
+            got = got[1:]
+        assert got == want, f"{tag}/{case}/{fn}"
