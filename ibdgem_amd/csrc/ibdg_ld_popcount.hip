@@ -143,8 +143,9 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 //   All LDS reads in the loop are asm: hipcc drains vmcnt(0) before any LDS read that follows
 //   a direct-to-LDS load, which would serialise the ring (and so would table look-ups from
 //   global memory at the end of every window -- hence the tables in LDS).
-// Arithmetic per segment: for every weight bit-plane up to the highest non-empty one 14 VALU
-// ops for the seven cov-weighted counts and 4 for the two alt-weighted ones.
+// Arithmetic per segment: per weight bit-plane 14 VALU ops for the seven cov-weighted counts
+// and 4 for the two alt-weighted ones; three cov planes and two alt planes unconditionally,
+// higher planes (rare) under one uniform test.
 // At the end of each window the lane turns its counts into the five products, the wave sums
 // count[n]*product over its 64 individuals (fixed shuffle order) and lane 0 stores the
 // per-chunk partial; k_ld_finalize adds the chunks in ascending order and divides.
@@ -208,7 +209,7 @@ __device__ __forceinline__ double ld_value(double mK, int eK, const uint4 &p1, c
     return __builtin_ldexp(m, eK + (int)p1.z + (int)p2.z - (int)E3);
 }
 
-template <int KP, int NS, bool TAB_LDS>
+template <int NS, bool TAB_LDS>
 __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
                                                      const uint2 *__restrict__ twords,
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                                                      const uint4 *__restrict__ pow_eps,
                                                      PopArgs a)
 {
+    constexpr int FC = 3, FA = 2;      // weight bit-planes with counters of their own (cov, alt)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
@@ -279,10 +281,16 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
     const double wgt = a.weight[(size_t)t * a.lanes + c * 64 + lane];
 
-    uint32_t c0[KP], c1[KP], ch[KP], g00[KP], g01[KP], g10[KP], g11[KP], A0[KP], A1[KP];
+    // Counters per weight bit-plane: three planes for the cov-weighted sums, two for the
+    // alt-weighted ones are kept apart (one v_bcnt_u32_b32 accumulates into them directly);
+    // the rare higher planes are shifted into plane 0 as they are counted.
+    uint32_t c0[FC], c1[FC], ch[FC], g00[FC], g01[FC], g10[FC], g11[FC], A0[FA], A1[FA];
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
-        c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = A0[k] = A1[k] = 0;
+    for (int k = 0; k < FC; ++k)
+        c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = 0;
+#pragma unroll
+    for (int k = 0; k < FA; ++k)
+        A0[k] = A1[k] = 0;
 
     // ---- prime the ring: pairs qcur .. qcur+NS-1 (not past the run's last pair)
     uint32_t tile = segs[seg0].tile;                 // tile of the segment being fetched
@@ -323,42 +331,58 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                                     __builtin_amdgcn_readlane(recw, RW_TW + 1));   // target's haplotypes
         tile += flags >> 16;                         // tile of the next segment
 
+        // every mask the common case needs, read up front (v_readlane -> SGPR)
+        const uint32_t cov0 = __builtin_amdgcn_readlane(recw, RW_COV), cov1 = __builtin_amdgcn_readlane(recw, RW_COV + 1);
+        const uint32_t cov2 = __builtin_amdgcn_readlane(recw, RW_COV + 2);
+        const uint32_t alt0 = __builtin_amdgcn_readlane(recw, RW_ALT), alt1 = __builtin_amdgcn_readlane(recw, RW_ALT + 1);
 #if IBDG_TIMING_EXPERIMENT
-        const uint32_t ncov = (a.debug & 2) ? 0 : (flags & 0xff), nalt = (a.debug & 2) ? 0 : ((flags >> 8) & 0xff);
+        const bool count = !(a.debug & 2);
 #else
-        const uint32_t ncov = flags & 0xff, nalt = (flags >> 8) & 0xff;
+        const bool count = true;
 #endif
+        const uint32_t ncov = flags & 0xff, nalt = (flags >> 8) & 0xff;
         const uint32_t hom = x.x & x.y;
-#define IBDG_COV_PLANE(k)                                                   \
+#define IBDG_COV_PLANE(k, cov)                                              \
     {                                                                       \
-        const uint32_t cov = __builtin_amdgcn_readlane(recw, RW_COV + (k)); \
-        const uint32_t u0 = x.x & cov, u1 = x.y & cov;                      \
+        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
         c0[k] += __popc(u0);                                                \
         c1[k] += __popc(u1);                                                \
-        ch[k] += __popc(hom & cov);                                         \
+        ch[k] += __popc(hom & (cov));                                       \
         g00[k] += __popc(u0 & at.x);                                        \
         g01[k] += __popc(u1 & at.x);                                        \
         g10[k] += __popc(u0 & at.y);                                        \
         g11[k] += __popc(u1 & at.y);                                        \
     }
-#define IBDG_ALT_PLANE(k)                                                   \
-    {                                                                       \
-        const uint32_t alt = __builtin_amdgcn_readlane(recw, RW_ALT + (k)); \
-        A0[k] += __popc(x.x & alt);                                         \
-        A1[k] += __popc(x.y & alt);                                         \
-    }
-        // one uniform skip per plane (a fall-through switch makes hipcc copy every
-        // accumulator at every case label)
-#pragma unroll
-        for (int k = 0; k < KP; ++k)
-            if ((uint32_t)k < ncov)
-                IBDG_COV_PLANE(k)
-#pragma unroll
-        for (int k = 0; k < KP; ++k)
-            if ((uint32_t)k < nalt)
-                IBDG_ALT_PLANE(k)
+        if (count) {
+            // planes 0-2 of cov and 0-1 of alt are non-empty in nearly every segment: no test
+            // (an empty mask adds zero); higher planes are rare and go the slow way
+            IBDG_COV_PLANE(0, cov0)
+            IBDG_COV_PLANE(1, cov1)
+            IBDG_COV_PLANE(2, cov2)
+            A0[0] += __popc(x.x & alt0);
+            A1[0] += __popc(x.y & alt0);
+            A0[1] += __popc(x.x & alt1);
+            A1[1] += __popc(x.y & alt1);
+            if (ncov > FC || nalt > FA) {
+                for (uint32_t k = FC; k < ncov; ++k) {
+                    const uint32_t cov = __builtin_amdgcn_readlane(recw, RW_COV + k);
+                    const uint32_t u0 = x.x & cov, u1 = x.y & cov;
+                    c0[0] += (uint32_t)__popc(u0) << k;
+                    c1[0] += (uint32_t)__popc(u1) << k;
+                    ch[0] += (uint32_t)__popc(hom & cov) << k;
+                    g00[0] += (uint32_t)__popc(u0 & at.x) << k;
+                    g01[0] += (uint32_t)__popc(u1 & at.x) << k;
+                    g10[0] += (uint32_t)__popc(u0 & at.y) << k;
+                    g11[0] += (uint32_t)__popc(u1 & at.y) << k;
+                }
+                for (uint32_t k = FA; k < nalt; ++k) {
+                    const uint32_t alt = __builtin_amdgcn_readlane(recw, RW_ALT + k);
+                    A0[0] += (uint32_t)__popc(x.x & alt) << k;
+                    A1[0] += (uint32_t)__popc(x.y & alt) << k;
+                }
+            }
+        }
 #undef IBDG_COV_PLANE
-#undef IBDG_ALT_PLANE
 
         if (last) {
             const uint32_t w = __builtin_amdgcn_readlane(recw, RW_WIN);
@@ -373,10 +397,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 const uint32_t CT = __builtin_amdgcn_readlane(wcw, WC_CT), AT = __builtin_amdgcn_readlane(wcw, WC_AT);
                 const uint32_t a0cov = __builtin_amdgcn_readlane(wcw, WC_A0COV), a1cov = __builtin_amdgcn_readlane(wcw, WC_A1COV);
                 const uint32_t a0alt = __builtin_amdgcn_readlane(wcw, WC_A0ALT), a1alt = __builtin_amdgcn_readlane(wcw, WC_A1ALT);
-                const uint32_t C0 = planes_sum<KP>(c0), C1 = planes_sum<KP>(c1), CH = planes_sum<KP>(ch);
-                const uint32_t G00 = planes_sum<KP>(g00), G01 = planes_sum<KP>(g01);
-                const uint32_t G10 = planes_sum<KP>(g10), G11 = planes_sum<KP>(g11);
-                const uint32_t a0 = planes_sum<KP>(A0), a1 = planes_sum<KP>(A1);
+                const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
+                const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
+                const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
+                const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
                 uint32_t E2[5], E3[5];
                 E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
                 E3[1] = a0cov + C0 - 2 * G00;  E2[1] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
@@ -418,8 +442,11 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 }
             }
 #pragma unroll
-            for (int k = 0; k < KP; ++k)
-                c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = A0[k] = A1[k] = 0;
+            for (int k = 0; k < FC; ++k)
+                c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = 0;
+#pragma unroll
+            for (int k = 0; k < FA; ++k)
+                A0[k] = A1[k] = 0;
         }
     }
     // leave no direct-to-LDS load in flight when the wave ends
@@ -474,11 +501,11 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
     return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024;
 }
 
-template <int KP, int NS, bool TAB>
+template <int NS, bool TAB>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
 {
     const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS);
-    auto kern = k_ld_popcount<KP, NS, TAB>;
+    auto kern = k_ld_popcount<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
@@ -487,23 +514,16 @@ static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
     return 0;
 }
 
-template <int KP>
-static int launch_pop_kp(const PopArgs &a, dim3 grid, hipStream_t st)
-{
-    if (a.ring_slots == 4)
-        return a.tab_in_lds ? launch_pop<KP, 4, true>(a, grid, st) : launch_pop<KP, 4, false>(a, grid, st);
-    return a.tab_in_lds ? launch_pop<KP, 8, true>(a, grid, st) : launch_pop<KP, 8, false>(a, grid, st);
-}
-
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st)
 {
     if (a.n_win == 0)
         return 0;
+    if (planes < 1 || planes > 8)
+        return 1;
     dim3 grid((a.n_win + a.win_per_group - 1) / a.win_per_group, (a.n_chunks + 7) / 8, n_targets);
-    if (planes <= 3) return launch_pop_kp<3>(a, grid, st);
-    if (planes <= 5) return launch_pop_kp<5>(a, grid, st);
-    if (planes <= 7) return launch_pop_kp<7>(a, grid, st);
-    return 1;
+    if (a.ring_slots == 4)
+        return a.tab_in_lds ? launch_pop<4, true>(a, grid, st) : launch_pop<4, false>(a, grid, st);
+    return a.tab_in_lds ? launch_pop<8, true>(a, grid, st) : launch_pop<8, false>(a, grid, st);
 }
 
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st)
