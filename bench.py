@@ -84,20 +84,6 @@ def build_shard(torch, dev, row0, row1, n_ids, target, seed):
     return panel, np.concatenate(nrs), np.concatenate(nas)
 
 
-def shard_bounds(n_ref, n_alt, window, world):
-    """Cut rows so that every rank gets a whole number of windows (window = `window` covered rows)."""
-    covered = (n_ref.astype(np.int32) + n_alt) > 0
-    csum = np.cumsum(covered)
-    n_win = (int(csum[-1]) + window - 1) // window
-    cuts = [0]
-    for r in range(1, world):
-        w = (n_win * r) // world
-        # first row AFTER the (w*window)-th covered row
-        cuts.append(int(np.searchsorted(csum, w * window, side="left")) + 1)
-    cuts.append(len(covered))
-    return cuts
-
-
 # ----------------------------------------------------------------------------- CPU baseline (reference binary)
 def unpack_rows(words, n_ids):
     """packed uint64 [L][2*chunks] -> alleles uint8 [L][2*n_ids] ([2n]=first, [2n+1]=second)."""
@@ -252,7 +238,8 @@ def main():
             del w
         nr_all = np.concatenate(nr_all)[:L]
         na_all = np.concatenate(na_all)[:L]
-        cuts = shard_bounds(nr_all, na_all, args.window, world)
+        from ibdgem_amd.sharding import shard_rows
+        cuts = shard_rows(nr_all, na_all, args.window, world)
         row0, row1 = cuts[rank], cuts[rank + 1]
     else:
         row0, row1 = 0, L
