@@ -9,6 +9,15 @@ import sys
 
 import pytest
 
+# torch (used by the full-size tests and bench.py to generate synthetic panels on the device)
+# ships its own HIP runtime; load it before libibdgem_hip.so pulls in the system one, otherwise
+# the second runtime in the process sees no device.
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:                                   # pragma: no cover
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))

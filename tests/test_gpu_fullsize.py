@@ -1,0 +1,151 @@
+"""Parity at BASELINE.json sizes (GPU).
+
+configs[1]  non-LD, ~100k SNP rows, 1 comparison individual   -> bit-exact vs the oracle
+configs[2]  --LD, ~100k rows, 100-individual panel, window 100 -> per-site bit-exact, LD 1e-10
+configs[3]  --LD, 4M rows, 2504-individual panel, window 100   -> the oracle cannot run this in
+            seconds, so: (a) 64 windows sampled across the chromosome are recomputed by the oracle
+            from the panel rows read back from the device input, (b) the strict and the
+            exponent-counting kernels agree on every window, (c) two half-chromosome shards cut at a
+            window boundary reproduce the whole, (d) a second run is bit-identical, (e) alt counts of
+            sampled rows equal numpy popcounts.
+The synthetic data are bench.py's (same generator, same seed)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from ibdgem_amd import engine as E            # noqa: E402
+from ibdgem_amd.sharding import shard_rows    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TINY = 1e-290
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def ld_close(got, want, rtol=1e-10):
+    got, want = np.asarray(got), np.asarray(want)
+    tiny = np.abs(want) < TINY
+    assert (np.abs(got[tiny]) < TINY).all()
+    rel = np.abs(got[~tiny] - want[~tiny]) / np.abs(want[~tiny])
+    assert rel.size == 0 or rel.max() <= rtol, rel.max()
+    return 0.0 if rel.size == 0 else float(rel.max())
+
+
+def synth_host(seed, L, N):
+    rng = np.random.default_rng(seed)
+    f = np.clip(rng.beta(0.3, 1.0, size=L), 1e-3, 0.999)
+    alle = np.empty((L, 2 * N), dtype=np.uint8)
+    for a in range(0, L, 20000):
+        b = min(L, a + 20000)
+        alle[a:b] = rng.random((b - a, 2 * N)) < f[a:b, None]
+    cov = np.minimum(rng.poisson(2.0, size=L), 20)
+    n_alt = rng.binomial(cov, f)
+    return alle, (cov - n_alt).astype(np.uint8), n_alt.astype(np.uint8)
+
+
+def test_config1_nonld_100k_rows(oracle):
+    L, N = 100_000, 64
+    alle, nr, na = synth_host(1, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([11], ld=False)
+        res = oracle.compare(alle, nr, na, 11, window=100, ld=False)
+        assert (bits(eng.site_ll(0)) == bits(res["site"])).all()
+        assert (bits(eng.site_af()) == bits(res["af"])).all()
+        assert (bits(eng.window_ll(0)) == bits(res["win"])).all()
+        first, last, ncov = eng.windows()
+        assert (first == res["first"]).all() and (last == res["last"]).all() and (ncov == res["nsites"]).all()
+
+
+def test_config2_ld_100k_rows_100_individuals(oracle):
+    L, N = 100_000, 100
+    alle, nr, na = synth_host(2, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        res = oracle.compare(alle, nr, na, 42, window=100, ld=True)
+        for variant in (1, 2):
+            eng.set_option("ld_variant", variant)
+            eng.run([42], ld=True)
+            assert eng.last_ld_variant() == variant
+            assert (bits(eng.site_ll(0)) == bits(res["site"])).all()
+            win = eng.window_ll(0)
+            assert (bits(win[:, 2]) == bits(res["win"][:, 2])).all()
+            ld_close(win[:, :2], res["win"][:, :2])
+
+
+@pytest.fixture(scope="module")
+def chr1():
+    """bench.py's 4M x 2504 workload, panel resident in an engine."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    L, N, target, seed = 4_000_000, 2504, 7, 20241008
+    panel, nr, na = bench.build_shard(torch, dev, 0, L, N, target, seed)
+    torch.cuda.synchronize()
+    eng = E.Engine(0, 0.02, 20)
+    eng.upload_panel_dev(panel.data_ptr(), L, N)
+    yield dict(eng=eng, panel=panel, nr=nr, na=na, L=L, N=N, target=target, torch=torch)
+    eng.close()
+
+
+def test_config3_chr1_2504_individuals(chr1, oracle):
+    import bench
+    eng, nr, na, L, N, t = chr1["eng"], chr1["nr"], chr1["na"], chr1["L"], chr1["N"], chr1["target"]
+    eng.upload_sites(np.arange(L, dtype=np.uint32), nr, na, 100)
+    eng.run([t], ld=True)
+    assert eng.last_ld_variant() == 2
+    win = eng.window_ll(0)
+    site = eng.site_ll(0)
+    first, last, ncov = eng.windows()
+    n_win = len(win)
+    assert n_win == (int(((nr.astype(int) + na) > 0).sum()) + 99) // 100 and (ncov[:-1] == 100).all()
+
+    # (d) run-to-run determinism
+    eng.run([t], ld=True)
+    assert (bits(eng.window_ll(0)) == bits(win)).all() and (bits(eng.site_ll(0)) == bits(site)).all()
+
+    # (b) strict kernel (reference operation order per individual) on every window
+    eng.set_option("ld_variant", 1)
+    eng.run([t], ld=True)
+    strict = eng.window_ll(0)
+    eng.set_option("ld_variant", 0)
+    assert (bits(strict[:, 2]) == bits(win[:, 2])).all()
+    worst = ld_close(win[:, :2], strict[:, :2])
+    print(f"exponent counting vs strict over {n_win} windows: max rel {worst:.2e}")
+
+    # (a) oracle on sampled windows, from the rows as the device received them
+    rng = np.random.default_rng(5)
+    pick = np.unique(np.concatenate([[0, 1, n_win - 2, n_win - 1], rng.integers(0, n_win, 60)]))
+    for w in pick:
+        a, b = int(first[w]), int(last[w]) + 1
+        words = chr1["panel"][a:b].cpu().numpy().view(np.uint64)
+        alle = bench.unpack_rows(words, N)
+        res = oracle.compare(alle, nr[a:b], na[a:b], t, window=100, ld=True)
+        assert len(res["win"]) == 1 and res["nsites"][0] == ncov[w]
+        assert (bits(site[a:b]) == bits(res["site"])).all(), w
+        assert bits(win[w, 2]) == bits(res["win"][0, 2])
+        ld_close(win[w:w + 1, :2], res["win"][:, :2])
+
+    # (e) alt counts
+    rows = rng.integers(0, L, 200)
+    for r in rows:
+        words = chr1["panel"][int(r)].cpu().numpy().view(np.uint64)
+        assert eng.alt_counts(int(r), 1)[0] == sum(bin(int(x)).count("1") for x in words)
+
+    # (c) two shards cut at a window boundary reproduce the whole (the multi-GPU decomposition)
+    cuts = shard_rows(nr, na, 100, 2)
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.upload_sites(np.arange(a, b, dtype=np.uint32), nr[a:b], na[a:b], 100)
+        eng.run([t], ld=True)
+        parts.append(eng.window_ll(0))
+    assert (bits(np.concatenate(parts)) == bits(win)).all()
