@@ -25,6 +25,7 @@
 #include <getopt.h>
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +49,7 @@ static struct option longopts[] = {
     {"LD", no_argument, &opt_ld, 1},
     {"plan", no_argument, &opt_plan, 1},
     {"rand-stream", required_argument, 0, 1000},
+    {"devices", required_argument, 0, 1001},
     {"vcf", required_argument, 0, 'V'},
     {"hap", required_argument, 0, 'H'},
     {"legend", required_argument, 0, 'L'},
@@ -96,6 +98,9 @@ static void usage(int code)
           "  -c/--chromosome STR       use only this chromosome of the pileup / -A / -p files\n"
           "  -e/--error-rate FLOAT     sequencing error rate (default 0.02)\n"
           "  -v/--variable-sites-only  skip sites where the compared individual is 0/0\n"
+          "  --devices LIST            GPUs to spread the windows of each comparison over, e.g. 0,1,2,3\n"
+          "                            (default 0); every GPU holds the whole panel, the windows are cut\n"
+          "                            into contiguous ranges, one per GPU, and gathered on the host\n"
           "  --plan                    print the filtered rows and windows only (no device needed)\n"
           "  -h/--help\n\n"
           "Outputs <out>/<pileup-name>.<individual>.tab.txt with columns\n"
@@ -433,6 +438,66 @@ static void print_ll(FILE *fp, double v, char sep)
     fputc(sep, fp);
 }
 
+/* ---- one comparison spread over several GPUs (window ranges, host-side gather) ------------ */
+typedef struct {
+    ibdg_ctx *eng;
+    /* inputs: a contiguous slice [a,b) of the comparison's site list */
+    const uint32_t *row;
+    const uint8_t *nr, *na;
+    const double *fo;
+    size_t a, b;
+    unsigned window;
+    uint32_t target;
+    const uint8_t *bg_count;
+    int pu_id, ld;
+    /* outputs, written at the slice's offsets of the comparison-wide arrays */
+    double *site_af, *site_ll;
+    uint32_t *w_first, *w_last, *w_ncov;     /* slice-local arrays, window indices local */
+    double *win_ll;
+    size_t n_win;
+    int failed;
+} shard_job;
+
+static void *shard_run(void *arg)
+{
+    shard_job *j = arg;
+    const size_t n = j->b - j->a;
+    j->failed = 1;
+    if (ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a, j->fo ? j->fo + j->a : NULL, n,
+                          j->window) ||
+        ibdg_run(j->eng, &j->target, 1, j->bg_count, j->pu_id, j->ld))
+        return NULL;
+    j->n_win = ibdg_num_windows(j->eng);
+    j->w_first = malloc((j->n_win + 1) * 4);
+    j->w_last = malloc((j->n_win + 1) * 4);
+    j->w_ncov = malloc((j->n_win + 1) * 4);
+    j->win_ll = malloc((j->n_win + 1) * 24);
+    if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_site_af(j->eng, j->site_af + j->a) ||
+        ibdg_get_site_ll(j->eng, 0, j->site_ll + 3 * j->a) || ibdg_get_window_ll(j->eng, 0, j->win_ll))
+        return NULL;
+    j->failed = 0;
+    return NULL;
+}
+
+/* cut points of a site list into `parts` contiguous pieces holding whole windows
+ * (a window = `window` consecutive covered rows; uncovered rows stay with the open window) */
+static void window_cuts(const uint8_t *nr, const uint8_t *na, size_t n, unsigned window, int parts, size_t *cuts)
+{
+    size_t covered = 0;
+    for (size_t i = 0; i < n; ++i)
+        covered += (nr[i] + na[i]) > 0;
+    const size_t n_win = (covered + window - 1) / window;
+    cuts[0] = 0;
+    size_t seen = 0, i = 0;
+    for (int p = 1; p < parts; ++p) {
+        const size_t want = (n_win * (size_t)p / (size_t)parts) * window;    /* covered rows before this cut */
+        while (i < n && seen < want)
+            seen += (nr[i] + na[i]) > 0, ++i;
+        cuts[p] = want >= covered ? n : i;
+    }
+    cuts[parts] = n;
+}
+
 #define DIE(...)                          \
     do {                                  \
         fprintf(stderr, __VA_ARGS__);     \
@@ -444,7 +509,7 @@ int main(int argc, char **argv)
     const clock_t t_start = clock();
     const char *hap_fn = NULL, *legend_fn = NULL, *indv_fn = NULL, *pu_fn = NULL, *vcf_fn = NULL;
     const char *sample_fn = NULL, *sample_csv = NULL, *bg_fn = NULL, *af_fn = NULL, *pos_fn = NULL;
-    const char *uchr = NULL, *out_dir = NULL;
+    const char *uchr = NULL, *out_dir = NULL, *devices_arg = "0";
     char cwd[PATH_MAX];
     if (argc == 1)
         usage(0);
@@ -476,6 +541,7 @@ int main(int argc, char **argv)
         case 'D': opt_target_dp = atof(optarg); has_D = 1; break;
         case 'v': has_v = 1; break;
         case 'h': usage(0); break;
+        case 1001: devices_arg = optarg; break;
         case 1000:                                  /* test hook: the first N values of the read-thinning stream */
             for (long i = atol(optarg); i > 0; --i)
                 printf("%d\n", glibc_rand());
@@ -583,14 +649,24 @@ int main(int argc, char **argv)
     }
 
     /* ---- engine: panel upload, alt counts back for the AF filter ---------------------- */
-    ibdg_ctx *eng = NULL;
+    ibdg_ctx *engs[64];
+    int n_eng = 0;
     uint32_t *alt_count = malloc((n_rows ? n_rows : 1) * sizeof *alt_count);
     if (!opt_plan) {
-        eng = ibdg_create(0, opt_eps, opt_max_cov);
-        if (!eng)
-            DIE("%s\n", ibdg_last_error(NULL));
-        if (ibdg_upload_panel(eng, packed, n_rows, n_ids) || ibdg_get_alt_counts(eng, 0, n_rows, alt_count))
-            DIE("%s\n", ibdg_last_error(eng));
+        char *dl = strdup(devices_arg);
+        for (char *tok = strtok(dl, ","); tok && n_eng < 64; tok = strtok(NULL, ",")) {
+            ibdg_ctx *e = ibdg_create(atoi(tok), opt_eps, opt_max_cov);
+            if (!e)
+                DIE("%s\n", ibdg_last_error(NULL));
+            if (ibdg_upload_panel(e, packed, n_rows, n_ids))      /* every GPU holds the whole panel */
+                DIE("%s\n", ibdg_last_error(e));
+            engs[n_eng++] = e;
+        }
+        free(dl);
+        if (n_eng == 0)
+            DIE("[::] ERROR: --devices needs at least one device index.\n");
+        if (ibdg_get_alt_counts(engs[0], 0, n_rows, alt_count))
+            DIE("%s\n", ibdg_last_error(engs[0]));
     } else {
         for (size_t r = 0; r < n_rows; ++r) {           /* --plan: same integers, on the host */
             unsigned c = 0;
@@ -678,16 +754,45 @@ int main(int argc, char **argv)
                 k++;
             }
         } else {
-            uint32_t one = tgt;
-            if (ibdg_upload_sites(eng, s_row, s_nr, s_na, s_fo, n, (unsigned)opt_window) ||
-                ibdg_run(eng, &one, 1, bg_count, (int)pu_id, opt_ld))
-                DIE("%s\n", ibdg_last_error(eng));
-            n_win = ibdg_num_windows(eng);
+            /* one contiguous window range per GPU, evaluated concurrently, gathered in order */
+            size_t cuts[65];
+            shard_job jobs[64];
+            pthread_t th[64];
+            window_cuts(s_nr, s_na, n, (unsigned)opt_window, n_eng, cuts);
+            for (int d = 0; d < n_eng; ++d) {
+                shard_job *j = &jobs[d];
+                memset(j, 0, sizeof *j);
+                j->eng = engs[d]; j->row = s_row; j->nr = s_nr; j->na = s_na; j->fo = s_fo;
+                j->a = cuts[d]; j->b = cuts[d + 1]; j->window = (unsigned)opt_window; j->target = tgt;
+                j->bg_count = bg_count; j->pu_id = (int)pu_id; j->ld = opt_ld;
+                j->site_af = site_af; j->site_ll = site_ll;
+                if (n_eng == 1)
+                    shard_run(j);
+                else if (pthread_create(&th[d], NULL, shard_run, j))
+                    DIE("[::] ERROR: cannot start a worker thread.\n");
+            }
+            n_win = 0;
+            for (int d = 0; d < n_eng; ++d) {
+                if (n_eng > 1)
+                    pthread_join(th[d], NULL);
+                if (jobs[d].failed)
+                    DIE("%s\n", ibdg_last_error(jobs[d].eng));
+                n_win += jobs[d].n_win;
+            }
             w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = malloc((n_win + 1) * 4);
             win_ll = malloc((n_win + 1) * 24);
-            if (ibdg_get_windows(eng, w_first, w_last, w_ncov) || ibdg_get_site_af(eng, site_af) ||
-                ibdg_get_site_ll(eng, 0, site_ll) || ibdg_get_window_ll(eng, 0, win_ll))
-                DIE("%s\n", ibdg_last_error(eng));
+            size_t wo = 0;
+            for (int d = 0; d < n_eng; ++d) {
+                shard_job *j = &jobs[d];
+                for (size_t w = 0; w < j->n_win; ++w) {
+                    w_first[wo + w] = j->w_first[w] + (uint32_t)j->a;
+                    w_last[wo + w] = j->w_last[w] + (uint32_t)j->a;
+                    w_ncov[wo + w] = j->w_ncov[w];
+                    memcpy(win_ll + 3 * (wo + w), j->win_ll + 3 * w, 24);
+                }
+                wo += j->n_win;
+                free(j->w_first); free(j->w_last); free(j->w_ncov); free(j->win_ll);
+            }
         }
 
         FILE *tab, *sum;
@@ -761,8 +866,8 @@ int main(int argc, char **argv)
         }
         free(w_first); free(w_last); free(w_ncov); free(win_ll);
     }
-    if (eng)
-        ibdg_destroy(eng);
+    for (int d = 0; d < n_eng; ++d)
+        ibdg_destroy(engs[d]);
     pileup_free(pu);
     fprintf(stderr, "Run time: %f minutes.\n", ((double)(clock() - t_start) / CLOCKS_PER_SEC) / 60);
     return EXIT_SUCCESS;

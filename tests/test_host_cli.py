@@ -202,3 +202,22 @@ def test_cli_reproduces_the_reference_on_synthetic_cases(tag, case, tmp_path):
         if fn.endswith(".tab.txt.gz"):
             got = got[1:]
         assert got == want, f"{tag}/{case}/{fn}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,devices", [("ld_default", "0,0"), ("ld_downsample", "0,0,0"), ("ld_varsites", "0,0,0,0,0"),
+                                          ("nonld_all_targets_w2", "0,0,0")])
+def test_cli_window_sharding_over_several_contexts(case, devices, tmp_path):
+    """--devices: the windows of each comparison are cut into contiguous ranges, one per engine
+    context (here several contexts on the one GPU of the test box), evaluated by one host thread
+    each and gathered on the host -- output files still byte-identical to the reference's."""
+    meta = G.cases("synA")
+    _run_full(meta["base_args"] + meta["cases"][case] + ["--devices", devices], os.path.join(G.GOLD, "synA", "input"),
+              tmp_path)
+    ref = os.path.join(G.GOLD, "synA", case, "ref7")
+    for fn in sorted(os.listdir(ref)):
+        got = _read(str(tmp_path / fn[:-3]))
+        want = _read(os.path.join(ref, fn))
+        if fn.endswith(".tab.txt.gz"):
+            got = got[1:]
+        assert got == want, f"{case}/{fn} with --devices {devices}"

@@ -65,7 +65,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_over_gloo_reproduce_the_unsharded_result(oracle):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp      # the parent stays torch-free; the two ranks import torch themselves
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
