@@ -692,6 +692,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.pow_tab = (const double *)c->pow_tab.p;
     sa.fo = c->have_fo ? (const double *)c->fo.p : nullptr;
     sa.targets = (const uint32_t *)c->targets.p;
+    sa.t32 = c->pop_lut_ok ? (const uint4 *)c->t32.p : nullptr;
+    sa.n_pairs = c->n_pairs;
     sa.af = (double *)c->af.p;
     sa.site_ll = (double *)c->site_ll.p;
     ibdg::launch_site(sa, (unsigned)T, c->stream);

@@ -18,6 +18,8 @@ struct SiteArgs {
     const double *pow_tab;      // [2*n_ids+1][2] = pow(1-f,2), pow(f,2) at f=k/(2N)
     const double *fo;           // NULL or [n_sites][3] = f, pow(1-f,2), pow(f,2) (-A)
     const uint32_t *targets;    // [T]
+    const uint4 *t32;           // tile-transposed panel (NULL if not built) and its pairs per chunk
+    uint32_t n_pairs;
     double *af;                 // [n_sites]
     double *site_ll;            // [T][n_sites][3]
 };

@@ -78,8 +78,19 @@ __global__ __launch_bounds__(256) void k_site(SiteArgs a)
         }
     }
     const uint32_t tgt = a.targets[t];
-    const unsigned A0 = (unsigned)(row[2 * (tgt >> 6)] >> (tgt & 63)) & 1u;
-    const unsigned A1 = (unsigned)(row[2 * (tgt >> 6) + 1] >> (tgt & 63)) & 1u;
+    unsigned A0, A1;
+    if (a.t32) {
+        // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
+        // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
+        const uint2 *tw = reinterpret_cast<const uint2 *>(
+            a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc.x >> 6)) * 64 + (tgt & 63));
+        const uint2 w = tw[(rc.x >> 5) & 1];
+        A0 = (w.x >> (rc.x & 31)) & 1u;
+        A1 = (w.y >> (rc.x & 31)) & 1u;
+    } else {
+        A0 = (unsigned)(row[2 * (tgt >> 6)] >> (tgt & 63)) & 1u;
+        A1 = (unsigned)(row[2 * (tgt >> 6) + 1] >> (tgt & 63)) & 1u;
+    }
     const unsigned g = A0 + A1;
 
     const double omf = 1 - f;
