@@ -327,8 +327,13 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         lds_fetch(recw, x, rec_lane + s * (IBDG_REC_WORDS * 4), ring_lane + (q % NS) * 1024 + (tile & 1) * 8);
         const uint32_t flags = __builtin_amdgcn_readlane(recw, RW_FLAGS);
         const uint32_t last = __builtin_amdgcn_readlane(recw, RW_LAST);
-        const uint2 at = make_uint2(__builtin_amdgcn_readlane(recw, RW_TW),
-                                    __builtin_amdgcn_readlane(recw, RW_TW + 1));   // target's haplotypes
+        // the target's haplotype words, broadcast to every lane ONCE per segment: as VGPRs they can
+        // sit next to an SGPR mask in v_bitop3 (one scalar operand per VALU instruction); left in
+        // SGPRs hipcc re-materialises them with a v_mov in every plane
+        uint2 at;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                     : "=v"(at.x), "=v"(at.y)
+                     : "s"(__builtin_amdgcn_readlane(recw, RW_TW)), "s"(__builtin_amdgcn_readlane(recw, RW_TW + 1)));
         tile += flags >> 16;                         // tile of the next segment
 
         // every mask the common case needs, read up front (v_readlane -> SGPR)

@@ -376,3 +376,47 @@ def test_windows_per_wave_option(oracle):
             assert_ld_close(got[:, :2], res["win"][:, :2], "wpw=1")
         else:
             assert_bits(got, ref, f"windows_per_wave={wpw}")
+
+
+@pytest.mark.parametrize("ring,recbytes,wpw", [(8, 12288, 16), (4, 1024, 16), (8, 1024, 1), (4, 90000, 256)])
+def test_exponent_counting_launch_geometries(oracle, ring, recbytes, wpw):
+    """ring depth, LDS record budget (forces fewer windows per workgroup) and windows per wave do
+    not change a single bit of the result."""
+    N, L = 200, 3000
+    alle, nr, na = synth(81, L, N)
+    with E.Engine() as eng:
+        eng.set_option("ld_variant", 2)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([3], ld=True)
+        ref = eng.window_ll(0)
+        res = oracle.compare(alle, nr, na, 3, window=100, ld=True)
+        assert_ld_close(ref[:, :2], res["win"][:, :2], "default geometry")
+    with E.Engine() as eng:
+        eng.set_option("ld_variant", 2)
+        eng.set_option("ring_slots", ring)
+        eng.set_option("record_lds_bytes", recbytes)
+        eng.set_option("windows_per_wave", wpw)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([3], ld=True)
+        assert eng.last_ld_variant() == 2
+        assert_bits(eng.window_ll(0), ref, f"ring={ring} recbytes={recbytes} wpw={wpw}")
+
+
+def test_sparse_pileup_rows_far_apart(oracle):
+    """Few covered rows spread over many panel rows: windows span hundreds of tiles."""
+    N, Lp = 130, 60000
+    rng = np.random.default_rng(91)
+    alle, nr, na = synth(91, Lp, N)
+    keep = np.sort(rng.choice(Lp, size=900, replace=False))
+    nrk, nak = np.maximum(nr[keep], 1), na[keep]
+    for variant in (0, 1):
+        with E.Engine() as eng:
+            eng.set_option("ld_variant", variant)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(keep, nrk, nak, 100)
+            eng.run([7], ld=True)
+            res = oracle.compare(alle[keep], nrk, nak, 7, window=100, ld=True)
+            assert_bits(eng.site_ll(0), res["site"], "site")
+            assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"sparse variant={variant}")
