@@ -36,7 +36,9 @@ struct DevBuf {
 struct ibdg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // per-site + window-product kernels run beside the --LD kernels
     hipEvent_t ev[6] = {};
+    hipEvent_t ev2[4] = {};
     std::string err;
 
     double eps = 0.02;
@@ -451,7 +453,11 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
     for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto &ev : c->ev2)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     const size_t d = (size_t)max_cov + 1;
     c->lut_h.resize(d * d * 3);
@@ -485,6 +491,11 @@ void ibdg_destroy(ibdg_ctx *c)
     for (auto &ev : c->ev)
         if (ev)
             (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev2)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->stream2)
+        (void)hipStreamDestroy(c->stream2);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -673,13 +684,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
 
     const bool recount = c->opt_count_in_run || !c->counts_valid;
+    // Two streams: the per-site kernel and the window products (memory-bound, few waves) run on
+    // stream2 beside the --LD kernels (VALU-bound) on the main stream; they only meet at the end.
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[0], 0));
+    HIP_TRY(c, hipEventRecord(c->ev2[0], c->stream2));
     if (recount) {
         ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
-                               c->stream);
+                               c->stream2);
         c->counts_valid = true;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev2[1], c->stream2));
 
     ibdg::SiteArgs sa;
     sa.panel = (const uint64_t *)c->panel.p;
@@ -696,7 +711,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.n_pairs = c->n_pairs;
     sa.af = (double *)c->af.p;
     sa.site_ll = (double *)c->site_ll.p;
-    ibdg::launch_site(sa, (unsigned)T, c->stream);
+    ibdg::launch_site(sa, (unsigned)T, c->stream2);
+    HIP_TRY(c, hipEventRecord(c->ev2[2], c->stream2));
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
 
     bool use_pop = false;
@@ -773,17 +789,19 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     wa.n_win = c->n_win;
     wa.ld_mode = ld_mode ? 1 : 0;
     wa.win_ll = (double *)c->win_ll.p;
-    ibdg::launch_window_prod(wa, (unsigned)T, c->stream);
+    ibdg::launch_window_prod(wa, (unsigned)T, c->stream2);
+    HIP_TRY(c, hipEventRecord(c->ev2[3], c->stream2));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev2[3], 0));
     HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     float v;
     HIP_TRY(c, hipEventElapsedTime(&v, c->ev[0], c->ev[4])); c->ms[0] = v;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[0], c->ev[1])); c->ms[1] = recount ? v : 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[1], c->ev[2])); c->ms[2] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[0], c->ev2[1])); c->ms[1] = recount ? v : 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[1], c->ev2[2])); c->ms[2] = v;
     HIP_TRY(c, hipEventElapsedTime(&v, c->ev[2], c->ev[3])); c->ms[3] = ld_mode ? v : 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[3], c->ev[4])); c->ms[4] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[2], c->ev2[3])); c->ms[4] = v;
     c->n_targets = T;
     c->have_results = true;
     return 0;

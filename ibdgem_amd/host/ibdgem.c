@@ -11,7 +11,10 @@
  * engine's error, except for --plan (below), which never needs the engine.
  *
  * Differences from the reference, all outside the BASELINE configs:
- *   - IMPUTE input only for now (-H/-L/-I); -V reports that VCF input is not built yet;
+ *   - VCF input (-V) follows the IMPUTE semantics: any number of comparison individuals (the
+ *     reference frees its genotype regex inside the per-individual loop, src/ibdgem.c:472, and
+ *     crashes on the second one) and the -B background indexed by individual (the reference's VCF
+ *     loop indexes genotypes by list position, src/ibdgem.c:374-375);
  *   - no 30720-byte line limit (src/file-io.h:10); .hap rows with a character other than
  *     '0'/'1' at an allele offset are counted as skipped instead of read as garbage;
  *   - the genotype files are read once, not once per comparison individual
@@ -81,7 +84,7 @@ static void usage(int code)
           "Usage: ibdgem [--LD] -H hap -L legend -I indv -P pileup [options]\n"
           "  --LD                      background-panel (linkage-aware) window likelihoods\n"
           "  -H/--hap, -L/--legend, -I/--indv FILE   IMPUTE genotype input (plain or .gz)\n"
-          "  -V/--vcf FILE             VCF genotype input (not built yet in this engine)\n"
+          "  -V/--vcf FILE             VCF genotype input (plain or .gz), biallelic SNP rows with 0/1 genotypes\n"
           "  -P/--pileup FILE          samtools pileup of the unknown sample (required)\n"
           "  -N/--pileup-name STR      name of the pileup sample (default UNKWN)\n"
           "  -A/--allele-freqs FILE    CHROM POS AF table overriding the panel's own frequencies\n"
@@ -304,7 +307,9 @@ typedef struct {
     uint32_t id_off, ref_off, alt_off;   /* into the string arena */
     unsigned long pos;
     uint8_t legend_ok;                   /* the legend row had its 4 fields (src/ibdgem.c:589) */
-    uint8_t hap_ok;                      /* the .hap row packed cleanly */
+    uint8_t hap_ok;                      /* the .hap row packed cleanly / the VCF row parsed, is biallelic, GTs ok */
+    uint8_t gt_failed;                   /* VCF: a genotype field did not look like [01][/|][01] (message per run) */
+    double qual;                         /* VCF QUAL column (-q) */
 } row_t;
 
 static row_t *rows;
@@ -364,6 +369,101 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
     }
     ls_close(hap);
     ls_close(leg);
+    return 0;
+}
+
+/* VCF rows -> the same row table (restates the parsing of compare_vcf, reference
+ * src/ibdgem.c:272-296, src/ibd-parse.c:113-173): sample names from the #CHROM line; per row the
+ * eight fixed columns, FORMAT, then one field per sample whose first three characters must be
+ * [01][/|][01].  Rows that do not split into the fixed columns, multi-allelic rows (comma in ALT)
+ * and rows with an unparsable genotype are "skipped" rows. */
+static int read_genotypes_vcf(const char *vcf_fn, names_t *ids)
+{
+    line_src *vcf = ls_open(vcf_fn);
+    if (!vcf)
+        return 1;
+    char *line;
+    while ((line = ls_next(vcf, NULL)) && strncmp(line, "##", 2) == 0)
+        ;
+    static const char hdr[] = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t";
+    if (!line || strncmp(line, hdr, sizeof hdr - 1) != 0) {
+        fprintf(stderr, "[::] ERROR parsing VCF header.\n");
+        return 1;
+    }
+    {
+        char *p = line + sizeof hdr - 1;
+        p[strcspn(p, "\n")] = 0;
+        size_t cap = 0;
+        ids->n = 0;
+        ids->names = NULL;
+        for (char *tok = strtok(p, "\t"); tok; tok = strtok(NULL, "\t")) {
+            if (ids->n == cap) {
+                cap = cap ? cap * 2 : 256;
+                ids->names = realloc(ids->names, cap * sizeof *ids->names);
+            }
+            ids->names[ids->n++] = strdup(tok);
+        }
+        if (ids->n == 0) {
+            fprintf(stderr, "[::] ERROR: No samples found.\n");
+            return 1;
+        }
+    }
+    const unsigned n_ids = (unsigned)ids->n;
+    row_words = ibdg_row_words(n_ids);
+    uint8_t *alle = malloc(2 * (size_t)n_ids);
+    size_t cap = 0;
+    while ((line = ls_next(vcf, NULL))) {
+        if (n_rows == cap) {
+            cap = cap ? cap * 2 : (1 << 16);
+            rows = realloc(rows, cap * sizeof *rows);
+            packed = realloc(packed, cap * row_words * 8);
+        }
+        row_t *r = &rows[n_rows];
+        memset(r, 0, sizeof *r);
+        memset(packed + n_rows * row_words, 0, row_words * 8);
+        n_rows++;
+        line[strcspn(line, "\n")] = 0;
+        char *f[9], *p = line;
+        int nf = 0;
+        while (nf < 9) {                                  /* CHROM POS ID REF ALT QUAL FILTER INFO FORMAT */
+            char *t = strchr(p, '\t');
+            if (!t)
+                break;
+            *t = 0;
+            f[nf++] = p;
+            p = t + 1;
+        }
+        char *endp;
+        r->pos = strtoul(nf > 1 ? f[1] : "", &endp, 10);
+        if (nf < 9 || endp == f[1] || !*p)
+            continue;                                     /* the reference's sscanf != 8 branch */
+        r->legend_ok = 1;
+        r->id_off = arena_add(f[2]);
+        r->ref_off = arena_add(f[3]);
+        r->alt_off = arena_add(f[4]);
+        r->qual = atof(f[5]);
+        if (strchr(f[4], ','))
+            continue;                                     /* not biallelic (src/ibdgem.c:275) */
+        unsigned i = 0;
+        for (char *tok = p; i < n_ids && tok; ++i) {
+            char *t = strchr(tok, '\t');
+            if (t)
+                *t = 0;
+            if (!((tok[0] == '0' || tok[0] == '1') && (tok[1] == '/' || tok[1] == '|') && (tok[2] == '0' || tok[2] == '1')))
+                break;
+            alle[2 * i] = (uint8_t)(tok[0] - '0');
+            alle[2 * i + 1] = (uint8_t)(tok[2] - '0');
+            tok = t ? t + 1 : NULL;
+        }
+        if (i < n_ids) {
+            r->gt_failed = 1;
+            continue;
+        }
+        ibdg_pack_alleles(alle, n_ids, packed + (n_rows - 1) * row_words);
+        r->hap_ok = 1;
+    }
+    free(alle);
+    ls_close(vcf);
     return 0;
 }
 
@@ -594,16 +694,19 @@ int main(int argc, char **argv)
         DIE("[::] ERROR: Missing genotype files.\n");
     if (in_vcf && in_impute)
         DIE("[::] ERROR: 2 types of genotype inputs detected. Please choose either IMPUTE or VCF format.\n");
-    if (in_vcf)
-        DIE("[::] ERROR: VCF input (%s) is not built in this engine yet; convert to IMPUTE (-H/-L/-I).\n", vcf_fn);
-    if (!hap_fn || !legend_fn || !indv_fn)
+    if (in_impute && (!hap_fn || !legend_fn || !indv_fn))
         DIE("[::] ERROR parsing hap/legend/indv data; make sure inputs are valid.\n");
 
     names_t ids;
-    if (read_names(indv_fn, &ids))
-        exit(1);
-    if (ids.n == 0)
-        DIE("[::] ERROR: No samples found in .indv file.\n");
+    if (in_vcf) {
+        if (read_genotypes_vcf(vcf_fn, &ids))
+            exit(1);
+    } else {
+        if (read_names(indv_fn, &ids))
+            exit(1);
+        if (ids.n == 0)
+            DIE("[::] ERROR: No samples found in .indv file.\n");
+    }
     const unsigned n_ids = (unsigned)ids.n;
     idlist_t targets = {NULL, 0}, bg = {NULL, 0};
     if (has_S) {                                            /* -S wins over -s (:1135-1155) */
@@ -629,7 +732,7 @@ int main(int argc, char **argv)
     }
     const long pu_id = find_name(&ids, opt_sq);            /* is the pileup's own name in the panel? (:501-506) */
 
-    if (read_genotypes(hap_fn, legend_fn, n_ids))
+    if (in_impute && read_genotypes(hap_fn, legend_fn, n_ids))
         exit(1);
 
     /* input coverage distribution and cull ratio: find_cull_p (:83-106) */
@@ -688,6 +791,7 @@ int main(int argc, char **argv)
         if (!R->legend_ok) continue;
         const char *ref = arena + R->ref_off, *alt = arena + R->alt_off;
         if (!is_snp(ref, alt)) continue;
+        if (in_vcf && R->qual < opt_min_qual) continue;                /* -q (src/ibdgem.c:297) */
         const pu_line *pl = pileup_find(pu, R->pos);
         if (!pl) continue;
         if (has_p && !pos_listed(R->pos)) continue;
@@ -718,7 +822,12 @@ int main(int argc, char **argv)
         unsigned long skipped = 0, final_total = 0, final_dist[128] = {0};
         size_t n = 0;
         for (size_t r = 0, ci = 0; r < n_rows; ++r) {
-            if (row_fate[r] == 0) { skipped++; continue; }
+            if (row_fate[r] == 0) {
+                if (rows[r].gt_failed)
+                    fprintf(stderr, "Failed to parse genotype fields at %lu. Skipping to next site.\n", rows[r].pos);
+                skipped++;
+                continue;
+            }
             const int is_cand = row_fate[r] == 1;
             const size_t my = ci;
             if (is_cand) ci++;

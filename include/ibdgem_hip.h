@@ -136,9 +136,12 @@ int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out
 
 /* ---- measurement / tuning --------------------------------------------------- */
 
-/* Device time of the last ibdg_run, from HIP events on the engine's stream:
- * out[0] total, out[1] alt-count kernel (0 if not run), out[2] per-site
- * kernel, out[3] LD window kernel, out[4] window-product kernel (ms). */
+/* Device time of the last ibdg_run, from HIP events on the engine's streams:
+ * out[0] total (first launch to last completion), out[1] alt-count kernel
+ * (0 if not run), out[2] per-site kernel, out[3] the --LD launches, out[4]
+ * window-product kernel (ms).  The per-site and window-product kernels run on
+ * a second stream beside the --LD kernels, so the parts overlap and need not
+ * add up to the total. */
 int ibdg_last_run_ms(const ibdg_ctx *ctx, float out[5]);
 
 /* Which --LD kernel the last ibdg_run used: 0 none (non-LD), 1 the strict

@@ -163,6 +163,47 @@ def build_syn(tag, seed, n_ids, n_sites, truth_id, cases, extra_files):
         fh.write("\n")
 
 
+def build_vcf_case():
+    """synA's panel as a VCF (plus rows the VCF path must skip) through the reference's -V path.
+    One comparison individual per run: the reference frees its GT regex inside the per-target loop
+    (src/ibdgem.c:472) and crashes on the second target."""
+    root = os.path.join(HERE, "synV")
+    shutil.rmtree(root, ignore_errors=True)
+    inp = os.path.join(root, "input")
+    os.makedirs(inp)
+    src = os.path.join(HERE, "synA", "input")
+    with gzip.open(os.path.join(src, "panel.hap.gz"), "rt") as fh:
+        hap = [l.split() for l in fh.read().splitlines()]
+    with gzip.open(os.path.join(src, "panel.legend.gz"), "rt") as fh:
+        leg = [l.split() for l in fh.read().splitlines()[1:]]
+    names = open(os.path.join(src, "panel.indv")).read().split()
+    rng = np.random.default_rng(7)
+    out = ["##fileformat=VCFv4.2", "##source=make_golden.py",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
+    for (rid, pos, ref, alt), row in zip(leg, hap):
+        u = rng.random()
+        qual = "50" if u > 0.1 else "12.5"
+        gts = [f"{row[2 * i]}|{row[2 * i + 1]}" for i in range(len(names))]
+        if u > 0.97:
+            alt = alt + ",G"                       # multi-allelic: skipped
+        elif u > 0.95:
+            gts[5] = "./."                         # unparsable genotype: row skipped with a message
+        elif u > 0.93:
+            gts[2] = gts[2].replace("|", "/") + ":35"   # unphased separator and extra sub-fields are fine
+        out.append("\t".join(["7", pos, rid, ref, alt, qual, "PASS", "AC=1", "GT"] + gts))
+    gz_write(os.path.join(inp, "panel.vcf.gz"), "\n".join(out) + "\n")
+    shutil.copy(os.path.join(src, "reads.pileup.gz"), os.path.join(inp, "reads.pileup.gz"))
+    base = ["-V", "panel.vcf.gz", "-P", "reads.pileup.gz"]
+    cases = {"vcf_ld": ["--LD", "-s", "ind3"], "vcf_nonld_q30": ["-s", "ind64", "-q", "30"],
+             "vcf_ld_varsites_w50": ["--LD", "-v", "-w", "50", "-s", "ind9", "-N", "ind5"]}
+    with tempfile.TemporaryDirectory() as wd:
+        for name, extra in cases.items():
+            run_case(wd, inp, name, base + extra, root)
+    with open(os.path.join(root, "cases.json"), "w") as fh:
+        json.dump({"base_args": base, "cases": cases}, fh, indent=1)
+        fh.write("\n")
+
+
 def math_grid():
     lib = ctypes.CDLL(REFMATH)
     lib.init_nCk.restype = ctypes.c_void_p
@@ -230,6 +271,7 @@ def main():
         "ld_w37": ["--LD", "-w", "37", "-s", "ind129,ind0,ind63,ind64"],
         "ld_pu_named": ["--LD", "-N", "ind129", "-s", "ind129,ind1"],
     }, lambda d: {})
+    build_vcf_case()
     print("golden vectors written under", HERE)
 
 

@@ -92,6 +92,20 @@ def test_plan_matches_reference_on_synthetic_cases(tag, case):
         check_plan_against(plan[name], tab, summ)
 
 
+@pytest.mark.parametrize("case", ["vcf_ld", "vcf_nonld_q30", "vcf_ld_varsites_w50"])
+def test_plan_matches_reference_on_vcf_input(case):
+    meta = G.cases("synV")
+    res = subprocess.run([_exe()] + meta["base_args"] + meta["cases"][case] + ["--plan"],
+                         cwd=os.path.join(G.GOLD, "synV", "input"), capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    plan = parse_plan(res.stdout)
+    flags = G.parse_flags(meta["cases"][case])
+    (name,) = plan
+    tab, summ = G.syn_outputs("synV", case, flags["sq"], name)
+    check_plan_against(plan[name], tab, summ)
+    assert "Failed to parse genotype fields at" in res.stderr
+
+
 def test_option_errors_match_the_reference():
     exe = _exe()
 
@@ -112,6 +126,8 @@ def test_option_errors_match_the_reference():
     assert r.returncode == 1 and "[::] ERROR: Missing genotype files." in r.stderr
     r = run(*base, "-V", "x.vcf")
     assert r.returncode == 1 and "2 types of genotype inputs detected" in r.stderr
+    r = run("-V", "test.legend", "-P", "test1.pileup")
+    assert r.returncode == 1 and "[::] ERROR parsing VCF header." in r.stderr
     r = run(*base, "-s", "nobody", "--plan")
     assert r.returncode == 1 and "Sample nobody not found in reference panel." in r.stderr
     r = run("-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "missing.pileup")
@@ -221,3 +237,39 @@ def test_cli_window_sharding_over_several_contexts(case, devices, tmp_path):
         if fn.endswith(".tab.txt.gz"):
             got = got[1:]
         assert got == want, f"{case}/{fn} with --devices {devices}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["vcf_ld", "vcf_nonld_q30", "vcf_ld_varsites_w50"])
+def test_cli_reproduces_the_reference_on_vcf_input(case, tmp_path):
+    meta = G.cases("synV")
+    _run_full(meta["base_args"] + meta["cases"][case], os.path.join(G.GOLD, "synV", "input"), tmp_path)
+    ref = os.path.join(G.GOLD, "synV", case, "ref7")
+    files = sorted(os.listdir(ref))
+    assert files and sorted(os.listdir(tmp_path)) == [f[:-3] for f in files]
+    for fn in files:
+        got = _read(str(tmp_path / fn[:-3]))
+        want = _read(os.path.join(ref, fn))
+        if fn.endswith(".tab.txt.gz"):
+            got = got[1:]
+        assert got == want, f"synV/{case}/{fn}"
+
+
+@pytest.mark.gpu
+def test_cli_vcf_with_several_comparison_individuals(tmp_path):
+    """The reference crashes on the second individual of a VCF run; here the VCF path gives, row by
+    row, what the IMPUTE path gives for the same genotypes (synV's VCF = synA's panel plus rows the
+    VCF path must skip)."""
+    metaV, metaA = G.cases("synV"), G.cases("synA")
+    outV, outA = tmp_path / "v", tmp_path / "a"
+    outV.mkdir()
+    outA.mkdir()
+    _run_full(metaV["base_args"] + ["--LD", "-s", "ind3,ind64,ind9"], os.path.join(G.GOLD, "synV", "input"), outV)
+    _run_full(metaA["base_args"] + ["--LD", "-s", "ind3,ind64,ind9"], os.path.join(G.GOLD, "synA", "input"), outA)
+    for name in ("ind3", "ind64", "ind9"):
+        tv = {l.split("\t")[2]: l for l in _read(str(outV / f"UNKWN.{name}.tab.txt")) if l and l[0] != "#"}
+        ta = {l.split("\t")[2]: l for l in _read(str(outA / f"UNKWN.{name}.tab.txt")) if l and l[0] != "#"}
+        assert 900 < len(tv) < len(ta)
+        for pos, l in tv.items():
+            assert ta[pos] == l
+        assert len(_read(str(outV / f"UNKWN.{name}.summary.txt"))) > 3
