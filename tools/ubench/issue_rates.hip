@@ -51,6 +51,30 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
                 asm volatile("v_and_b32 %1, %2, %0\n v_bcnt_u32_b32 %0, %1, %0\n v_and_b32 %1, %2, %0\n v_bcnt_u32_b32 %0, %1, %0\n"
                              "v_and_b32 %1, %2, %0\n v_bcnt_u32_b32 %0, %1, %0\n v_and_b32 %1, %2, %0\n v_bcnt_u32_b32 %0, %1, %0"
                              : "+v"(a0), "+v"(a1) : "s"(m));
+            } else if (KIND == 9) { // v_and_b32, VGPR operands only
+                asm volatile("v_and_b32 %0, %8, %0\n v_and_b32 %1, %8, %1\n v_and_b32 %2, %8, %2\n v_and_b32 %3, %8, %3\n"
+                             "v_and_b32 %4, %8, %4\n v_and_b32 %5, %8, %5\n v_and_b32 %6, %8, %6\n v_and_b32 %7, %8, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            } else if (KIND == 10) { // v_fma_f32
+                asm volatile("v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_fma_f32 %2, %2, %4, %2\n v_fma_f32 %3, %3, %4, %3\n"
+                             "v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_fma_f32 %2, %2, %4, %2\n v_fma_f32 %3, %3, %4, %3"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            } else if (KIND == 11) { // v_pk_add_u16
+                asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %4\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %4\n"
+                             "v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %4\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %4"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            } else if (KIND == 12) { // v_add_f32 (VOP2, VGPR only)
+                asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n"
+                             "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            } else if (KIND == 13) { // v_pk_fma_f32 (64-bit operands)
+                asm volatile("v_pk_fma_f32 %0, %0, %2, %0\n v_pk_fma_f32 %1, %1, %2, %1\n v_pk_fma_f32 %0, %0, %2, %0\n v_pk_fma_f32 %1, %1, %2, %1\n"
+                             "v_pk_fma_f32 %0, %0, %2, %0\n v_pk_fma_f32 %1, %1, %2, %1\n v_pk_fma_f32 %0, %0, %2, %0\n v_pk_fma_f32 %1, %1, %2, %1"
+                             : "+v"(d0), "+v"(d1) : "v"(d2));
+            } else if (KIND == 14) { // v_add_u32 VGPR only
+                asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
+                             "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
             } else if (KIND == 8) { // s_nop 0
                 asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
             }
@@ -78,10 +102,12 @@ double run(int waves_per_simd, uint32_t *out)
 int main()
 {
     uint32_t *out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);
-    const char *names[] = {"v_and_b32", "v_bcnt_u32_b32", "v_bitop3_b32", "v_readlane_b32", "v_mul_f64", "s_and_b32", "v_and+s_and mixed", "and->bcnt dependent", "s_nop 0"};
+    const char *names[] = {"v_and_b32 (sgpr mask)", "v_bcnt_u32_b32", "v_bitop3_b32", "v_readlane_b32", "v_mul_f64", "s_and_b32", "v_and+s_and mixed", "and->bcnt dependent", "s_nop 0",
+                           "v_and_b32 (vgpr only)", "v_fma_f32", "v_pk_add_u16", "v_add_f32", "v_pk_fma_f32", "v_add_u32 (vgpr only)"};
     for (int w : {1, 2, 4, 8}) {
-        double t[9] = {run<0>(w, out), run<1>(w, out), run<2>(w, out), run<3>(w, out), run<4>(w, out), run<5>(w, out), run<6>(w, out), run<7>(w, out), run<8>(w, out)};
-        for (int i = 0; i < 9; ++i)
+        double t[15] = {run<0>(w, out), run<1>(w, out), run<2>(w, out), run<3>(w, out), run<4>(w, out), run<5>(w, out), run<6>(w, out), run<7>(w, out), run<8>(w, out),
+                        run<9>(w, out), run<10>(w, out), run<11>(w, out), run<12>(w, out), run<13>(w, out), run<14>(w, out)};
+        for (int i = 0; i < 15; ++i)
             printf("waves/SIMD=%d  %-22s %.2f ns per wave-instruction per SIMD  (%.2f cycles @2.4GHz)\n", w, names[i], t[i] * 1e9, t[i] * 2.4e9);
         fflush(stdout);
     }
