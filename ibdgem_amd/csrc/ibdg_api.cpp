@@ -65,6 +65,7 @@ struct ibdg_ctx {
     DevBuf t32, segs, wconst, wtarget, twords, pow1, pow2, partial;
     uint32_t wpg = 0, max_seg = 0;     // windows per workgroup run and its largest segment count
     int tab_in_lds = 0;
+    int seg_ring = 4;                  // ring depth the segment control words were built for
     uint32_t n_pairs = 0, n_segs = 0, ct_max = 0;
     int planes = 0;
     bool pop_lut_ok = false;     // P(D|G) table is the unclamped binomial form
@@ -343,18 +344,6 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         wc[w].alt_total = at;
         ct_max = std::max(ct_max, ct);
     }
-    for (size_t i = 0; i < segs.size(); ++i) {
-        ibdg::Seg &sg = segs[i];
-        uint32_t nc = 0, na = 0;
-        for (int k = 0; k < 8; ++k) {
-            if (sg.cov[k]) nc = k + 1;
-            if (sg.alt[k]) na = k + 1;
-        }
-        const uint32_t delta = i + 1 < segs.size() ? segs[i + 1].tile - sg.tile : 0;
-        if (delta > 0xffff)
-            return 0;                      // rows too far apart for the record format: strict kernel
-        sg.flags = nc | (na << 8) | (delta << 16);
-    }
     wc[c->n_win].seg_begin = (uint32_t)segs.size();
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     {
@@ -369,8 +358,36 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
                 break;
             }
         }
+        // per-segment control word (see ibdg::Seg::flags): needs the run structure chosen above
+        const uint32_t NS = (uint32_t)c->opt_ring;
+        for (uint32_t w = 0; w < c->n_win; w += c->wpg) {
+            const uint32_t s0 = wc[w].seg_begin, s1 = wc[std::min(w + c->wpg, c->n_win)].seg_begin;
+            if (s0 == s1)
+                continue;
+            const uint32_t q0 = segs[s0].tile >> 1;
+            for (uint32_t i = s0; i < s1; ++i) {
+                ibdg::Seg &sg = segs[i];
+                uint32_t nc = 0, na = 0;
+                for (int k = 0; k < 8; ++k) {
+                    if (sg.cov[k]) nc = k + 1;
+                    if (sg.alt[k]) na = k + 1;
+                }
+                uint32_t nslot = 0, nhalf = 0, adv = 0;
+                if (i + 1 < s1) {
+                    const uint32_t qn = segs[i + 1].tile >> 1;
+                    adv = qn - (sg.tile >> 1);
+                    if (adv > 255)
+                        return 0;          // rows too far apart for the record format: strict kernel
+                    nslot = (qn - q0) % NS;
+                    nhalf = segs[i + 1].tile & 1;
+                }
+                sg.flags = nslot | (nhalf << 3) | (adv << 4) | ((nc > 3 || na > 2) ? 1u << 12 : 0u) |
+                           (sg.last ? 1u << 13 : 0u) | (nc << 16) | (na << 24);
+            }
+        }
+        c->seg_ring = (int)NS;
         c->tab_in_lds = (size_t)(ct_max + 1) * 32 <= 24 * 1024;
-        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, (int)c->opt_ring) > 150 * 1024)
+        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, c->seg_ring) > 150 * 1024)
             return 0;                      // a single window with thousands of tiles: strict kernel
     }
     wc[c->n_win].mK = 0;
@@ -747,7 +764,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.weight = (const double *)c->weight.p;
         pa.lanes = (uint32_t)lanes;
         pa.partial = (double *)c->partial.p;
-        pa.ring_slots = (uint32_t)c->opt_ring;
+        pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
         pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;

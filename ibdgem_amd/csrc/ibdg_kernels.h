@@ -58,8 +58,10 @@ struct Seg {
     uint32_t tile;
     uint32_t win;        // window index
     uint32_t last;       // 1 = last segment of its window
-    uint32_t flags;      // bits 0-7: number of cov planes to visit (highest non-zero + 1),
-                         // bits 8-15: same for alt, bits 16-31: (next segment's tile) - tile
+    uint32_t flags;      // bits 0-2 ring slot of the next segment's tile pair (relative to its run's first
+                         // pair, modulo the ring depth), bit 3 its tile parity, bits 4-11 pairs between this
+                         // segment and the next, bit 12 weight planes beyond cov 0-2 / alt 0-1 present,
+                         // bit 13 last segment of its window, bits 16-23 / 24-31 number of cov / alt planes
     uint32_t cov[8];
     uint32_t alt[8];
 };                       // 80 bytes

@@ -137,8 +137,9 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 //     1 KiB per instruction, no VGPRs) into a private ring of NS slots, NS-1 loads in flight
 //     while a pair is consumed.  Landing is tracked with counted s_waitcnt vmcnt
 //     (vector-memory ops of a wave complete in issue order).
-//   * a segment's record is read with ONE ds_read_b32 (word l -> lane l; fields are then
-//     picked with v_readlane into SGPRs and used as wave-uniform masks) and the lane's own
+//   * per segment one asm statement reads the hot half of the record with two broadcast
+//     ds_read_b128 (masks and the target's words land in VGPRs: VALU instructions with VGPR
+//     operands only issue at twice the rate of those with an SGPR operand) and the lane's own
 //     two tile words with one ds_read_b64.
 //   All LDS reads in the loop are asm: hipcc drains vmcnt(0) before any LDS read that follows
 //   a direct-to-LDS load, which would serialise the ring (and so would table look-ups from
@@ -152,24 +153,43 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
 
-// LDS image of a segment: the 20 words of Seg followed by the target's two haplotype words.
-#define IBDG_REC_WORDS 22
-enum { RW_TILE = 0, RW_WIN = 1, RW_LAST = 2, RW_FLAGS = 3, RW_COV = 4, RW_ALT = 12, RW_TW = 20 };
-// LDS image of a window's constants
+// LDS image of a segment (20 words, 16-byte aligned):
+//   hot  [0..7]   flags' | cov0 cov1 cov2 | alt0 alt1 | target words t0 t1
+//   cold [8..19]  window index | cov3..cov7 | alt2..alt7
+// flags = ring slot of the NEXT segment's pair (3) | its tile half (1) | pairs to advance before it (8)
+//       | rare planes present (1) | last segment of its window (1) | - | ncov (8) | nalt (8)   (host-built)
+// The hot half is read with two BROADCAST ds_read_b128 (every lane the same address), so the
+// masks land in VGPRs: on gfx950 a VALU instruction with an SGPR operand issues at half the rate
+// of one with VGPR operands only (tools/ubench/issue_rates.hip: v_and_b32 4.1 vs 2.4 cycles),
+// and a wave-uniform mask is just as good in a VGPR.
+#define IBDG_REC_WORDS 20
+enum { RC_WIN = 8, RC_COV3 = 9, RC_ALT2 = 14 };
+// LDS image of a window's constants (12 words): mK(2) eK CT | AT a0cov a1cov a0alt | a1alt - - -
 #define IBDG_WC_WORDS 12
-enum { WC_MK = 0, WC_EK = 2, WC_CT = 3, WC_AT = 4, WC_A0COV = 5, WC_A1COV = 6, WC_A0ALT = 7, WC_A1ALT = 8 };
 
 // Issue and wait in ONE statement: an asm output must be final when the statement ends,
 // because hipcc is free to copy it to another register right afterwards (it did, with the
 // wait in a later statement: the copy read the register before the LDS data had landed).
 // The LDS latency is covered by the other resident waves of the SIMD instead.
-__device__ __forceinline__ void lds_fetch(uint32_t &recw, uint2 &x, uint32_t rec_addr, uint32_t x_addr)
+__device__ __forceinline__ void lds_fetch(uint4 &h0, uint4 &h1, uint2 &x, uint32_t rec_addr, uint32_t x_addr)
 {
-    asm volatile("ds_read_b32 %0, %2\n\t"
-                 "ds_read_b64 %1, %3\n\t"
+    asm volatile("ds_read_b128 %0, %3\n\t"
+                 "ds_read_b128 %1, %3 offset:16\n\t"
+                 "ds_read_b64 %2, %4\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(recw), "=&v"(x)
+                 : "=&v"(h0), "=&v"(h1), "=&v"(x)
                  : "v"(rec_addr), "v"(x_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_read_wc(uint4 &w0, uint4 &w1, uint4 &w2, uint32_t addr)
+{
+    asm volatile("ds_read_b128 %0, %3\n\t"
+                 "ds_read_b128 %1, %3 offset:16\n\t"
+                 "ds_read_b128 %2, %3 offset:32\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+                 : "v"(addr)
                  : "memory");
 }
 
@@ -241,17 +261,31 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 
     // ---- stage the run's records, window constants and tables (whole workgroup)
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(segs + seg0);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(segs + seg0);    // tile win last flags cov[8] alt[8]
         const uint2 *tws = twords + (size_t)t * a.n_segs + seg0;
         for (uint32_t i = threadIdx.x; i < nseg * 32; i += blockDim.x) {
             const uint32_t sg = i >> 5, wd = i & 31;
-            if (wd < 20)
-                rec_lds[sg * IBDG_REC_WORDS + wd] = src[sg * 20 + wd];
-            else if (wd == 20) {
-                const uint2 v = tws[sg];
-                rec_lds[sg * IBDG_REC_WORDS + RW_TW] = v.x;
-                rec_lds[sg * IBDG_REC_WORDS + RW_TW + 1] = v.y;
-            }
+            const uint32_t *S = src + sg * 20;
+            uint32_t v;
+            if (wd >= IBDG_REC_WORDS)
+                continue;
+            if (wd == 0)
+                v = S[3];
+            else if (wd <= 3)
+                v = S[4 + (wd - 1)];                   // cov0..2
+            else if (wd <= 5)
+                v = S[12 + (wd - 4)];                  // alt0..1
+            else if (wd == 6)
+                v = tws[sg].x;
+            else if (wd == 7)
+                v = tws[sg].y;
+            else if (wd == RC_WIN)
+                v = S[1];
+            else if (wd < RC_ALT2)
+                v = S[4 + 3 + (wd - RC_COV3)];         // cov3..7
+            else
+                v = S[12 + 2 + (wd - RC_ALT2)];        // alt2..7
+            rec_lds[sg * IBDG_REC_WORDS + wd] = v;
         }
         for (uint32_t i = threadIdx.x; i < (w1 - w0) * 16; i += blockDim.x) {
             const uint32_t wj = i >> 4, wd = i & 15;
@@ -272,8 +306,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     if (c >= a.n_chunks)
         return;
     char *ring = ring0 + (size_t)wave * NS * 1024;
-    const uint32_t rec_lane = (uint32_t)(uintptr_t)(lds_void *)rec_lds + min(lane, (unsigned)IBDG_REC_WORDS - 1) * 4;
-    const uint32_t wc_lane = (uint32_t)(uintptr_t)(lds_void *)wc_lds + min(lane, (unsigned)IBDG_WC_WORDS - 1) * 4;
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
@@ -292,60 +324,55 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     for (int k = 0; k < FA; ++k)
         A0[k] = A1[k] = 0;
 
-    // ---- prime the ring: pairs qcur .. qcur+NS-1 (not past the run's last pair)
-    uint32_t tile = segs[seg0].tile;                 // tile of the segment being fetched
-    const uint32_t q_last = segs[seg1 - 1].tile >> 1;
-    uint32_t qcur = tile >> 1;                       // oldest pair still in the ring
+    // ---- prime the ring: pairs q0 .. q0+NS-1 (not past the run's last pair)
+    const uint32_t tile0 = segs[seg0].tile;
+    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
+    uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
-        if (qcur + i <= q_last)
-            __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(qcur + i) * 64),
-                                             (lds_void *)(ring + ((qcur + i) % NS) * 1024), 16, 0, 0);
-    if (qcur + NS - 1 <= q_last)
+    for (int i = 0; i < NS; ++i, ++q_issue)
+        if (q_issue <= q_last)
+            __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                             (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+    if (q_issue - 1 <= q_last)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (uint32_t s = 0; s < nseg; ++s) {
-        // ---- advance the ring to the pair of this segment
-        const uint32_t q = tile >> 1;
-        if (q != qcur) {
-            while (qcur < q) {                       // the slot of qcur is free: refill it NS pairs ahead
-                if (qcur + NS <= q_last)
-                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(qcur + NS) * 64),
-                                                     (lds_void *)(ring + (qcur % NS) * 1024), 16, 0, 0);
-                ++qcur;
-            }
-            // pair q is followed by exactly NS-1 younger direct-to-LDS loads unless the run ends first
-            if (q + NS - 1 <= q_last)
+    // Where a segment's tile words sit in the ring and how far the ring must advance before the
+    // NEXT segment are precomputed by the host into each record's flag word (ring slot relative to
+    // the run's first pair), so the loop carries no tile/pair arithmetic:
+    //   flags = next slot (3) | next half (1) | pairs to advance (8) | rare planes (1) | last (1) | .. | ncov (8) | nalt (8)
+    uint32_t x_off = (tile0 & 1) * 8;                // ring byte offset of the current segment's words (slot 0)
+    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
+    const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
+    for (uint32_t s = 0; s < nseg; ++s, rec_addr += IBDG_REC_WORDS * 4) {
+        uint4 h0, h1;            // hot half of the record, the same in every lane
+        uint2 x;                 // this lane's haplotype words of the tile
+        lds_fetch(h0, h1, x, rec_addr, ring_lane + x_off);
+        const uint32_t flags = __builtin_amdgcn_readfirstlane(h0.x);
+        const uint32_t last = flags & (1u << 13);
+        // ---- advance the ring for the next segment: every pair left behind frees a slot, which is
+        // refilled NS pairs ahead; then its pair must have landed
+        const uint32_t adv = (flags >> 4) & 0xff;
+        if (adv) {
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)
+                if (q_issue <= q_last)
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+            // the pair now at the head was issued NS-1 direct-to-LDS loads ago unless the run ends first
+            if (q_issue - 1 <= q_last)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        uint32_t recw;
-        uint2 x;
-        lds_fetch(recw, x, rec_lane + s * (IBDG_REC_WORDS * 4), ring_lane + (q % NS) * 1024 + (tile & 1) * 8);
-        const uint32_t flags = __builtin_amdgcn_readlane(recw, RW_FLAGS);
-        const uint32_t last = __builtin_amdgcn_readlane(recw, RW_LAST);
-        // the target's haplotype words, broadcast to every lane ONCE per segment: as VGPRs they can
-        // sit next to an SGPR mask in v_bitop3 (one scalar operand per VALU instruction); left in
-        // SGPRs hipcc re-materialises them with a v_mov in every plane
-        uint2 at;
-        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                     : "=v"(at.x), "=v"(at.y)
-                     : "s"(__builtin_amdgcn_readlane(recw, RW_TW)), "s"(__builtin_amdgcn_readlane(recw, RW_TW + 1)));
-        tile += flags >> 16;                         // tile of the next segment
-
-        // every mask the common case needs, read up front (v_readlane -> SGPR)
-        const uint32_t cov0 = __builtin_amdgcn_readlane(recw, RW_COV), cov1 = __builtin_amdgcn_readlane(recw, RW_COV + 1);
-        const uint32_t cov2 = __builtin_amdgcn_readlane(recw, RW_COV + 2);
-        const uint32_t alt0 = __builtin_amdgcn_readlane(recw, RW_ALT), alt1 = __builtin_amdgcn_readlane(recw, RW_ALT + 1);
+        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;
+        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;
+        const uint2 at = make_uint2(h1.z, h1.w);     // the target's two haplotype words of this tile
 #if IBDG_TIMING_EXPERIMENT
         const bool count = !(a.debug & 2);
 #else
         const bool count = true;
 #endif
-        const uint32_t ncov = flags & 0xff, nalt = (flags >> 8) & 0xff;
         const uint32_t hom = x.x & x.y;
 #define IBDG_COV_PLANE(k, cov)                                              \
     {                                                                       \
@@ -368,9 +395,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             A1[0] += __popc(x.y & alt0);
             A0[1] += __popc(x.x & alt1);
             A1[1] += __popc(x.y & alt1);
-            if (ncov > FC || nalt > FA) {
+            if (flags & (1u << 12)) {                 // rare: weight bit-planes beyond the counted ones
+                const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;
                 for (uint32_t k = FC; k < ncov; ++k) {
-                    const uint32_t cov = __builtin_amdgcn_readlane(recw, RW_COV + k);
+                    const uint32_t cov = lds_read_b32(rec_addr + (RC_COV3 - FC + k) * 4);
                     const uint32_t u0 = x.x & cov, u1 = x.y & cov;
                     c0[0] += (uint32_t)__popc(u0) << k;
                     c1[0] += (uint32_t)__popc(u1) << k;
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     g11[0] += (uint32_t)__popc(u1 & at.y) << k;
                 }
                 for (uint32_t k = FA; k < nalt; ++k) {
-                    const uint32_t alt = __builtin_amdgcn_readlane(recw, RW_ALT + k);
+                    const uint32_t alt = lds_read_b32(rec_addr + (RC_ALT2 - FA + k) * 4);
                     A0[0] += (uint32_t)__popc(x.x & alt) << k;
                     A1[0] += (uint32_t)__popc(x.y & alt) << k;
                 }
@@ -390,18 +418,17 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 #undef IBDG_COV_PLANE
 
         if (last) {
-            const uint32_t w = __builtin_amdgcn_readlane(recw, RW_WIN);
+            const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_addr + RC_WIN * 4));
 #if IBDG_TIMING_EXPERIMENT
             if (!(a.debug & 1))
 #endif
             {
-                const uint32_t wcw = lds_read_b32(wc_lane + (w - w0) * (IBDG_WC_WORDS * 4));
-                const double mK = __hiloint2double((int)__builtin_amdgcn_readlane(wcw, WC_MK + 1),
-                                                   (int)__builtin_amdgcn_readlane(wcw, WC_MK));
-                const int eK = (int)__builtin_amdgcn_readlane(wcw, WC_EK);
-                const uint32_t CT = __builtin_amdgcn_readlane(wcw, WC_CT), AT = __builtin_amdgcn_readlane(wcw, WC_AT);
-                const uint32_t a0cov = __builtin_amdgcn_readlane(wcw, WC_A0COV), a1cov = __builtin_amdgcn_readlane(wcw, WC_A1COV);
-                const uint32_t a0alt = __builtin_amdgcn_readlane(wcw, WC_A0ALT), a1alt = __builtin_amdgcn_readlane(wcw, WC_A1ALT);
+                uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
+                lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
+                const double mK = __hiloint2double((int)k0.y, (int)k0.x);
+                const int eK = (int)k0.z;
+                const uint32_t CT = k0.w, AT = k1.x;
+                const uint32_t a0cov = k1.y, a1cov = k1.z, a0alt = k1.w, a1alt = k2.x;
                 const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
                 const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
                 const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);

@@ -75,6 +75,24 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
                 asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
                              "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            } else if (KIND == 15) { // v_bitop3_b32, VGPR operands only
+                asm volatile("v_bitop3_b32 %0, %8, %0, %9 bitop3:0x80\n v_bitop3_b32 %1, %8, %1, %9 bitop3:0x80\n v_bitop3_b32 %2, %8, %2, %9 bitop3:0x80\n v_bitop3_b32 %3, %8, %3, %9 bitop3:0x80\n"
+                             "v_bitop3_b32 %4, %8, %4, %9 bitop3:0x80\n v_bitop3_b32 %5, %8, %5, %9 bitop3:0x80\n v_bitop3_b32 %6, %8, %6, %9 bitop3:0x80\n v_bitop3_b32 %7, %8, %7, %9 bitop3:0x80"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(seed));
+            } else if (KIND == 16) { // the LD kernel's plane block: 3 and + 4 bitop3 + 7 bcnt (14 instr), VGPR only; counted as 8 per asm -> scale 14/8
+                uint32_t t0, t1, t2;
+                asm volatile("v_and_b32 %8, %11, %12\n v_and_b32 %9, %11, %13\n v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %9, %1\n"
+                             "v_bitop3_b32 %10, %11, %12, %13 bitop3:0x80\n v_bcnt_u32_b32 %2, %10, %2\n"
+                             "v_bitop3_b32 %10, %8, %14, %14 bitop3:0x80\n v_bcnt_u32_b32 %3, %10, %3\n"
+                             "v_bitop3_b32 %10, %9, %14, %14 bitop3:0x80\n v_bcnt_u32_b32 %4, %10, %4\n"
+                             "v_bitop3_b32 %10, %8, %15, %15 bitop3:0x80\n v_bcnt_u32_b32 %5, %10, %5\n"
+                             "v_and_b32 %10, %9, %15\n v_bcnt_u32_b32 %6, %10, %6"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+                             : "v"(m), "v"(seed), "v"(seed * 3), "v"(seed * 5), "v"(seed * 7));
+            } else if (KIND == 17) { // v_lshl_add_u32 VGPR only
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4\n"
+                             "v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
             } else if (KIND == 8) { // s_nop 0
                 asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
             }
@@ -103,11 +121,13 @@ int main()
 {
     uint32_t *out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);
     const char *names[] = {"v_and_b32 (sgpr mask)", "v_bcnt_u32_b32", "v_bitop3_b32", "v_readlane_b32", "v_mul_f64", "s_and_b32", "v_and+s_and mixed", "and->bcnt dependent", "s_nop 0",
-                           "v_and_b32 (vgpr only)", "v_fma_f32", "v_pk_add_u16", "v_add_f32", "v_pk_fma_f32", "v_add_u32 (vgpr only)"};
+                           "v_and_b32 (vgpr only)", "v_fma_f32", "v_pk_add_u16", "v_add_f32", "v_pk_fma_f32", "v_add_u32 (vgpr only)",
+                           "v_bitop3 (vgpr only)", "plane block x14/8", "v_lshl_add_u32 (vgpr)"};
     for (int w : {1, 2, 4, 8}) {
-        double t[15] = {run<0>(w, out), run<1>(w, out), run<2>(w, out), run<3>(w, out), run<4>(w, out), run<5>(w, out), run<6>(w, out), run<7>(w, out), run<8>(w, out),
-                        run<9>(w, out), run<10>(w, out), run<11>(w, out), run<12>(w, out), run<13>(w, out), run<14>(w, out)};
-        for (int i = 0; i < 15; ++i)
+        double t[18] = {run<0>(w, out), run<1>(w, out), run<2>(w, out), run<3>(w, out), run<4>(w, out), run<5>(w, out), run<6>(w, out), run<7>(w, out), run<8>(w, out),
+                        run<9>(w, out), run<10>(w, out), run<11>(w, out), run<12>(w, out), run<13>(w, out), run<14>(w, out),
+                        run<15>(w, out), run<16>(w, out), run<17>(w, out)};
+        for (int i = 0; i < 18; ++i)
             printf("waves/SIMD=%d  %-22s %.2f ns per wave-instruction per SIMD  (%.2f cycles @2.4GHz)\n", w, names[i], t[i] * 1e9, t[i] * 2.4e9);
         fflush(stdout);
     }
