@@ -113,6 +113,29 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, WinTarget *__rest
     out[(size_t)t * a.n_win + w] = r;
 }
 
+// v + (v of the lane selected by a DPP control): the cross-lane step of a wave reduction with
+// data-parallel-primitive moves instead of ds_bpermute (no LDS traffic, no lane-index arithmetic).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(phi, plo);
+}
+
+// Sum over the 64 lanes in a fixed order; the total ends up in lane 63.
+__device__ __forceinline__ double wave_sum_to_lane63(double v)
+{
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a 16-lane row holds the row total
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <int KP>
 __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 {
@@ -462,12 +485,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 const double Q11 = ld_value(mK, eK, pw[8], pw[9], E3[4]);
                 double s0 = wgt * P2;                                   // :743
                 double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    s0 += __shfl_xor(s0, off);
-                    s1 += __shfl_xor(s1, off);
-                }
-                if (lane == 0) {
+                s0 = wave_sum_to_lane63(s0);
+                s1 = wave_sum_to_lane63(s1);
+                if (lane == 63) {
                     double *o = a.partial + (((size_t)t * a.n_win + w) * a.n_chunks + c) * 2;
                     o[0] = s0;
                     o[1] = s1;
