@@ -218,11 +218,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # BENCH_FORCE_DEVICE / BENCH_BACKEND exist only to rehearse the multi-rank path on a one-GPU box
+    # (all ranks on one device, gloo instead of RCCL); the driver's runs use neither.
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # Every rank derives the same global cut points from the (cheap) read counts of all rows;
     # only its own panel shard is materialised.
@@ -298,7 +306,8 @@ def main():
     eng.set_option("count_in_run", 0)
     ld_variant = eng.last_ld_variant()
 
-    tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64,
+                       device=dev if backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -72,6 +72,11 @@ struct ibdg_ctx {
     bool pop_sites_ok = false;   // site rows strictly increasing, segments built
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
+    // inputs of the previous ibdg_run whose device copies are still valid
+    std::vector<uint32_t> prev_targets;
+    std::vector<uint8_t> prev_bg;
+    int prev_pu = -2, prev_has_bg = -1;
+    size_t prev_lanes = 0;
 
     // run state / results
     DevBuf targets, weight, nrefpanel, af, site_ll, win_ll;
@@ -84,7 +89,8 @@ struct ibdg_ctx {
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
-    long opt_wpg = 16;     // windows per wave in the fast kernel
+    long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
+    bool opt_wpg_fixed = false;
     long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
@@ -347,7 +353,16 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
     wc[c->n_win].seg_begin = (uint32_t)segs.size();
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     {
+        // few windows (a shard of a chromosome, a small region): shorter runs, so that the grid still
+        // holds several rounds of workgroups for every CU and the last round is not mostly idle
         uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
+        {
+            const uint64_t rows_of_blocks = (c->n_chunks + 7) / 8;
+            const uint64_t want_blocks = 256ull * 3 * 8;           // CUs x resident blocks x rounds
+            const uint64_t g_fit = std::max<uint64_t>(1, (uint64_t)c->n_win * rows_of_blocks / want_blocks);
+            if (!c->opt_wpg_fixed && g_fit < g)
+                g = (uint32_t)g_fit;
+        }
         for (;; g = (g + 1) / 2) {
             uint32_t mx = 0;
             for (uint32_t w = 0; w < c->n_win; w += g)
@@ -675,14 +690,18 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     if (ensure(c, c->targets, T * 4) || ensure(c, c->af, c->n_sites * 8) ||
         ensure(c, c->site_ll, T * c->n_sites * 24) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
-    HIP_TRY(c, hipMemcpyAsync(c->targets.p, targets, T * 4, hipMemcpyHostToDevice, c->stream));
-    std::vector<double> wt;
-    std::vector<int> nref;
-    if (ld_mode) {
+    // targets / background weights change rarely between calls (a loop over windows sizes, repeated
+    // timing steps): their device copies are rebuilt only when the inputs differ
+    const bool same_inputs = c->prev_targets.size() == T && std::equal(targets, targets + T, c->prev_targets.begin()) &&
+                             c->prev_pu == pu_id && c->prev_has_bg == (bg_count ? 1 : 0) && c->prev_lanes == lanes &&
+                             (!bg_count || std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin())) &&
+                             (!ld_mode || c->weight.p);
+    if (!same_inputs) {
+        HIP_TRY(c, hipMemcpyAsync(c->targets.p, targets, T * 4, hipMemcpyHostToDevice, c->stream));
+        std::vector<double> wt(T * lanes, 0.0);
+        std::vector<int> nref(T, 0);
         // background multiplicity per individual; the target and the -N sample contribute nothing
         // (src/ibdgem.c:714, :742-750)
-        wt.assign(T * lanes, 0.0);
-        nref.assign(T, 0);
         for (size_t t = 0; t < T; ++t) {
             int cnt = 0;
             for (unsigned n = 0; n < c->n_ids; ++n) {
@@ -698,6 +717,13 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             return 1;
         HIP_TRY(c, hipMemcpyAsync(c->weight.p, wt.data(), wt.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->nrefpanel.p, nref.data(), T * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vectors go out of scope
+        c->prev_targets.assign(targets, targets + T);
+        c->prev_pu = pu_id;
+        c->prev_has_bg = bg_count ? 1 : 0;
+        c->prev_lanes = lanes;
+        if (bg_count)
+            c->prev_bg.assign(bg_count, bg_count + c->n_ids);
     }
 
     const bool recount = c->opt_count_in_run || !c->counts_valid;
@@ -897,7 +923,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     }
     if (!strcmp(name, "windows_per_wave")) {
         if (value < 1 || value > 65536) return fail(c, "[::] ERROR in ibdg_set_option: windows_per_wave must be 1..65536");
-        c->opt_wpg = value; return 0;
+        c->opt_wpg = value; c->opt_wpg_fixed = true; return 0;
     }
     return fail(c, "[::] ERROR in ibdg_set_option: unknown option '%s'", name);
 }
