@@ -793,7 +793,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
-        pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;
+#if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
+        pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;   // ablation builds only
+#else
+        pa.debug = 0;
+#endif
         ibdg::launch_win_target(pa, (unsigned)T, c->stream);
         if (ibdg::launch_ld_popcount(pa, (unsigned)T, c->planes, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);

@@ -149,3 +149,36 @@ def test_config3_chr1_2504_individuals(chr1, oracle):
         eng.run([t], ld=True)
         parts.append(eng.window_ll(0))
     assert (bits(np.concatenate(parts)) == bits(win)).all()
+
+
+def test_config5_500_comparison_individuals_in_one_launch(chr1, oracle):
+    """BASELINE configs[4] shape: chr1, 2504-individual panel, 500 comparison individuals batched
+    in ONE ibdg_run (sites x targets x panel).  Batched results must equal single-target runs bit
+    for bit, and sampled windows must agree with the oracle."""
+    import bench
+    eng, nr, na, L, N = chr1["eng"], chr1["nr"], chr1["na"], chr1["L"], chr1["N"]
+    rng = np.random.default_rng(17)
+    targets = np.sort(rng.choice(N, size=500, replace=False)).astype(np.uint32)
+    eng.upload_sites(np.arange(L, dtype=np.uint32), nr, na, 100)
+    eng.run(targets, ld=True, pu_id=int(targets[3]))
+    assert eng.last_ld_variant() == 2
+    ms = eng.last_run_ms()
+    first, last, ncov = eng.windows()
+    n_win = len(first)
+    print(f"500 targets x {L} rows x {N} individuals: {ms['total']:.1f} ms device time, "
+          f"{500 * int(ncov.sum()) / (ms['total'] * 1e-3):.3e} site-target pairs/s")
+    picks = [0, 3, 250, 499]
+    batched = {i: (eng.window_ll(i), eng.site_ll(i)) for i in picks}
+    for i in picks:
+        eng.run([int(targets[i])], ld=True, pu_id=int(targets[3]))
+        assert (bits(eng.window_ll(0)) == bits(batched[i][0])).all(), f"target slot {i}: windows"
+        assert (bits(eng.site_ll(0)) == bits(batched[i][1])).all(), f"target slot {i}: sites"
+    for i in (3, 499):
+        t = int(targets[i])
+        for w in rng.integers(0, n_win, 6):
+            a, b = int(first[w]), int(last[w]) + 1
+            alle = bench.unpack_rows(chr1["panel"][a:b].cpu().numpy().view(np.uint64), N)
+            res = oracle.compare(alle, nr[a:b], na[a:b], t, window=100, ld=True, pu_id=int(targets[3]))
+            assert (bits(batched[i][1][a:b]) == bits(res["site"])).all()
+            assert bits(batched[i][0][w, 2]) == bits(res["win"][0, 2])
+            ld_close(batched[i][0][w:w + 1, :2], res["win"][:, :2])
