@@ -72,6 +72,8 @@ struct ibdg_ctx {
     bool pop_sites_ok = false;   // site rows strictly increasing, segments built
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
+    void *stamp_ptr = nullptr;         // ablation builds: in-kernel stamp sums of the last --LD launch
+    size_t stamp_bytes = 0;
     // inputs of the previous ibdg_run whose device copies are still valid
     std::vector<uint32_t> prev_targets;
     std::vector<uint8_t> prev_bg;
@@ -768,8 +770,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
     c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     if (use_pop) {
-        if (ensure(c, c->wtarget, T * (size_t)c->n_win * sizeof(ibdg::WinTarget)) ||
-            ensure(c, c->twords, T * (size_t)c->n_segs * 8) ||
+        if (ensure(c, c->wtarget, T * (size_t)c->n_win * 48) ||
+            ensure(c, c->twords, T * (size_t)c->n_segs * 80) ||
             ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
             return 1;
         ibdg::PopArgs pa;
@@ -779,11 +781,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.segs = (const ibdg::Seg *)c->segs.p;
         pa.n_segs = c->n_segs;
         pa.max_seg = c->max_seg;
-        pa.twords = (const uint2 *)c->twords.p;
+        pa.rec_ready = (const uint32_t *)c->twords.p;
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
         pa.win_per_group = c->wpg;
-        pa.wtarget = (const ibdg::WinTarget *)c->wtarget.p;
+        pa.wc_ready = (const uint32_t *)c->wtarget.p;
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
@@ -793,8 +795,18 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
+        pa.stamps = nullptr;
 #if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
         pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;   // ablation builds only
+        if (getenv("IBDG_STAMPS")) {
+            const size_t n_w = (size_t)((c->n_win + c->wpg - 1) / c->wpg) * ((c->n_chunks + 7) / 8) * T * 8;
+            static DevBuf stamp_buf;
+            if (ensure(c, stamp_buf, n_w * 64)) return 1;
+            HIP_TRY(c, hipMemsetAsync(stamp_buf.p, 0, n_w * 64, c->stream));
+            pa.stamps = (unsigned long long *)stamp_buf.p;
+            c->stamp_ptr = stamp_buf.p;
+            c->stamp_bytes = n_w * 64;
+        }
 #else
         pa.debug = 0;
 #endif
@@ -851,6 +863,24 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[2], c->ev2[3])); c->ms[4] = v;
     c->n_targets = T;
     c->have_results = true;
+#if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
+    if (c->stamp_ptr && getenv("IBDG_STAMPS")) {
+        std::vector<unsigned long long> h(c->stamp_bytes / 8);
+        HIP_TRY(c, hipMemcpy(h.data(), c->stamp_ptr, c->stamp_bytes, hipMemcpyDeviceToHost));
+        unsigned long long sum[8] = {0};
+        size_t n = 0;
+        for (size_t i = 0; i + 8 <= h.size(); i += 8)
+            if (h[i + 5]) { for (int k = 0; k < 8; ++k) sum[k] += h[i + k]; ++n; }
+        FILE *f = fopen(getenv("IBDG_STAMPS"), "w");
+        if (f) {
+            fprintf(f, "waves %zu\nstage %.1f\ndma %.1f\nfetch %.1f\ncount %.1f\nfinalize %.1f\ntotal %.1f\nsegs %.1f\nwindows %.1f\n", n,
+                    (double)sum[0] / n, (double)sum[1] / n, (double)sum[2] / n, (double)sum[3] / n, (double)sum[4] / n,
+                    (double)sum[5] / n, (double)sum[6] / n, (double)sum[7] / n);
+            fclose(f);
+        }
+        c->stamp_ptr = nullptr;
+    }
+#endif
     return 0;
 }
 

@@ -82,11 +82,6 @@ struct WinConst {
     uint32_t seg_begin;  // first segment of the window
 };                       // 24 bytes
 
-// per (target, window)
-struct WinTarget {
-    uint32_t a0cov, a1cov, a0alt, a1alt;   // <target haplotype, cov> and <target haplotype, alt>
-};
-
 struct PopArgs {
     const uint32_t *t32;        // [n_chunks][n_pairs][64] uint4: tile-transposed panel (see k_transpose32)
     uint32_t n_pairs;           // tile pairs per chunk, a multiple of 4 (whole octs)
@@ -94,11 +89,11 @@ struct PopArgs {
     const Seg *segs;
     uint32_t n_segs;
     uint32_t max_seg;           // most segments in one run of win_per_group windows (LDS sizing)
-    const uint2 *twords;        // [T][n_segs] the target's haplotype words of each segment's tile
+    const uint32_t *rec_ready;  // [T][n_segs][20] LDS-ready segment records (written by k_win_target)
     const WinConst *wconst;     // [n_win + 1] (the extra entry carries seg_begin = n_segs)
     uint32_t n_win;
     uint32_t win_per_group;
-    const WinTarget *wtarget;   // [T][n_win]
+    const uint32_t *wc_ready;   // [T][n_win][12] LDS-ready window constants (written by k_win_target)
     const PowEntry *pow_1me;    // [(max cov_total)+1]
     const PowEntry *pow_eps;
     const uint32_t *targets;    // [T]
@@ -108,6 +103,7 @@ struct PopArgs {
     uint32_t ring_slots;        // 4 or 8 tile pairs of LDS ring per wave
     uint32_t tab_len;           // entries per power table = (max cov_total) + 1
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
+    unsigned long long *stamps; // ablation builds only: per-wave stamp sums (8 x u64 per wave), else NULL
     uint32_t debug;             // timing experiments only (env IBDG_DEBUG): 1 skip window math, 2 skip counting
 };
 

@@ -85,32 +85,49 @@ __device__ __forceinline__ uint2 tile_words(const uint4 *__restrict__ base, uint
 }
 
 // ---------------------------------------------------------------------------
-// Per (window, target): <t0,cov>, <t1,cov>, <t0,alt>, <t1,alt> over the window's rows.
+// Per target, one thread per segment and per window: the LDS-ready images the --LD kernel stages with plain
+// contiguous copies -- every segment's 20-word record (layout above k_ld_popcount) with the
+// target's haplotype words of its tile filled in, and the window's 12 constants including
+// <t0,cov>, <t1,cov>, <t0,alt>, <t1,alt> summed over the window's rows.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_win_target(PopArgs a, WinTarget *__restrict__ out,
-                                                    uint2 *__restrict__ twords)
+__global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restrict__ rec_ready,
+                                                    uint32_t *__restrict__ wc_ready)
 {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.n_win)
-        return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned t = blockIdx.y;
     const uint32_t tgt = a.targets[t];
     const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
-    WinTarget r = {0, 0, 0, 0};
-    const uint32_t s1 = a.wconst[w + 1].seg_begin;
-    for (uint32_t s = a.wconst[w].seg_begin; s < s1; ++s) {
-        const Seg &S = a.segs[s];
+    if (i < a.n_segs) {                      // thread i: the record of segment i
+        const Seg S = a.segs[i];
         const uint2 at = tile_words(tt, S.tile);
-        twords[(size_t)t * a.n_segs + s] = at;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            r.a0cov += (uint32_t)__popc(at.x & S.cov[k]) << k;
-            r.a1cov += (uint32_t)__popc(at.y & S.cov[k]) << k;
-            r.a0alt += (uint32_t)__popc(at.x & S.alt[k]) << k;
-            r.a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
-        }
+        uint4 *o = reinterpret_cast<uint4 *>(rec_ready + ((size_t)t * a.n_segs + i) * 20);
+        o[0] = make_uint4(S.flags, S.cov[0], S.cov[1], S.cov[2]);          // hot half
+        o[1] = make_uint4(S.alt[0], S.alt[1], at.x, at.y);
+        o[2] = make_uint4(S.win, S.cov[3], S.cov[4], S.cov[5]);            // cold half
+        o[3] = make_uint4(S.cov[6], S.cov[7], S.alt[2], S.alt[3]);
+        o[4] = make_uint4(S.alt[4], S.alt[5], S.alt[6], S.alt[7]);
     }
-    out[(size_t)t * a.n_win + w] = r;
+    if (i < a.n_win) {                       // thread i: the constants of window i
+        const uint32_t w = i;
+        uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
+        const uint32_t s1 = a.wconst[w + 1].seg_begin;
+        for (uint32_t s = a.wconst[w].seg_begin; s < s1; ++s) {
+            const Seg &S = a.segs[s];
+            const uint2 at = tile_words(tt, S.tile);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0cov += (uint32_t)__popc(at.x & S.cov[k]) << k;
+                a1cov += (uint32_t)__popc(at.y & S.cov[k]) << k;
+                a0alt += (uint32_t)__popc(at.x & S.alt[k]) << k;
+                a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
+            }
+        }
+        const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);    // mK(2) eK ct at seg_begin
+        uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * 12);
+        o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
+        o[1] = make_uint4(wcs[4], a0cov, a1cov, a0alt);
+        o[2] = make_uint4(a1alt, 0, 0, 0);
+    }
 }
 
 // v + (v of the lane selected by a DPP control): the cross-lane step of a wave reduction with
@@ -252,12 +269,30 @@ __device__ __forceinline__ double ld_value(double mK, int eK, const uint4 &p1, c
     return __builtin_ldexp(m, eK + (int)p1.z + (int)p2.z - (int)E3);
 }
 
+#if IBDG_TIMING_EXPERIMENT
+// In-kernel stamps (ablation builds only): shader-clock ticks, summed per wave and written to
+// PopArgs::stamps[wave_global][8]; never read by the kernel, never part of a product build.
+__device__ __forceinline__ unsigned long long stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define IBDG_STAMP(var) const unsigned long long var = stamp()
+#define IBDG_ACC(sum, a_, b_) sum += (b_) - (a_)
+#else
+#define IBDG_STAMP(var)
+#define IBDG_ACC(sum, a_, b_)
+#endif
+
 template <int NS, bool TAB_LDS>
 __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
-                                                     const uint2 *__restrict__ twords,
+                                                     const uint32_t *__restrict__ rec_ready,
                                                      const WinConst *__restrict__ wconst,
-                                                     const WinTarget *__restrict__ wtarget,
+                                                     const uint32_t *__restrict__ wc_ready,
                                                      const uint4 *__restrict__ pow_1me,
                                                      const uint4 *__restrict__ pow_eps,
                                                      PopArgs a)
@@ -274,6 +309,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     if (nseg == 0)
         return;
 
+#if IBDG_TIMING_EXPERIMENT
+    unsigned long long t_stage = 0, t_dma = 0, t_fetch = 0, t_count = 0, t_fin = 0;
+#endif
+    IBDG_STAMP(ts0);
     // ---- LDS carve-up (see ld_popcount_lds_bytes)
     uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][22]
     uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_REC_WORDS;               // [win_per_group][12]
@@ -282,58 +321,50 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
     char *ring0 = smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
 
+    // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
+    // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
+    // two start-up latencies of a workgroup overlap instead of adding up.
+    const unsigned c = blockIdx.y * 8 + wave;
+    const bool has_chunk = c < a.n_chunks;
+    char *ring = ring0 + (size_t)wave * NS * 1024;
+    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
+    const uint32_t tile0 = segs[seg0].tile;
+    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
+    uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
+    if (has_chunk) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i, ++q_issue)
+            if (q_issue <= q_last)
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+    }
+
     // ---- stage the run's records, window constants and tables (whole workgroup)
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(segs + seg0);    // tile win last flags cov[8] alt[8]
-        const uint2 *tws = twords + (size_t)t * a.n_segs + seg0;
-        for (uint32_t i = threadIdx.x; i < nseg * 32; i += blockDim.x) {
-            const uint32_t sg = i >> 5, wd = i & 31;
-            const uint32_t *S = src + sg * 20;
-            uint32_t v;
-            if (wd >= IBDG_REC_WORDS)
-                continue;
-            if (wd == 0)
-                v = S[3];
-            else if (wd <= 3)
-                v = S[4 + (wd - 1)];                   // cov0..2
-            else if (wd <= 5)
-                v = S[12 + (wd - 4)];                  // alt0..1
-            else if (wd == 6)
-                v = tws[sg].x;
-            else if (wd == 7)
-                v = tws[sg].y;
-            else if (wd == RC_WIN)
-                v = S[1];
-            else if (wd < RC_ALT2)
-                v = S[4 + 3 + (wd - RC_COV3)];         // cov3..7
-            else
-                v = S[12 + 2 + (wd - RC_ALT2)];        // alt2..7
-            rec_lds[sg * IBDG_REC_WORDS + wd] = v;
-        }
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 16; i += blockDim.x) {
-            const uint32_t wj = i >> 4, wd = i & 15;
-            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(wconst + w0 + wj);     // mK(2) eK ct at seg
-            const uint32_t *wts = reinterpret_cast<const uint32_t *>(wtarget + (size_t)t * a.n_win + w0 + wj);
-            if (wd < 5)
-                wc_lds[wj * IBDG_WC_WORDS + wd] = wcs[wd];
-            else if (wd < 9)
-                wc_lds[wj * IBDG_WC_WORDS + wd] = wts[wd - 5];
-        }
+        // plain contiguous copies (k_win_target prepared the LDS images): every load of a thread is
+        // independent of the others, so the whole staging costs about one memory latency
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * 5;
+        uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
+        for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
+            rdst[i] = rsrc[i];
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * 3;
+        uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 3; i += blockDim.x)
+            wdst[i] = wsrc[i];
         if (TAB_LDS)
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
                 tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
     }
     __syncthreads();
 
-    const unsigned c = blockIdx.y * 8 + wave;
-    if (c >= a.n_chunks)
+    if (!has_chunk)
         return;
-    char *ring = ring0 + (size_t)wave * NS * 1024;
+    IBDG_STAMP(ts1);
+    IBDG_ACC(t_stage, ts0, ts1);
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
 
-    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
     const double wgt = a.weight[(size_t)t * a.lanes + c * 64 + lane];
 
     // Counters per weight bit-plane: three planes for the cov-weighted sums, two for the
@@ -347,15 +378,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     for (int k = 0; k < FA; ++k)
         A0[k] = A1[k] = 0;
 
-    // ---- prime the ring: pairs q0 .. q0+NS-1 (not past the run's last pair)
-    const uint32_t tile0 = segs[seg0].tile;
-    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
-    uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
-#pragma unroll
-    for (int i = 0; i < NS; ++i, ++q_issue)
-        if (q_issue <= q_last)
-            __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
-                                             (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+    // the first pair must have landed (it was requested before the staging loads, so it has)
     if (q_issue - 1 <= q_last)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
     else
@@ -371,8 +394,11 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     for (uint32_t s = 0; s < nseg; ++s, rec_addr += IBDG_REC_WORDS * 4) {
         uint4 h0, h1;            // hot half of the record, the same in every lane
         uint2 x;                 // this lane's haplotype words of the tile
+        IBDG_STAMP(tf0);
         lds_fetch(h0, h1, x, rec_addr, ring_lane + x_off);
         const uint32_t flags = __builtin_amdgcn_readfirstlane(h0.x);
+        IBDG_STAMP(tf1);
+        IBDG_ACC(t_fetch, tf0, tf1);
         const uint32_t last = flags & (1u << 13);
         // ---- advance the ring for the next segment: every pair left behind frees a slot, which is
         // refilled NS pairs ahead; then its pair must have landed
@@ -389,6 +415,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;
+        IBDG_STAMP(td1);
+        IBDG_ACC(t_dma, tf1, td1);
         const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;
         const uint2 at = make_uint2(h1.z, h1.w);     // the target's two haplotype words of this tile
 #if IBDG_TIMING_EXPERIMENT
@@ -440,6 +468,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         }
 #undef IBDG_COV_PLANE
 
+        IBDG_STAMP(tc1);
+        IBDG_ACC(t_count, td1, tc1);
         if (last) {
             const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_addr + RC_WIN * 4));
 #if IBDG_TIMING_EXPERIMENT
@@ -499,10 +529,19 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 #pragma unroll
             for (int k = 0; k < FA; ++k)
                 A0[k] = A1[k] = 0;
+            IBDG_STAMP(tn1);
+            IBDG_ACC(t_fin, tc1, tn1);
         }
     }
     // leave no direct-to-LDS load in flight when the wave ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if IBDG_TIMING_EXPERIMENT
+    if (a.stamps && lane == 0) {
+        const unsigned long long te = stamp();
+        unsigned long long *o = a.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        o[0] = t_stage; o[1] = t_dma; o[2] = t_fetch; o[3] = t_count; o[4] = t_fin; o[5] = te - ts0; o[6] = nseg; o[7] = w1 - w0;
+    }
+#endif
 }
 
 // Sum the per-chunk partials in ascending chunk order and take the background average
@@ -539,8 +578,9 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
 {
     if (a.n_win == 0)
         return;
-    hipLaunchKernelGGL(k_win_target, dim3((a.n_win + 255) / 256, n_targets), dim3(256), 0, st, a,
-                       const_cast<WinTarget *>(a.wtarget), const_cast<uint2 *>(a.twords));
+    const uint32_t n = a.n_segs > a.n_win ? a.n_segs : a.n_win;
+    hipLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, a,
+                       const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
 }
 
 // LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
@@ -561,8 +601,8 @@ static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.twords, a.wconst,
-                       a.wtarget, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
+                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a);
     return 0;
 }
 
