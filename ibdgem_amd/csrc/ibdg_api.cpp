@@ -198,6 +198,18 @@ ME me_norm(long double x, long long e)
     return ME{m, e + k};
 }
 
+ME me_powl(ME b, uint64_t n)
+{
+    ME r = me_norm(1.0L, 0);
+    while (n) {
+        if (n & 1)
+            r = me_norm(r.m * b.m, r.e + b.e);
+        b = me_norm(b.m * b.m, 2 * b.e);
+        n >>= 1;
+    }
+    return r;
+}
+
 ME me_pow(double base, uint64_t n)
 {
     ME r = me_norm(1.0L, 0), b = me_norm((long double)base, 0);
@@ -346,8 +358,12 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
             K = me_norm(K.m * (long double)c->nck_h[(size_t)cv * d + r], K.e);
         }
         segs.back().last = 1;
-        wc[w].mK = (double)K.m;
-        wc[w].eK = (int32_t)K.e;
+        // K' = K * (1-eps)^(all reads of the window): with it a product is K' * rho^E2 * sigma^E3,
+        // rho = eps/(1-eps), sigma = 1/(2(1-eps))  (E1 = reads - E2 - E3 eliminated)
+        const ME B = me_pow(1 - c->eps, ct);
+        const ME Kp = me_norm(K.m * B.m, K.e + B.e);
+        wc[w].mK = (double)Kp.m;
+        wc[w].eK = (int32_t)Kp.e;
         wc[w].cov_total = ct;
         wc[w].alt_total = at;
         ct_max = std::max(ct_max, ct);
@@ -413,9 +429,12 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
     c->n_segs = (uint32_t)segs.size();
     c->ct_max = ct_max;
     std::vector<ibdg::PowEntry> p1(ct_max + 1), p2(ct_max + 1);
-    const double b1 = 1 - c->eps;
+    // rho^n and sigma^n in extended precision; the bases come from the doubles the reference uses
+    // (epsilon and 1-epsilon, src/ibd-math.c:58-61)
+    const long double one_me = (long double)(double)(1 - c->eps);
+    const ME rho = me_norm((long double)c->eps / one_me, 0), sigma = me_norm(0.5L / one_me, 0);
     for (uint32_t n = 0; n <= ct_max; ++n) {
-        const ME x = me_pow(b1, n), y = me_pow(c->eps, n);
+        const ME x = me_powl(rho, n), y = me_powl(sigma, n);
         if (x.e < -2000000000LL || y.e < -2000000000LL)
             return 0;
         p1[n].m = (double)x.m; p1[n].e = (int32_t)x.e; p1[n].pad = 0;
@@ -814,6 +833,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (ibdg::launch_ld_popcount(pa, (unsigned)T, c->planes, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         ibdg::PopFinalArgs fa;
+        fa.wconst = pa.wconst;
         fa.partial = pa.partial;
         fa.n_win = c->n_win;
         fa.n_chunks = c->n_chunks;

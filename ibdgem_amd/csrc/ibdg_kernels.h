@@ -66,7 +66,7 @@ struct Seg {
     uint32_t alt[8];
 };                       // 80 bytes
 
-// (1-eps)^E or eps^E as m * 2^e with m in [0.5,1]
+// rho^n or sigma^n (rho = eps/(1-eps), sigma = 1/(2(1-eps))) as m * 2^e with m in [0.5,1]
 struct PowEntry {
     double m;
     int32_t e;
@@ -75,7 +75,7 @@ struct PowEntry {
 
 // per window, target independent
 struct WinConst {
-    double mK;           // prod of the binomial coefficients C(cov,n_ref) = mK * 2^eK
+    double mK;           // K' = prod C(cov,n_ref) * (1-eps)^cov_total = mK * 2^eK
     int32_t eK;
     uint32_t cov_total;  // sum of n_ref+n_alt over the window's rows
     uint32_t alt_total;  // sum of n_alt
@@ -108,6 +108,7 @@ struct PopArgs {
 };
 
 struct PopFinalArgs {
+    const WinConst *wconst;
     const double *partial;
     uint32_t n_win, n_chunks;
     const int *n_refpanel;

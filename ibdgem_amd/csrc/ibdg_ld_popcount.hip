@@ -7,6 +7,7 @@
 // (C = binomial coefficient, r/a = n_ref/n_alt of the row, e = epsilon), so a product over the
 // rows of a window is exactly
 //     prod = K * (1-e)^E1 * e^E2 * 2^-E3,    K = prod C,
+//          = K' * rho^E2 * sigma^E3,  K' = K (1-e)^reads, rho = e/(1-e), sigma = 1/(2(1-e)),
 //     E3 = reads on rows where the genotype is 1, E2 = reads that contradict a homozygous
 //     genotype (alt reads under 0, ref reads under 2), E1 = all reads - E2 - E3.
 // E2 and E3 are integers: sums of small per-row weights over the rows selected by haplotype
@@ -22,9 +23,9 @@
 //     pDg[x0+x1]:  E3 = C(x0)+C(x1)-2C(x0&x1)        E2 = ALT - A(x0) - A(x1) + C(x0&x1)
 //     pDg[t +x ]:  E3 = <t,cov> + C(x) - 2G(x,t)     E2 = ALT - <t,alt> - A(x) + G(x,t)
 // The integers are exact, so rows may be visited in any grouping; the floating-point value
-//     ldexp(mK * m1[E1] * m2[E2], eK + e1[E1] + e2[E2] - E3)
-// (tables of (1-e)^n and e^n as mantissa/exponent pairs, built on the host in extended
-// precision) carries ~4 roundings, i.e. it is CLOSER to the exact product than the reference's
+//     mK' * ldexp(m1[E2] * m2[E3], eK' + e1[E2] + e2[E3])
+// (tables of rho^n and sigma^n as mantissa/exponent pairs, built on the host in extended
+// precision; mK' is applied after the sum over the background) carries ~4 roundings, i.e. it is CLOSER to the exact product than the reference's
 // 100 sequential multiplications; the two agree to ~1e-14 relative (documented bar: 1e-10).
 // Values below the double range come out as 0/subnormal from the final ldexp, like the
 // reference's running product.  The host enables this kernel only when the P(D|G) table is
@@ -261,12 +262,12 @@ __device__ __forceinline__ void lds_read_pow10(uint4 (&p)[10], const uint32_t (&
                  : "memory");
 }
 
-// K * (1-e)^E1 * e^E2 * 2^-E3 from two table entries {m (2 words), e, pad}
-__device__ __forceinline__ double ld_value(double mK, int eK, const uint4 &p1, const uint4 &p2, uint32_t E3)
+// rho^E2 * sigma^E3 * 2^eK from two table entries {m (2 words), e, pad}; the mantissa of K' is
+// applied once per window in k_ld_finalize
+__device__ __forceinline__ double ld_value(int eK, const uint4 &p1, const uint4 &p2)
 {
     const double m1 = __hiloint2double((int)p1.y, (int)p1.x), m2 = __hiloint2double((int)p2.y, (int)p2.x);
-    const double m = (mK * m1) * m2;
-    return __builtin_ldexp(m, eK + (int)p1.z + (int)p2.z - (int)E3);
+    return __builtin_ldexp(m1 * m2, eK + (int)p1.z + (int)p2.z);
 }
 
 #if IBDG_TIMING_EXPERIMENT
@@ -478,9 +479,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             {
                 uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
                 lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
-                const double mK = __hiloint2double((int)k0.y, (int)k0.x);
                 const int eK = (int)k0.z;
-                const uint32_t CT = k0.w, AT = k1.x;
+                const uint32_t AT = k1.x;
                 const uint32_t a0cov = k1.y, a1cov = k1.z, a0alt = k1.w, a1alt = k2.x;
                 const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
                 const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
@@ -497,22 +497,22 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     uint32_t ad[10];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        ad[2 * i] = tab1 + (CT - E2[i] - E3[i]) * 16;
-                        ad[2 * i + 1] = tab2 + E2[i] * 16;
+                        ad[2 * i] = tab1 + E2[i] * 16;
+                        ad[2 * i + 1] = tab2 + E3[i] * 16;
                     }
                     lds_read_pow10(pw, ad);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        pw[2 * i] = pow_1me[CT - E2[i] - E3[i]];
-                        pw[2 * i + 1] = pow_eps[E2[i]];
+                        pw[2 * i] = pow_1me[E2[i]];
+                        pw[2 * i + 1] = pow_eps[E3[i]];
                     }
                 }
-                const double P2 = ld_value(mK, eK, pw[0], pw[1], E3[0]);
-                const double Q00 = ld_value(mK, eK, pw[2], pw[3], E3[1]);
-                const double Q01 = ld_value(mK, eK, pw[4], pw[5], E3[2]);
-                const double Q10 = ld_value(mK, eK, pw[6], pw[7], E3[3]);
-                const double Q11 = ld_value(mK, eK, pw[8], pw[9], E3[4]);
+                const double P2 = ld_value(eK, pw[0], pw[1]);
+                const double Q00 = ld_value(eK, pw[2], pw[3]);
+                const double Q01 = ld_value(eK, pw[4], pw[5]);
+                const double Q10 = ld_value(eK, pw[6], pw[7]);
+                const double Q11 = ld_value(eK, pw[8], pw[9]);
                 double s0 = wgt * P2;                                   // :743
                 double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
                 s0 = wave_sum_to_lane63(s0);
@@ -559,9 +559,10 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
         t1 += p[2 * c + 1];
     }
     const int nref = a.n_refpanel[t];
+    const double mK = a.wconst[w].mK;                 // mantissa of K' (its exponent went into every term)
     double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
-    o[0] = t0 / (double)nref;
-    o[1] = t1 / (double)(nref * 4);
+    o[0] = (t0 * mK) / (double)nref;
+    o[1] = (t1 * mK) / (double)(nref * 4);
 }
 
 // ---------------------------------------------------------------------------
