@@ -37,8 +37,23 @@ struct ibdg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // per-site + window-product kernels run beside the --LD kernels
-    hipEvent_t ev[6] = {};
-    hipEvent_t ev2[4] = {};
+    // Timing events of the last runs (asynchronous runs are timed after the fact).  Every event
+    // record is a barrier packet the command processor retires in ~5 us, so the main stream carries
+    // one per run (end of the --LD launches) plus a start only when the stream may have been idle.
+    static constexpr int EV_RING = 33;      // the last 32 runs can be queried
+    struct EvSet {
+        hipEvent_t start_own = nullptr;     // recorded when the previous run's end cannot serve as start
+        hipEvent_t ld_end = nullptr;        // main stream, after the last --LD launch
+        hipEvent_t s2_start = nullptr;      // stream2: before its first kernel of the run
+        hipEvent_t s2[3] = {};              // stream2: after alt-count, per-site, window-product kernels
+        hipEvent_t start = nullptr;         // start_own or the previous run's ld_end
+        bool recount = false, ld = false;
+    } evs[EV_RING];
+    int ev_head = 0;
+    long runs_done = 0;
+    bool chain_ok = false;      // main stream has been busy since the head run's ld_end was queued
+    bool s2_pending = false;    // stream2 holds work the main stream has not waited for yet
+    hipEvent_t last_s2 = nullptr;
     std::string err;
 
     double eps = 0.02;
@@ -70,6 +85,7 @@ struct ibdg_ctx {
     int planes = 0;
     bool pop_lut_ok = false;     // P(D|G) table is the unclamped binomial form
     bool pop_sites_ok = false;   // site rows strictly increasing, segments built
+    bool pop_dense_enough = true; // covered rows / spanned rows high enough for it to be the faster kernel
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
     void *stamp_ptr = nullptr;         // ablation builds: in-kernel stamp sums of the last --LD launch
@@ -84,10 +100,10 @@ struct ibdg_ctx {
     DevBuf targets, weight, nrefpanel, af, site_ll, win_ll;
     size_t n_targets = 0;
     bool have_results = false;
-    float ms[5] = {0, 0, 0, 0, 0};
 
     // options
     long opt_count_in_run = 0;
+    long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
@@ -119,6 +135,26 @@ int fail(ibdg_ctx *c, const char *fmt, ...)
         if (e_ != hipSuccess)                                                                   \
             return fail((c), "[::] ERROR in %s: %s: %s", __func__, #call, hipGetErrorString(e_)); \
     } while (0)
+
+// The main stream waits for whatever stream2 still holds (queued, not a host wait).
+int join_streams(ibdg_ctx *c)
+{
+    if (c->s2_pending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_s2, 0));
+        c->s2_pending = false;
+    }
+    return 0;
+}
+
+// Host wait until both streams are idle (before results are read or inputs replaced).
+int quiesce(ibdg_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (join_streams(c)) return 1;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->chain_ok = false;
+    return 0;
+}
 
 int ensure(ibdg_ctx *c, DevBuf &b, size_t bytes)
 {
@@ -376,7 +412,7 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
         {
             const uint64_t rows_of_blocks = (c->n_chunks + 7) / 8;
-            const uint64_t want_blocks = 256ull * 3 * 8;           // CUs x resident blocks x rounds
+            const uint64_t want_blocks = 256ull * 2 * 5;           // CUs x resident blocks x rounds
             const uint64_t g_fit = std::max<uint64_t>(1, (uint64_t)c->n_win * rows_of_blocks / want_blocks);
             if (!c->opt_wpg_fixed && g_fit < g)
                 g = (uint32_t)g_fit;
@@ -449,6 +485,13 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
     HIP_TRY(c, hipMemcpyAsync(c->pow2.p, p2.data(), p2.size() * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pop_sites_ok = true;
+    // Sparse coverage: the exponent-counting kernel streams every 32-row tile between a window's first
+    // and last row (~175 issue cycles per tile and chunk) while the strict kernel touches covered rows
+    // only (~49 cycles per row and chunk): below ~1 covered row in 9 the strict kernel is the faster one.
+    {
+        const uint64_t span = (uint64_t)rec_cov.back().x - rec_cov.front().x + 1;
+        c->pop_dense_enough = (uint64_t)c->n_cov * 9 >= span;
+    }
     return 0;
 }
 
@@ -508,10 +551,10 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
         return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
-    for (auto &ev : c->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    for (auto &ev : c->ev2)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto &E : c->evs) {
+        for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
+            if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     const size_t d = (size_t)max_cov + 1;
     c->lut_h.resize(d * d * 3);
     build_pdg_table(epsilon, max_cov, c->lut_h.data());
@@ -535,18 +578,18 @@ void ibdg_destroy(ibdg_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
+    if (c->stream2)
+        (void)hipStreamSynchronize(c->stream2);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
                       &c->segs, &c->wconst, &c->wtarget, &c->twords, &c->pow1, &c->pow2, &c->partial})
         release(*b);
-    for (auto &ev : c->ev)
-        if (ev)
-            (void)hipEventDestroy(ev);
-    for (auto &ev : c->ev2)
-        if (ev)
-            (void)hipEventDestroy(ev);
+    for (auto &E : c->evs)
+        for (hipEvent_t ev : {E.start_own, E.ld_end, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
+            if (ev)
+                (void)hipEventDestroy(ev);
     if (c->stream2)
         (void)hipStreamDestroy(c->stream2);
     if (c->stream)
@@ -590,7 +633,7 @@ int ibdg_upload_panel(ibdg_ctx *c, const uint64_t *rows, size_t n_rows, unsigned
 {
     if (!c) return 1;
     if (!rows && n_rows) return fail(c, "[::] ERROR in ibdg_upload_panel: rows is NULL");
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (quiesce(c)) return 1;
     if (prepare_panel(c, n_rows, n_ids)) return 1;
     return copy_rows(c, rows, n_rows, hipMemcpyHostToDevice);
 }
@@ -599,7 +642,7 @@ int ibdg_upload_panel_dev(ibdg_ctx *c, const void *dev_rows, size_t n_rows, unsi
 {
     if (!c) return 1;
     if (!dev_rows && n_rows) return fail(c, "[::] ERROR in ibdg_upload_panel_dev: rows is NULL");
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (quiesce(c)) return 1;
     if (prepare_panel(c, n_rows, n_ids)) return 1;
     // the source may have been produced on another stream (e.g. torch's): make it visible first
     HIP_TRY(c, hipDeviceSynchronize());
@@ -616,7 +659,7 @@ int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_r
         return fail(c, "[::] ERROR in ibdg_upload_sites: NULL input array");
     if (n_sites > 0xffffffffull)
         return fail(c, "[::] ERROR in ibdg_upload_sites: more than 2^32-1 rows in one call");
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (quiesce(c)) return 1;
     const unsigned d = c->max_cov + 1;
     std::vector<uint2> rec_all(n_sites), rec_cov;
     rec_cov.reserve(n_sites);
@@ -718,6 +761,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                              (!bg_count || std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin())) &&
                              (!ld_mode || c->weight.p);
     if (!same_inputs) {
+        // stream2 may still read the previous targets: the main stream waits for it before overwriting
+        if (join_streams(c)) return 1;
         HIP_TRY(c, hipMemcpyAsync(c->targets.p, targets, T * 4, hipMemcpyHostToDevice, c->stream));
         std::vector<double> wt(T * lanes, 0.0);
         std::vector<int> nref(T, 0);
@@ -739,6 +784,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipMemcpyAsync(c->weight.p, wt.data(), wt.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->nrefpanel.p, nref.data(), T * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vectors go out of scope
+        c->chain_ok = false;
         c->prev_targets.assign(targets, targets + T);
         c->prev_pu = pu_id;
         c->prev_has_bg = bg_count ? 1 : 0;
@@ -748,17 +794,22 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
 
     const bool recount = c->opt_count_in_run || !c->counts_valid;
+    const int ev_slot = (c->ev_head + 1) % ibdg_ctx::EV_RING;      // becomes the head once the run is queued
+    ibdg_ctx::EvSet &E = c->evs[ev_slot];
+    E.recount = recount;
+    E.ld = ld_mode != 0;
     // Two streams: the per-site kernel and the window products (memory-bound, few waves) run on
-    // stream2 beside the --LD kernels (VALU-bound) on the main stream; they only meet at the end.
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[0], 0));
-    HIP_TRY(c, hipEventRecord(c->ev2[0], c->stream2));
-    if (recount) {
-        ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
-                               c->stream2);
-        c->counts_valid = true;
+    // stream2 beside the --LD kernels (VALU-bound) on the main stream.  stream2 only has to wait
+    // for the main stream when the inputs were just replaced there; the main stream waits for
+    // stream2 when somebody needs the results (join_streams), not once per run.
+    if (c->chain_ok && c->opt_async) {
+        E.start = c->evs[c->ev_head].ld_end;       // back-to-back runs: the previous end is this start
+    } else {
+        HIP_TRY(c, hipEventRecord(E.start_own, c->stream));
+        E.start = E.start_own;
     }
-    HIP_TRY(c, hipEventRecord(c->ev2[1], c->stream2));
+    if (!same_inputs || !c->opt_async)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
 
     ibdg::SiteArgs sa;
     sa.panel = (const uint64_t *)c->panel.p;
@@ -775,9 +826,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.n_pairs = c->n_pairs;
     sa.af = (double *)c->af.p;
     sa.site_ll = (double *)c->site_ll.p;
-    ibdg::launch_site(sa, (unsigned)T, c->stream2);
-    HIP_TRY(c, hipEventRecord(c->ev2[2], c->stream2));
-    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
 
     bool use_pop = false;
     if (ld_mode) {
@@ -785,7 +833,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (c->opt_variant == 2 && !can)
             return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
                            "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
-        use_pop = can && c->opt_variant != 1;
+        use_pop = can && c->opt_variant != 1 && (c->opt_variant == 2 || c->pop_dense_enough);
     }
     c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     if (use_pop) {
@@ -857,7 +905,18 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
+
+    // stream2, queued after the critical path so that the --LD launches reach the device first
+    HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
+    if (recount) {
+        ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
+                               c->stream2);
+        c->counts_valid = true;
+        HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
+    }
+    ibdg::launch_site(sa, (unsigned)T, c->stream2);
+    HIP_TRY(c, hipEventRecord(E.s2[1], c->stream2));
 
     ibdg::WinArgs wa;
     wa.site_ll = sa.site_ll;
@@ -869,18 +928,15 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     wa.ld_mode = ld_mode ? 1 : 0;
     wa.win_ll = (double *)c->win_ll.p;
     ibdg::launch_window_prod(wa, (unsigned)T, c->stream2);
-    HIP_TRY(c, hipEventRecord(c->ev2[3], c->stream2));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev2[3], 0));
-    HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
+    c->last_s2 = E.s2[2];
+    c->s2_pending = true;
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-
-    float v;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[0], c->ev[4])); c->ms[0] = v;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[0], c->ev2[1])); c->ms[1] = recount ? v : 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[1], c->ev2[2])); c->ms[2] = v;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev[2], c->ev[3])); c->ms[3] = ld_mode ? v : 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&v, c->ev2[2], c->ev2[3])); c->ms[4] = v;
+    c->ev_head = ev_slot;
+    ++c->runs_done;
+    c->chain_ok = true;
+    if (!c->opt_async && quiesce(c))
+        return 1;
     c->n_targets = T;
     c->have_results = true;
 #if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
@@ -908,9 +964,9 @@ static int fetch(ibdg_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return 0;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (join_streams(c)) return 1;
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return quiesce(c);
 }
 
 int ibdg_get_site_af(ibdg_ctx *c, double *af)
@@ -942,11 +998,34 @@ int ibdg_get_alt_counts(ibdg_ctx *c, size_t first_row, size_t n, uint32_t *out)
     return fetch(c, out, (const char *)c->alt_count.p + first_row * 4, n * 4);
 }
 
-int ibdg_last_run_ms(const ibdg_ctx *c, float out[5])
+int ibdg_run_ms(ibdg_ctx *c, unsigned back, float out[5])
 {
     if (!c || !out) return 1;
-    for (int i = 0; i < 5; ++i) out[i] = c->ms[i];
+    if (back + 1 >= (unsigned)ibdg_ctx::EV_RING || (long)back >= c->runs_done)
+        return fail(c, "[::] ERROR in ibdg_run_ms: no timing kept for the run %u calls back", back);
+    const ibdg_ctx::EvSet &E = c->evs[(c->ev_head + ibdg_ctx::EV_RING - (int)back) % ibdg_ctx::EV_RING];
+    if (quiesce(c)) return 1;
+    float v, w;
+    HIP_TRY(c, hipEventElapsedTime(&v, E.start, E.ld_end));
+    HIP_TRY(c, hipEventElapsedTime(&w, E.start, E.s2[2]));
+    out[0] = v > w ? v : w;                  // the run ends when both streams are done
+    out[3] = E.ld ? v : 0.f;
+    out[1] = 0.f;
+    if (E.recount)
+        HIP_TRY(c, hipEventElapsedTime(&out[1], E.s2_start, E.s2[0]));
+    HIP_TRY(c, hipEventElapsedTime(&v, E.recount ? E.s2[0] : E.s2_start, E.s2[1])); out[2] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, E.s2[1], E.s2[2])); out[4] = v;
     return 0;
+}
+
+int ibdg_last_run_ms(ibdg_ctx *c, float out[5])
+{
+    if (!c || !out) return 1;
+    if (c->runs_done == 0) {
+        for (int i = 0; i < 5; ++i) out[i] = 0.f;
+        return 0;
+    }
+    return ibdg_run_ms(c, 0, out);
 }
 
 int ibdg_last_ld_variant(const ibdg_ctx *c) { return c ? c->last_variant : 0; }
@@ -955,6 +1034,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 {
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
+    if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");
         c->opt_cpw = value; return 0;
@@ -985,9 +1065,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 int ibdg_sync(ibdg_ctx *c)
 {
     if (!c) return 1;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return quiesce(c);
 }
 
 }  // extern "C"

@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
         o[3] = make_uint4(S.cov[6], S.cov[7], S.alt[2], S.alt[3]);
         o[4] = make_uint4(S.alt[4], S.alt[5], S.alt[6], S.alt[7]);
     }
-    if (i < a.n_win) {                       // thread i: the constants of window i
-        const uint32_t w = i;
+    if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w
+        const uint32_t w = i >> 3;
         uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
         const uint32_t s1 = a.wconst[w + 1].seg_begin;
-        for (uint32_t s = a.wconst[w].seg_begin; s < s1; ++s) {
+        for (uint32_t s = a.wconst[w].seg_begin + (i & 7); s < s1; s += 8) {    // a window has ~4-5 segments
             const Seg &S = a.segs[s];
             const uint2 at = tile_words(tt, S.tile);
 #pragma unroll
@@ -123,11 +123,20 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
                 a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
             }
         }
-        const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);    // mK(2) eK ct at seg_begin
-        uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * 12);
-        o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
-        o[1] = make_uint4(wcs[4], a0cov, a1cov, a0alt);
-        o[2] = make_uint4(a1alt, 0, 0, 0);
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {    // the 8 lanes of a window sit in one wave (8 | 64, i is 8-aligned)
+            a0cov += __shfl_xor(a0cov, m);
+            a1cov += __shfl_xor(a1cov, m);
+            a0alt += __shfl_xor(a0alt, m);
+            a1alt += __shfl_xor(a1alt, m);
+        }
+        if ((i & 7) == 0) {
+            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);    // mK(2) eK ct at seg_begin
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * 12);
+            o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
+            o[1] = make_uint4(wcs[4], a0cov, a1cov, a0alt);
+            o[2] = make_uint4(a1alt, 0, 0, 0);
+        }
     }
 }
 
@@ -544,25 +553,32 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 #endif
 }
 
-// Sum the per-chunk partials in ascending chunk order and take the background average
-// (src/ibdgem.c:751-752).
+// Sum the per-chunk partials of a window and take the background average (src/ibdgem.c:751-752).
+// One wave per window: lane c adds chunks c, c+64, .. (coalesced 16-byte loads), then the wave
+// sums its lanes in the fixed order of wave_sum_to_lane63 -- the same order whatever the launch.
 __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
 {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= a.n_win)
         return;
+    const unsigned lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
-    const double *p = a.partial + ((size_t)t * a.n_win + w) * a.n_chunks * 2;
+    const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks;
     double t0 = 0.0, t1 = 0.0;
-    for (uint32_t c = 0; c < a.n_chunks; ++c) {
-        t0 += p[2 * c];
-        t1 += p[2 * c + 1];
+    for (uint32_t c = lane; c < a.n_chunks; c += 64) {
+        const double2 v = p[c];
+        t0 += v.x;
+        t1 += v.y;
     }
-    const int nref = a.n_refpanel[t];
-    const double mK = a.wconst[w].mK;                 // mantissa of K' (its exponent went into every term)
-    double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
-    o[0] = (t0 * mK) / (double)nref;
-    o[1] = (t1 * mK) / (double)(nref * 4);
+    t0 = wave_sum_to_lane63(t0);
+    t1 = wave_sum_to_lane63(t1);
+    if (lane == 63) {
+        const int nref = a.n_refpanel[t];
+        const double mK = a.wconst[w].mK;             // mantissa of K' (its exponent went into every term)
+        double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
+        o[0] = (t0 * mK) / (double)nref;
+        o[1] = (t1 * mK) / (double)(nref * 4);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -579,7 +595,7 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
 {
     if (a.n_win == 0)
         return;
-    const uint32_t n = a.n_segs > a.n_win ? a.n_segs : a.n_win;
+    const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
     hipLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, a,
                        const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
 }
@@ -623,7 +639,7 @@ void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t s
 {
     if (a.n_win == 0)
         return;
-    hipLaunchKernelGGL(k_ld_finalize, dim3((a.n_win + 255) / 256, n_targets), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_ld_finalize, dim3((a.n_win + 3) / 4, n_targets), dim3(256), 0, st, a);
 }
 
 }  // namespace ibdg

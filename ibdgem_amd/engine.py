@@ -35,6 +35,7 @@ SYMBOLS = {
     "ibdg_get_window_ll": (C.c_int, [_P, C.c_size_t, _P]),
     "ibdg_get_alt_counts": (C.c_int, [_P, C.c_size_t, C.c_size_t, _P]),
     "ibdg_last_run_ms": (C.c_int, [_P, _P]),
+    "ibdg_run_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_last_ld_variant": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "ibdg_sync": (C.c_int, [_P]),
@@ -192,6 +193,12 @@ class Engine:
     def last_run_ms(self):
         out = (C.c_float * 5)()
         self._chk(self.lib.ibdg_last_run_ms(self.ctx, out))
+        return dict(total=out[0], alt_count=out[1], site=out[2], ld=out[3], window=out[4])
+
+    def run_ms(self, back):
+        """Device times of the run `back` calls ago (0 = last); waits for the stream."""
+        out = (C.c_float * 5)()
+        self._chk(self.lib.ibdg_run_ms(self.ctx, back, out))
         return dict(total=out[0], alt_count=out[1], site=out[2], ld=out[3], window=out[4])
 
     def last_ld_variant(self):

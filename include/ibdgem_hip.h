@@ -142,14 +142,22 @@ int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out
  * window-product kernel (ms).  The per-site and window-product kernels run on
  * a second stream beside the --LD kernels, so the parts overlap and need not
  * add up to the total. */
-int ibdg_last_run_ms(const ibdg_ctx *ctx, float out[5]);
+int ibdg_last_run_ms(ibdg_ctx *ctx, float out[5]);
+
+/* The same for the run `back` calls ago (0 = the last one); the engine keeps the
+ * events of its last 32 runs.  Waits for the engine's stream first, so it is the
+ * way to time runs issued with the "async" option after ibdg_sync. */
+int ibdg_run_ms(ibdg_ctx *ctx, unsigned back, float out[5]);
 
 /* Which --LD kernel the last ibdg_run used: 0 none (non-LD), 1 the strict
  * kernel (sequential fp64 products in the reference's order), 2 the
  * exponent-counting kernel (same values to ~1e-14). */
 int ibdg_last_ld_variant(const ibdg_ctx *ctx);
 
-/* Options: "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
+/* Options: "async" (0/1: ibdg_run returns as soon as its kernels are queued;
+ * ibdg_sync, ibdg_run_ms and every ibdg_get_* wait for them -- lets a caller
+ * queue one run per comparison individual without a host round trip between
+ * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),

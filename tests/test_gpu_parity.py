@@ -257,6 +257,33 @@ def test_counting_inside_run_and_determinism():
             assert_bits(a, b, "run-to-run / option determinism")
 
 
+def test_async_runs_queue_in_order():
+    """"async": ibdg_run only enqueues; results and per-run timings are those of the synchronous calls."""
+    N, L = 300, 2500
+    alle, nr, na = synth(33, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        want = {}
+        for t in (5, 6, 9):
+            eng.run([t], ld=True)
+            want[t] = (eng.site_ll(0), eng.window_ll(0))
+        eng.set_option("async", 1)
+        for t in (5, 6, 9, 6):                       # four runs queued without a host wait between them
+            eng.run([t], ld=True)
+        assert_bits(eng.window_ll(0), want[6][1], "async window")      # getters wait for the stream
+        assert_bits(eng.site_ll(0), want[6][0], "async site")
+        for back in range(4):
+            ms = eng.run_ms(back)
+            assert ms["ld"] > 0 and ms["total"] >= ms["ld"]
+        eng.sync()
+        eng.set_option("async", 0)
+        eng.run([9], ld=True)
+        assert_bits(eng.window_ll(0), want[9][1], "back to synchronous")
+        with pytest.raises(E.EngineError):
+            eng.run_ms(32)
+
+
 def test_error_behaviour():
     alle, nr, na = synth(41, 50, 10)
     with E.Engine() as eng:
@@ -411,12 +438,14 @@ def test_sparse_pileup_rows_far_apart(oracle):
     alle, nr, na = synth(91, Lp, N)
     keep = np.sort(rng.choice(Lp, size=900, replace=False))
     nrk, nak = np.maximum(nr[keep], 1), na[keep]
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         with E.Engine() as eng:
             eng.set_option("ld_variant", variant)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nrk, nak, 100)
             eng.run([7], ld=True)
+            # few covered rows among those spanned: the automatic choice is the strict kernel
+            assert eng.last_ld_variant() == (2 if variant == 2 else 1)
             res = oracle.compare(alle[keep], nrk, nak, 7, window=100, ld=True)
             assert_bits(eng.site_ll(0), res["site"], "site")
             assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"sparse variant={variant}")
