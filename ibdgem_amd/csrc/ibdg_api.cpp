@@ -78,7 +78,10 @@ struct ibdg_ctx {
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
     DevBuf t32, segs, wconst, wtarget, twords, pow1, pow2, partial;
-    uint32_t wpg = 0, max_seg = 0;     // windows per workgroup run and its largest segment count
+    uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
+    uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
+    DevBuf runs;
+    int n_cu = 256;
     int tab_in_lds = 0;
     int seg_ring = 4;                  // ring depth the segment control words were built for
     uint32_t n_pairs = 0, n_segs = 0, ct_max = 0;
@@ -109,6 +112,7 @@ struct ibdg_ctx {
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
+    long opt_guided = 1;   // shrink the runs towards the end of the grid
     long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
@@ -407,30 +411,50 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
     wc[c->n_win].seg_begin = (uint32_t)segs.size();
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     {
-        // few windows (a shard of a chromosome, a small region): shorter runs, so that the grid still
-        // holds several rounds of workgroups for every CU and the last round is not mostly idle
         uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
-        {
+        if (!c->opt_guided && !c->opt_wpg_fixed) {
+            // uniform runs and few windows (a shard of a chromosome, a small region): shorter runs, so that
+            // the grid still holds several rounds of workgroups for every CU
             const uint64_t rows_of_blocks = (c->n_chunks + 7) / 8;
-            const uint64_t want_blocks = 256ull * 2 * 5;           // CUs x resident blocks x rounds
+            const uint64_t want_blocks = (uint64_t)c->n_cu * 2 * 5;          // CUs x resident blocks x rounds
             const uint64_t g_fit = std::max<uint64_t>(1, (uint64_t)c->n_win * rows_of_blocks / want_blocks);
-            if (!c->opt_wpg_fixed && g_fit < g)
+            if (g_fit < g)
                 g = (uint32_t)g_fit;
         }
+        // Runs of g windows, except towards the end of the grid, where they shrink (guided
+        // self-scheduling: remaining windows / workgroups in flight): workgroups are handed out in
+        // blockIdx order, so the last ones to start are short and the CUs run dry together instead
+        // of waiting for one last full-length run.
+        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * 2 / ((c->n_chunks + 7) / 8)));
+        std::vector<uint32_t> runs;
         for (;; g = (g + 1) / 2) {
             uint32_t mx = 0;
-            for (uint32_t w = 0; w < c->n_win; w += g)
-                mx = std::max(mx, wc[std::min(w + g, c->n_win)].seg_begin - wc[w].seg_begin);
+            runs.clear();
+            for (uint32_t w = 0; w < c->n_win;) {
+                runs.push_back(w);
+                uint32_t len = g;
+                if (c->opt_guided)
+                    len = std::min(g, std::max<uint32_t>(1, (c->n_win - w + in_flight - 1) / in_flight));
+                const uint32_t wn = std::min(w + len, c->n_win);
+                mx = std::max(mx, wc[wn].seg_begin - wc[w].seg_begin);
+                w = wn;
+            }
+            runs.push_back(c->n_win);
             if ((size_t)mx * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1) {
                 c->wpg = g;
                 c->max_seg = mx;
                 break;
             }
         }
+        c->n_runs = (uint32_t)runs.size() - 1;
+        if (ensure(c, c->runs, runs.size() * 4))
+            return 1;
+        HIP_TRY(c, hipMemcpyAsync(c->runs.p, runs.data(), runs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));        // `runs` is a local
         // per-segment control word (see ibdg::Seg::flags): needs the run structure chosen above
         const uint32_t NS = (uint32_t)c->opt_ring;
-        for (uint32_t w = 0; w < c->n_win; w += c->wpg) {
-            const uint32_t s0 = wc[w].seg_begin, s1 = wc[std::min(w + c->wpg, c->n_win)].seg_begin;
+        for (uint32_t r = 0; r < c->n_runs; ++r) {
+            const uint32_t s0 = wc[runs[r]].seg_begin, s1 = wc[runs[r + 1]].seg_begin;
             if (s0 == s1)
                 continue;
             const uint32_t q0 = segs[s0].tile >> 1;
@@ -555,6 +579,11 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
         for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
     }
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
+            c->n_cu = n_cu;
+    }
     const size_t d = (size_t)max_cov + 1;
     c->lut_h.resize(d * d * 3);
     build_pdg_table(epsilon, max_cov, c->lut_h.data());
@@ -584,7 +613,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->wconst, &c->wtarget, &c->twords, &c->pow1, &c->pow2, &c->partial})
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &E : c->evs)
         for (hipEvent_t ev : {E.start_own, E.ld_end, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
@@ -852,6 +881,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
         pa.win_per_group = c->wpg;
+        pa.run_begin = (const uint32_t *)c->runs.p;
+        pa.n_runs = c->n_runs;
+        pa.n_cgroups = (c->n_chunks + 7) / 8;
         pa.wc_ready = (const uint32_t *)c->wtarget.p;
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
@@ -866,7 +898,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
 #if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
         pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;   // ablation builds only
         if (getenv("IBDG_STAMPS")) {
-            const size_t n_w = (size_t)((c->n_win + c->wpg - 1) / c->wpg) * ((c->n_chunks + 7) / 8) * T * 8;
+            const size_t n_w = (size_t)c->n_runs * ((c->n_chunks + 7) / 8) * T * 8;
             static DevBuf stamp_buf;
             if (ensure(c, stamp_buf, n_w * 64)) return 1;
             HIP_TRY(c, hipMemsetAsync(stamp_buf.p, 0, n_w * 64, c->stream));
@@ -1034,6 +1066,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 {
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
+    if (!strcmp(name, "guided_runs")) { c->opt_guided = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");

@@ -92,7 +92,10 @@ struct PopArgs {
     const uint32_t *rec_ready;  // [T][n_segs][20] LDS-ready segment records (written by k_win_target)
     const WinConst *wconst;     // [n_win + 1] (the extra entry carries seg_begin = n_segs)
     uint32_t n_win;
-    uint32_t win_per_group;
+    uint32_t win_per_group;     // most windows in one run (LDS sizing)
+    const uint32_t *run_begin;  // [n_runs + 1] first window of every run; workgroup = (run, group of 8 chunks)
+    uint32_t n_runs;
+    uint32_t n_cgroups;         // groups of 8 chunks
     const uint32_t *wc_ready;   // [T][n_win][12] LDS-ready window constants (written by k_win_target)
     const PowEntry *pow_1me;    // [(max cov_total)+1]
     const PowEntry *pow_eps;

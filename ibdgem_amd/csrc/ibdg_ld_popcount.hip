@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                                                      const uint32_t *__restrict__ wc_ready,
                                                      const uint4 *__restrict__ pow_1me,
                                                      const uint4 *__restrict__ pow_eps,
+                                                     const uint32_t *__restrict__ run_begin,
                                                      PopArgs a)
 {
     constexpr int FC = 3, FA = 2;      // weight bit-planes with counters of their own (cov, alt)
@@ -312,8 +313,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     const unsigned t = blockIdx.z;
-    const uint32_t w0 = blockIdx.x * a.win_per_group;
-    const uint32_t w1 = min(w0 + a.win_per_group, a.n_win);
+    // workgroups of one run are neighbours in blockIdx order (and so in dispatch order): the
+    // runs at the end of the grid are the short ones (host: guided run lengths)
+    const uint32_t run = blockIdx.x / a.n_cgroups, cgroup = blockIdx.x - run * a.n_cgroups;
+    const uint32_t w0 = run_begin[run], w1 = run_begin[run + 1];
     const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
     const uint32_t nseg = seg1 - seg0;
     if (nseg == 0)
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
     // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
     // two start-up latencies of a workgroup overlap instead of adding up.
-    const unsigned c = blockIdx.y * 8 + wave;
+    const unsigned c = cgroup * 8 + wave;
     const bool has_chunk = c < a.n_chunks;
     char *ring = ring0 + (size_t)wave * NS * 1024;
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 #if IBDG_TIMING_EXPERIMENT
     if (a.stamps && lane == 0) {
         const unsigned long long te = stamp();
-        unsigned long long *o = a.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        unsigned long long *o = a.stamps + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 8;
         o[0] = t_stage; o[1] = t_dma; o[2] = t_fetch; o[3] = t_count; o[4] = t_fin; o[5] = te - ts0; o[6] = nseg; o[7] = w1 - w0;
     }
 #endif
@@ -619,7 +622,7 @@ static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
                             (int)lds) != hipSuccess)
         return 1;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
-                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a);
+                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
     return 0;
 }
 
@@ -629,7 +632,7 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
         return 0;
     if (planes < 1 || planes > 8)
         return 1;
-    dim3 grid((a.n_win + a.win_per_group - 1) / a.win_per_group, (a.n_chunks + 7) / 8, n_targets);
+    dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
     if (a.ring_slots == 4)
         return a.tab_in_lds ? launch_pop<4, true>(a, grid, st) : launch_pop<4, false>(a, grid, st);
     return a.tab_in_lds ? launch_pop<8, true>(a, grid, st) : launch_pop<8, false>(a, grid, st);

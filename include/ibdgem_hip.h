@@ -161,8 +161,9 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * so the timed region covers it); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
- * "waves_per_block" (strict kernel), "windows_per_wave" (exponent-counting
- * kernel).  Returns non-zero for an unknown name or a value out of range. */
+ * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
+ * "ring_slots", "record_lds_bytes" (exponent-counting kernel; set before
+ * ibdg_upload_sites).  Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
 
 /* Block until all work queued on the engine's stream is done. */

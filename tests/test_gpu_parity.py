@@ -389,10 +389,11 @@ def test_windows_per_wave_option(oracle):
     N, L = 130, 2000
     alle, nr, na = synth(71, L, N)
     ref = None
-    for wpw in (1, 2, 7, 32, 1000):
+    for wpw, guided in ((1, 1), (2, 0), (7, 1), (7, 0), (32, 1), (1000, 0), (1000, 1)):
         with E.Engine() as eng:
             eng.set_option("ld_variant", 2)
             eng.set_option("windows_per_wave", wpw)
+            eng.set_option("guided_runs", guided)     # runs shrinking towards the end of the grid, or uniform
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, 50)
             eng.run([2], ld=True)
@@ -402,7 +403,7 @@ def test_windows_per_wave_option(oracle):
             res = oracle.compare(alle, nr, na, 2, window=50, ld=True)
             assert_ld_close(got[:, :2], res["win"][:, :2], "wpw=1")
         else:
-            assert_bits(got, ref, f"windows_per_wave={wpw}")
+            assert_bits(got, ref, f"windows_per_wave={wpw} guided={guided}")
 
 
 @pytest.mark.parametrize("ring,recbytes,wpw", [(8, 12288, 16), (4, 1024, 16), (8, 1024, 1), (4, 90000, 256)])
