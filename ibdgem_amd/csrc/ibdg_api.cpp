@@ -828,17 +828,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     E.recount = recount;
     E.ld = ld_mode != 0;
     // Two streams: the per-site kernel and the window products (memory-bound, few waves) run on
-    // stream2 beside the --LD kernels (VALU-bound) on the main stream.  stream2 only has to wait
-    // for the main stream when the inputs were just replaced there; the main stream waits for
-    // stream2 when somebody needs the results (join_streams), not once per run.
+    // stream2 beside the --LD kernels (VALU-bound) on the main stream.  stream2 starts a run when
+    // the main stream does (a wait in stream2's queue costs the main stream nothing; it also orders
+    // stream2 behind an upload of new targets); the main stream waits for stream2 when somebody
+    // needs the results (join_streams), not once per run.
     if (c->chain_ok && c->opt_async) {
         E.start = c->evs[c->ev_head].ld_end;       // back-to-back runs: the previous end is this start
     } else {
         HIP_TRY(c, hipEventRecord(E.start_own, c->stream));
         E.start = E.start_own;
     }
-    if (!same_inputs || !c->opt_async)
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
 
     ibdg::SiteArgs sa;
     sa.panel = (const uint64_t *)c->panel.p;
