@@ -29,6 +29,7 @@
 #include <limits.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,6 +38,7 @@
 #include <unistd.h>
 
 #include "../../include/ibdgem_hip.h"
+#include "ingest.h"
 #include "lineio.h"
 #include "pileup.h"
 
@@ -47,12 +49,17 @@ static int opt_window = 100;
 static const char *opt_sq = "UNKWN";
 static int opt_ld = 0, opt_plan = 0, in_impute = 0, in_vcf = 0;
 static int has_S = 0, has_s = 0, has_B = 0, has_A = 0, has_p = 0, has_v = 0, has_D = 0;
+static int opt_threads = 0;
+static const char *cache_fn = NULL, *dump_panel_fn = NULL;
 
 static struct option longopts[] = {
     {"LD", no_argument, &opt_ld, 1},
     {"plan", no_argument, &opt_plan, 1},
     {"rand-stream", required_argument, 0, 1000},
     {"devices", required_argument, 0, 1001},
+    {"threads", required_argument, 0, 1002},
+    {"panel-cache", required_argument, 0, 1003},
+    {"dump-panel", required_argument, 0, 1004},
     {"vcf", required_argument, 0, 'V'},
     {"hap", required_argument, 0, 'H'},
     {"legend", required_argument, 0, 'L'},
@@ -104,6 +111,10 @@ static void usage(int code)
           "  --devices LIST            GPUs to spread the windows of each comparison over, e.g. 0,1,2,3\n"
           "                            (default 0); every GPU holds the whole panel, the windows are cut\n"
           "                            into contiguous ranges, one per GPU, and gathered on the host\n"
+          "  --threads INT             host threads for reading the .hap file and writing the output files\n"
+          "                            (default: the CPUs available to the process, at most 16)\n"
+          "  --panel-cache FILE        keep the bit-packed panel of the .hap file in FILE and reuse it\n"
+          "                            while the .hap file is unchanged\n"
           "  --plan                    print the filtered rows and windows only (no device needed)\n"
           "  -h/--help\n\n"
           "Outputs <out>/<pileup-name>.<individual>.tab.txt with columns\n"
@@ -333,31 +344,35 @@ static uint32_t arena_add(const char *s)
     return (uint32_t)(arena_len - l);
 }
 
-static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_ids)
+/* The legend rows (small text) are parsed on a thread of their own while the team of ingest.c
+ * packs the .hap rows; both files advance together in the reference (src/ibdgem.c:573-578), so the
+ * panel has as many rows as the shorter of the two. */
+typedef struct {
+    const char *fn;
+    size_t n;
+    int rc;
+} legend_job;
+
+static void *read_legend(void *arg)
 {
-    line_src *hap = ls_open(hap_fn), *leg = ls_open(legend_fn);
-    if (!hap || !leg) {
-        fprintf(stderr, "[::] ERROR parsing hap/legend/indv data; make sure inputs are valid.\n");
-        return 1;
+    legend_job *j = arg;
+    line_src *leg = ls_open(j->fn);
+    if (!leg) {
+        j->rc = 1;
+        return NULL;
     }
-    row_words = ibdg_row_words(n_ids);
-    size_t cap = 0;
+    size_t cap = 0, n = 0;
     ls_next(leg, NULL);                                   /* legend header (src/ibdgem.c:555) */
     for (;;) {
-        char *h = ls_next(hap, NULL);
-        if (!h)
-            break;
-        if (n_rows == cap) {
-            cap = cap ? cap * 2 : (1 << 16);
-            rows = realloc(rows, cap * sizeof *rows);
-            packed = realloc(packed, cap * row_words * 8);
-        }
-        row_t *r = &rows[n_rows];
-        memset(r, 0, sizeof *r);
-        r->hap_ok = ibdg_pack_hap_text(h, n_ids, packed + n_rows * row_words) == 0;
-        char *l = ls_next(leg, NULL);                     /* both files advance together (:573-578) */
+        char *l = ls_next(leg, NULL);
         if (!l)
             break;
+        if (n == cap) {
+            cap = cap ? cap * 2 : (1 << 16);
+            rows = realloc(rows, cap * sizeof *rows);
+        }
+        row_t *r = &rows[n];
+        memset(r, 0, sizeof *r);
         char id[129], ref[129], alt[129];
         if (sscanf(l, "%128s %lu %128s %128s", id, &r->pos, ref, alt) == 4) {
             r->legend_ok = 1;
@@ -365,10 +380,59 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
             r->ref_off = arena_add(ref);
             r->alt_off = arena_add(alt);
         }
-        n_rows++;
+        n++;
     }
-    ls_close(hap);
     ls_close(leg);
+    j->n = n;
+    return NULL;
+}
+
+static int default_threads(void)
+{
+    cpu_set_t set;
+    int n = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+        n = CPU_COUNT(&set);
+    return n < 1 ? 1 : n > 16 ? 16 : n;
+}
+
+static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_ids)
+{
+    row_words = ibdg_row_words(n_ids);
+    legend_job lj = {legend_fn, 0, 0};
+    pthread_t lt;
+    const int threaded = pthread_create(&lt, NULL, read_legend, &lj) == 0;
+    if (!threaded)
+        read_legend(&lj);
+    uint8_t *ok = NULL;
+    size_t n_hap = 0;
+    int rc = 1;
+    if (cache_fn)
+        rc = ingest_cache_load(cache_fn, hap_fn, n_ids, &packed, &ok, &n_hap);
+    if (rc) {
+        rc = ingest_hap(hap_fn, n_ids, opt_threads > 0 ? opt_threads : default_threads(), &packed, &ok, &n_hap);
+        if (!rc && cache_fn && ingest_cache_store(cache_fn, hap_fn, n_ids, packed, ok, n_hap))
+            fprintf(stderr, "Could not write the panel cache %s (continuing without it).\n", cache_fn);
+    }
+    if (threaded)
+        pthread_join(lt, NULL);
+    if (rc || lj.rc) {
+        fprintf(stderr, "[::] ERROR parsing hap/legend/indv data; make sure inputs are valid.\n");
+        return 1;
+    }
+    n_rows = n_hap < lj.n ? n_hap : lj.n;
+    for (size_t r = 0; r < n_rows; ++r)
+        rows[r].hap_ok = ok[r];
+    free(ok);
+    if (dump_panel_fn) {
+        FILE *f = fopen(dump_panel_fn, "wb");
+        if (!f)
+            return 1;
+        for (size_t r = 0; r < n_rows; ++r)
+            fputc(rows[r].hap_ok, f);
+        fwrite(packed, 8, n_rows * row_words, f);
+        fclose(f);
+    }
     return 0;
 }
 
@@ -642,6 +706,9 @@ int main(int argc, char **argv)
         case 'v': has_v = 1; break;
         case 'h': usage(0); break;
         case 1001: devices_arg = optarg; break;
+        case 1002: opt_threads = atoi(optarg); break;
+        case 1003: cache_fn = optarg; break;
+        case 1004: dump_panel_fn = optarg; break;   /* test hook: the packed rows + clean flags as a binary file */
         case 1000:                                  /* test hook: the first N values of the read-thinning stream */
             for (long i = atol(optarg); i > 0; --i)
                 printf("%d\n", glibc_rand());

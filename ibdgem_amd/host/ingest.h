@@ -1,0 +1,23 @@
+/* ingest.h -- block-wise, multi-threaded IMPUTE .hap reader and the packed-panel cache file.
+ * Replaces, for the whole file at once, what the reference does per row and per comparison
+ * individual: get_line_FS on the .hap file (src/ibdgem.c:573-574, src/file-io.c:20-27) and the
+ * character walk of find_f_impute (src/ibd-parse.c:91-99). */
+#ifndef IBDG_INGEST_H
+#define IBDG_INGEST_H
+#include <stddef.h>
+#include <stdint.h>
+
+/* Read the rows of `fn` (plain text: mapped, every thread packs a byte range of its own; gzip if
+ * the name ends in ".gz": streamed in blocks whose rows the team packs) into the
+ * packed layout of include/ibdgem_hip.h.  ok[r] = 1 when row r has >= 4*n_ids-1 characters and
+ * only '0'/'1' at its allele offsets (ibdg_pack_hap_text returning 0); other rows are all zero.
+ * The arrays are malloc'ed; returns 0, or 1 on I/O / memory failure. */
+int ingest_hap(const char *fn, unsigned n_ids, int threads, uint64_t **packed, uint8_t **ok, size_t *n_rows);
+
+/* Cache file = header (panel width, row count, size and mtime of the .hap file it was made from),
+ * ok flags, packed rows.  load returns 1 when the file is missing or was made from another input. */
+int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed, uint8_t **ok,
+                      size_t *n_rows);
+int ingest_cache_store(const char *cache_fn, const char *hap_fn, unsigned n_ids, const uint64_t *packed,
+                       const uint8_t *ok, size_t n_rows);
+#endif
