@@ -602,6 +602,118 @@ static void print_ll(FILE *fp, double v, char sep)
     fputc(sep, fp);
 }
 
+/* ---- per-site rows of the tab file, formatted by a team of threads ---------------------------
+ * The reference prints one fprintf per row (src/ibdgem.c:731-733): 4M rows x 14 columns per
+ * comparison individual.  Here the rows are cut into contiguous ranges, every thread formats its
+ * range into a buffer of its own with the same conversions (%lf, %e, %u, %lu through snprintf, so
+ * the text is what printf would have written), and the buffers are written in order. */
+static int fmt_ll(char *dst, double v, char sep)
+{
+    int n = isnan(v) ? sprintf(dst, "-nan") : sprintf(dst, "%e", v);   /* "-nan": x86 printf for 0/0 */
+    dst[n] = sep;
+    return n + 1;
+}
+
+/* a row that passed the target-independent part of the filter chain */
+typedef struct { uint32_t row; uint32_t pu; uint8_t n_ref, n_alt; double f; int f_is_override; } cand_t;
+typedef struct {
+    /* what a row is made of */
+    const cand_t *cand;
+    const uint32_t *s_cand;
+    const pileup_t *pu;
+    const double *site_af, *site_ll;
+    const uint8_t *s_nr, *s_na;
+    unsigned tgt;
+    int plan;
+    /* this thread's rows and its text */
+    size_t a, b;
+    char *buf;
+    size_t len, cap;
+    int failed;
+} fmt_job;
+
+static void *fmt_rows(void *arg)
+{
+    fmt_job *j = arg;
+    j->failed = 0;
+    for (size_t i = j->a; i < j->b; ++i) {
+        const cand_t *c = &j->cand[j->s_cand[i]];
+        const row_t *R = &rows[c->row];
+        const pu_line *pl = &j->pu->lines[c->pu];
+        const double f = j->plan ? c->f : j->site_af[i];
+        const char *chr = j->pu->chr_names[pl->chr], *id = arena + R->id_off, *ref = arena + R->ref_off,
+                   *alt = arena + R->alt_off;
+        /* strings + 3 x %lu/%lf (<= 330 chars for the largest double) + 5 x %u + 3 x %e + separators */
+        const size_t room = strlen(chr) + strlen(id) + strlen(ref) + strlen(alt) + 512;
+        if (j->len + room > j->cap) {
+            size_t nc = j->cap ? j->cap * 2 : ((size_t)1 << 20);
+            while (j->len + room > nc)
+                nc *= 2;
+            char *nb = realloc(j->buf, nc);
+            if (!nb) {
+                j->failed = 1;
+                return NULL;
+            }
+            j->buf = nb;
+            j->cap = nc;
+        }
+        char *d = j->buf + j->len;
+        d += sprintf(d, "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u", chr, id, R->pos, ref, alt, f, (unsigned)pl->cov,
+                     (unsigned)j->s_nr[i], (unsigned)j->s_na[i], row_allele(c->row, j->tgt, 0),
+                     row_allele(c->row, j->tgt, 1));
+        if (j->plan) {
+            *d++ = '\n';
+        } else {
+            *d++ = '\t';
+            d += fmt_ll(d, j->site_ll[3 * i], '\t');
+            d += fmt_ll(d, j->site_ll[3 * i + 1], '\t');
+            d += fmt_ll(d, j->site_ll[3 * i + 2], '\n');
+        }
+        j->len = (size_t)(d - j->buf);
+    }
+    return NULL;
+}
+
+static int write_rows_parallel(FILE *tab, fmt_job proto, size_t n, int threads)
+{
+    const size_t batch = (size_t)1 << 18;              /* rows per round: bounds the text held in memory */
+    fmt_job jobs[64];
+    pthread_t tid[64];
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = proto;
+        jobs[t].buf = NULL;
+        jobs[t].cap = 0;
+    }
+    int rc = 0;
+    for (size_t r0 = 0; r0 < n && !rc; r0 += batch) {
+        const size_t r1 = r0 + batch < n ? r0 + batch : n, m = r1 - r0;
+        const int team = m < 4096 ? 1 : threads;
+        int started[64] = {0};
+        for (int t = 0; t < team; ++t) {
+            jobs[t].a = r0 + m * (size_t)t / (size_t)team;
+            jobs[t].b = r0 + m * (size_t)(t + 1) / (size_t)team;
+            jobs[t].len = 0;
+        }
+        for (int t = 0; t + 1 < team; ++t)
+            started[t] = pthread_create(&tid[t], NULL, fmt_rows, &jobs[t]) == 0;
+        for (int t = 0; t < team; ++t)
+            if (!started[t])
+                fmt_rows(&jobs[t]);
+        for (int t = 0; t + 1 < team; ++t)
+            if (started[t])
+                pthread_join(tid[t], NULL);
+        for (int t = 0; t < team; ++t) {
+            if (jobs[t].failed || fwrite(jobs[t].buf, 1, jobs[t].len, tab) != jobs[t].len)
+                rc = 1;
+        }
+    }
+    for (int t = 0; t < threads; ++t)
+        free(jobs[t].buf);
+    return rc;
+}
+
 /* ---- one comparison spread over several GPUs (window ranges, host-side gather) ------------ */
 typedef struct {
     ibdg_ctx *eng;
@@ -847,7 +959,6 @@ int main(int argc, char **argv)
     }
 
     /* ---- target-independent part of the row filter chain (:589-626) ------------------- */
-    typedef struct { uint32_t row; uint32_t pu; uint8_t n_ref, n_alt; double f; int f_is_override; } cand_t;
     cand_t *cand = malloc((n_rows ? n_rows : 1) * sizeof *cand);
     uint8_t *row_fate = calloc(n_rows ? n_rows : 1, 1);   /* 0 skip-before-v, 1 candidate, 2 skipped after the -v test */
     size_t n_cand = 0;
@@ -1000,21 +1111,21 @@ int main(int argc, char **argv)
         fprintf(tab, "# CHR\trsID\tPOS\tREF\tALT\tAF\tDP\tSQ_NREF\tSQ_NALT\tGT_A0\tGT_A1\tLIBD0\tLIBD1\tLIBD2\n");
         if (!opt_plan)
             fprintf(sum, "# SEGMENT\tSTART\tEND\tLIBD0\tLIBD1\tLIBD2\tNUM_SITES\n");
-        for (size_t i = 0; i < n; ++i) {
-            const cand_t *c = &cand[s_cand[i]];
-            const row_t *R = &rows[c->row];
-            const pu_line *pl = &pu->lines[c->pu];
-            const double f = opt_plan ? c->f : site_af[i];
-            fprintf(tab, "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u", pu->chr_names[pl->chr], arena + R->id_off, R->pos,
-                    arena + R->ref_off, arena + R->alt_off, f, (unsigned)pl->cov, (unsigned)s_nr[i], (unsigned)s_na[i],
-                    row_allele(c->row, tgt, 0), row_allele(c->row, tgt, 1));
-            if (opt_plan) {
-                fputc('\n', tab);
-            } else {
-                fputc('\t', tab);
-                print_ll(tab, site_ll[3 * i], '\t');
-                print_ll(tab, site_ll[3 * i + 1], '\t');
-                print_ll(tab, site_ll[3 * i + 2], '\n');
+        {
+            fmt_job proto;
+            memset(&proto, 0, sizeof proto);
+            proto.cand = cand;
+            proto.s_cand = s_cand;
+            proto.pu = pu;
+            proto.site_af = site_af;
+            proto.site_ll = site_ll;
+            proto.s_nr = s_nr;
+            proto.s_na = s_na;
+            proto.tgt = tgt;
+            proto.plan = opt_plan;
+            if (write_rows_parallel(tab, proto, n, opt_threads > 0 ? opt_threads : default_threads())) {
+                fprintf(stderr, "[::] ERROR writing the per-site rows of %s.\n", tname);
+                return 1;
             }
         }
         for (size_t w = 0; w < n_win; ++w) {

@@ -148,3 +148,16 @@ def test_panel_cache_round_trip_and_invalidation(tmp_path):
     res = subprocess.run([_exe(), "-H", hap, "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind0", "--plan",
                           "--panel-cache", cache], cwd=tmp_path, capture_output=True, text=True)
     assert res.returncode == 0
+
+
+def test_row_formatter_output_does_not_depend_on_the_thread_count(tmp_path):
+    """Output formatter (§8(f) rank 2): the per-site rows are formatted by a team of threads into
+    buffers written in order -- the text is the same for any team size (here: the `--plan` rows;
+    the full files are compared byte for byte with the reference's in test_host_cli.py on a GPU)."""
+    N, L = 12, 30000
+    hap, alle, ok = write_inputs(str(tmp_path), N, L, seed=31, mutate=False)
+    with open(os.path.join(tmp_path, "p.pileup"), "w") as fh:
+        for i in range(L):
+            fh.write(f"chr1\t{100 + 10 * i}\tN\t3\tAGA\tIII\t]]]\n")
+    outs = [run_dump(str(tmp_path), hap, th)[1] for th in (1, 5, 16)]
+    assert outs[0].count("\n") > L and outs[0] == outs[1] == outs[2]

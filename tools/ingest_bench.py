@@ -73,4 +73,21 @@ if os.path.exists(ref):
     os.makedirs(o, exist_ok=True)
     dt = timed([ref, *base, "-O", o])
     out["reference_nonld_one_individual"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
+# end to end on a device (text in -> output files): ingest + engine + formatter, --LD, one individual
+if os.path.exists("/dev/kfd"):
+    out["end_to_end_LD"] = {}
+    for th in (1, 16):
+        o = os.path.join(work, f"out{th}")
+        os.makedirs(o, exist_ok=True)
+        dt = timed([exe, *base, "--LD", "-O", o, "--threads", str(th)])
+        out["end_to_end_LD"][f"threads_{th}"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
+    if os.path.exists(ref):
+        o = os.path.join(work, "ref_out_ld")
+        os.makedirs(o, exist_ok=True)
+        dt = timed([ref, *base, "--LD", "-O", o])
+        out["end_to_end_LD"]["reference"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
+        same = all(open(os.path.join(o, f)).read().split("\n", 1)[1] ==
+                   open(os.path.join(work, "out16", f)).read().split("\n", 1)[1]
+                   for f in ("UNKWN.ind7.tab.txt", "UNKWN.ind7.summary.txt"))
+        out["end_to_end_LD"]["files_identical_to_reference_after_line_1"] = same
 print(json.dumps(out))
