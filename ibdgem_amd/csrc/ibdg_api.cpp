@@ -77,7 +77,7 @@ struct ibdg_ctx {
     std::vector<uint32_t> cov_site_h;
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
-    DevBuf t32, segs, wconst, wtarget, twords, pow1, pow2, partial;
+    DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, partial;
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
     DevBuf runs;
@@ -112,6 +112,7 @@ struct ibdg_ctx {
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
+    long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
     long opt_guided = 1;   // shrink the runs towards the end of the grid
     long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
@@ -480,7 +481,7 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         }
         c->seg_ring = (int)NS;
         c->tab_in_lds = (size_t)(ct_max + 1) * 32 <= 24 * 1024;
-        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, c->seg_ring) > 150 * 1024)
+        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, c->seg_ring, 0) > 150 * 1024)
             return 0;                      // a single window with thousands of tiles: strict kernel
     }
     wc[c->n_win].mK = 0;
@@ -613,7 +614,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->pow1, &c->pow2, &c->partial})
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &E : c->evs)
         for (hipEvent_t ev : {E.start_own, E.ld_end, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
@@ -866,8 +867,16 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
     c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     if (use_pop) {
-        if (ensure(c, c->wtarget, T * (size_t)c->n_win * 48) ||
-            ensure(c, c->twords, T * (size_t)c->n_segs * 80) ||
+        // Comparison individuals in groups of MT share one workgroup (and the counts that do not
+        // depend on them) in k_ld_popcount_mt; what is left over goes one per workgroup.
+        const size_t MT = (size_t)ibdg::ld_popcount_mt_width();
+        const bool mt_fits = ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring,
+                                                         1) <= 150 * 1024;
+        const size_t n_grp = (c->opt_multi_target && mt_fits && T >= MT) ? T / MT : 0, T_one = T - n_grp * MT;
+        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 48) ||
+            ensure(c, c->twords, T_one * (size_t)c->n_segs * 80) ||
+            ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
+            ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
             return 1;
         ibdg::PopArgs pa;
@@ -888,6 +897,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
+        pa.t_base = 0;
         pa.weight = (const double *)c->weight.p;
         pa.lanes = (uint32_t)lanes;
         pa.partial = (double *)c->partial.p;
@@ -909,9 +919,20 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
 #else
         pa.debug = 0;
 #endif
-        ibdg::launch_win_target(pa, (unsigned)T, c->stream);
-        if (ibdg::launch_ld_popcount(pa, (unsigned)T, c->planes, c->stream))
-            return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
+        if (n_grp) {
+            ibdg::PopArgs pm = pa;
+            pm.rec_ready = (const uint32_t *)c->twords_mt.p;
+            pm.wc_ready = (const uint32_t *)c->wtarget_mt.p;
+            ibdg::launch_win_target_mt(pm, (unsigned)n_grp, c->stream);
+            if (ibdg::launch_ld_popcount_mt(pm, (unsigned)n_grp, c->stream))
+                return fail(c, "[::] ERROR in ibdg_run: the multi-target --LD kernel could not be launched");
+        }
+        if (T_one) {
+            pa.t_base = (uint32_t)(n_grp * MT);
+            ibdg::launch_win_target(pa, (unsigned)T_one, c->stream);
+            if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream))
+                return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
+        }
         ibdg::PopFinalArgs fa;
         fa.wconst = pa.wconst;
         fa.partial = pa.partial;
@@ -1066,6 +1087,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 {
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
+    if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {

@@ -100,6 +100,7 @@ struct PopArgs {
     const PowEntry *pow_1me;    // [(max cov_total)+1]
     const PowEntry *pow_eps;
     const uint32_t *targets;    // [T]
+    uint32_t t_base;            // first comparison individual of this launch (blockIdx.z / group 0)
     const double *weight;       // [T][lanes] background multiplicity (0 = excluded)
     uint32_t lanes;             // stride of weight per target
     double *partial;            // [T][n_win][n_chunks][2]
@@ -123,7 +124,13 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st);
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st);
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
-                             int ring_slots);
+                             int ring_slots, int multi_target);
+// groups of ld_popcount_mt_width() comparison individuals per workgroup (shared target-independent counts)
+int ld_popcount_mt_width(void);
+size_t ld_popcount_mt_rec_bytes(void);
+size_t ld_popcount_mt_wc_bytes(void);
+void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st);
+int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st);
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st);
 
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,

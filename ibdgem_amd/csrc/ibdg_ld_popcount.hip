@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned t = blockIdx.y;
-    const uint32_t tgt = a.targets[t];
+    const uint32_t tgt = a.targets[a.t_base + t];
     const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
     if (i < a.n_segs) {                      // thread i: the record of segment i
         const Seg S = a.segs[i];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
 
-    const double wgt = a.weight[(size_t)t * a.lanes + c * 64 + lane];
+    const double wgt = a.weight[(size_t)(a.t_base + t) * a.lanes + c * 64 + lane];
 
     // Counters per weight bit-plane: three planes for the cov-weighted sums, two for the
     // alt-weighted ones are kept apart (one v_bcnt_u32_b32 accumulates into them directly);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 s0 = wave_sum_to_lane63(s0);
                 s1 = wave_sum_to_lane63(s1);
                 if (lane == 63) {
-                    double *o = a.partial + (((size_t)t * a.n_win + w) * a.n_chunks + c) * 2;
+                    double *o = a.partial + (((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2;
                     o[0] = s0;
                     o[1] = s1;
                 }
@@ -554,6 +554,375 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         o[0] = t_stage; o[1] = t_dma; o[2] = t_fetch; o[3] = t_count; o[4] = t_fin; o[5] = te - ts0; o[6] = nseg; o[7] = w1 - w0;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Several comparison individuals per workgroup (BASELINE.json configs[4]: hundreds of them against
+// one panel).  Of the nine sums per background individual and window only the four G(x,t) depend
+// on the comparison individual; A(x0) A(x1) C(x0) C(x1) C(x0&x1), the tile words, the masks and
+// the product of the individual's own genotype factors (ibdgem.c:715) do not.  A workgroup of
+// k_ld_popcount_mt therefore serves TB comparison individuals at once: per segment the common
+// 13 counts are taken once and 12 more per individual; per window the common exponents and P2
+// once, then per individual the four IBD1 products, its weight (the individual itself is
+// excluded from its own background, ibdgem.c:714) and its two wave sums -- in exactly the
+// operations and order of k_ld_popcount, so the results are the same bits.
+//
+// LDS images (written by k_win_target_mt):
+//   segment, 12 + 2 TB + 4.. words: flags cov0 cov1 cov2 | alt0 alt1 - - | TB x {t0 t1} |
+//                                   window cov3..cov7 alt2..alt7            (IBDG_RECM_WORDS)
+//   window, 8 + 4 TB words:         mK(2) eK CT | AT - - - | TB x {a0cov a1cov a0alt a1alt}
+// ---------------------------------------------------------------------------
+#define IBDG_MT 4
+#define IBDG_RECM_WORDS (8 + 2 * IBDG_MT + 12)
+#define IBDG_WCM_WORDS (8 + 4 * IBDG_MT)
+enum { RM_TW = 8, RM_WIN = 8 + 2 * IBDG_MT, RM_COV3 = RM_WIN + 1, RM_ALT2 = RM_WIN + 6 };
+
+__global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__restrict__ rec_ready,
+                                                       uint32_t *__restrict__ wc_ready)
+{
+    constexpr int TB = IBDG_MT;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned g = blockIdx.y;                     // group of TB comparison individuals
+    const uint4 *tt[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const uint32_t tgt = a.targets[a.t_base + g * TB + j];
+        tt[j] = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
+    }
+    if (i < a.n_segs) {
+        const Seg S = a.segs[i];
+        uint4 *o = reinterpret_cast<uint4 *>(rec_ready + ((size_t)g * a.n_segs + i) * IBDG_RECM_WORDS);
+        o[0] = make_uint4(S.flags, S.cov[0], S.cov[1], S.cov[2]);
+        o[1] = make_uint4(S.alt[0], S.alt[1], 0, 0);
+#pragma unroll
+        for (int j = 0; j < TB; j += 2) {
+            const uint2 ta = tile_words(tt[j], S.tile), tb = tile_words(tt[j + 1], S.tile);
+            o[2 + j / 2] = make_uint4(ta.x, ta.y, tb.x, tb.y);
+        }
+        o[2 + TB / 2] = make_uint4(S.win, S.cov[3], S.cov[4], S.cov[5]);
+        o[3 + TB / 2] = make_uint4(S.cov[6], S.cov[7], S.alt[2], S.alt[3]);
+        o[4 + TB / 2] = make_uint4(S.alt[4], S.alt[5], S.alt[6], S.alt[7]);
+    }
+    if ((i >> 3) < a.n_win) {
+        const uint32_t w = i >> 3;
+        uint32_t acc[TB][4];
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+            acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0;
+        const uint32_t s1 = a.wconst[w + 1].seg_begin;
+        for (uint32_t s = a.wconst[w].seg_begin + (i & 7); s < s1; s += 8) {
+            const Seg &S = a.segs[s];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const uint2 at = tile_words(tt[j], S.tile);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc[j][0] += (uint32_t)__popc(at.x & S.cov[k]) << k;
+                    acc[j][1] += (uint32_t)__popc(at.y & S.cov[k]) << k;
+                    acc[j][2] += (uint32_t)__popc(at.x & S.alt[k]) << k;
+                    acc[j][3] += (uint32_t)__popc(at.y & S.alt[k]) << k;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[j][q] += __shfl_xor(acc[j][q], m);
+        if ((i & 7) == 0) {
+            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)g * a.n_win + w) * IBDG_WCM_WORDS);
+            o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
+            o[1] = make_uint4(wcs[4], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                o[2 + j] = make_uint4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_fetch_mt(uint4 &h0, uint4 &h1, uint4 &h2, uint4 &h3, uint2 &x, uint32_t rec_addr,
+                                             uint32_t x_addr)
+{
+    asm volatile("ds_read_b128 %0, %5\n\t"
+                 "ds_read_b128 %1, %5 offset:16\n\t"
+                 "ds_read_b128 %2, %5 offset:32\n\t"
+                 "ds_read_b128 %3, %5 offset:48\n\t"
+                 "ds_read_b64 %4, %6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(x)
+                 : "v"(rec_addr), "v"(x_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr)
+{
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, uint32_t addr1)
+{
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w0), "=&v"(w1)
+                 : "v"(addr0), "v"(addr1)
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad)[8])
+{
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\t"
+                 "ds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\t"
+                 "ds_read_b128 %5, %13\n\t"
+                 "ds_read_b128 %6, %14\n\t"
+                 "ds_read_b128 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]),
+                   "=&v"(p[7])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                 : "memory");
+}
+
+template <int NS, bool TAB_LDS>
+__global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict__ t32,
+                                                        const Seg *__restrict__ segs,
+                                                        const uint32_t *__restrict__ rec_ready,
+                                                        const WinConst *__restrict__ wconst,
+                                                        const uint32_t *__restrict__ wc_ready,
+                                                        const uint4 *__restrict__ pow_1me,
+                                                        const uint4 *__restrict__ pow_eps,
+                                                        const uint32_t *__restrict__ run_begin,
+                                                        PopArgs a)
+{
+    constexpr int FC = 3, FA = 2, TB = IBDG_MT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned g = blockIdx.z;                     // group of TB comparison individuals
+    const uint32_t run = blockIdx.x / a.n_cgroups, cgroup = blockIdx.x - run * a.n_cgroups;
+    const uint32_t w0 = run_begin[run], w1 = run_begin[run + 1];
+    const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
+    const uint32_t nseg = seg1 - seg0;
+    if (nseg == 0)
+        return;
+
+    // ---- LDS carve-up (ld_popcount_lds_bytes with the record / constant sizes of this kernel)
+    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_RECM_WORDS;
+    const size_t head = ((size_t)a.max_seg * IBDG_RECM_WORDS + (size_t)a.win_per_group * IBDG_WCM_WORDS) * 4 + 15;
+    uint4 *tab_lds = reinterpret_cast<uint4 *>(smem + (head & ~(size_t)15));
+    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
+    char *ring0 = smem + ((head + tab_bytes + 1023) & ~(size_t)1023);
+
+    // ---- prime the ring, then stage (see k_ld_popcount)
+    const unsigned c = cgroup * 8 + wave;
+    const bool has_chunk = c < a.n_chunks;
+    char *ring = ring0 + (size_t)wave * NS * 1024;
+    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;
+    const uint32_t tile0 = segs[seg0].tile;
+    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
+    uint32_t q_issue = q0;
+    if (has_chunk) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i, ++q_issue)
+            if (q_issue <= q_last)
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+    }
+    {
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)g * a.n_segs + seg0) * (IBDG_RECM_WORDS / 4);
+        uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
+        for (uint32_t i = threadIdx.x; i < nseg * (IBDG_RECM_WORDS / 4); i += blockDim.x)
+            rdst[i] = rsrc[i];
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)g * a.n_win + w0) * (IBDG_WCM_WORDS / 4);
+        uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WCM_WORDS / 4); i += blockDim.x)
+            wdst[i] = wsrc[i];
+        if (TAB_LDS)
+            for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
+                tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
+    }
+    __syncthreads();
+    if (!has_chunk)
+        return;
+    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+    const uint32_t tab2 = tab1 + a.tab_len * 16;
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+
+    double wgt[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+        wgt[j] = a.weight[(size_t)(a.t_base + g * TB + j) * a.lanes + c * 64 + lane];
+
+    uint32_t c0[FC], c1[FC], ch[FC], A0[FA], A1[FA];
+    uint32_t gq[TB][4][FC];          // G(x0,t0) G(x1,t0) G(x0,t1) G(x1,t1) per individual and plane
+#pragma unroll
+    for (int k = 0; k < FC; ++k) {
+        c0[k] = c1[k] = ch[k] = 0;
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+            gq[j][0][k] = gq[j][1][k] = gq[j][2][k] = gq[j][3][k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < FA; ++k)
+        A0[k] = A1[k] = 0;
+
+    if (q_issue - 1 <= q_last)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    uint32_t x_off = (tile0 & 1) * 8;
+    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;
+    const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
+    for (uint32_t s = 0; s < nseg; ++s, rec_addr += IBDG_RECM_WORDS * 4) {
+        uint4 h0, h1, h2, h3;
+        uint2 x;
+        lds_fetch_mt(h0, h1, h2, h3, x, rec_addr, ring_lane + x_off);
+        const uint32_t flags = __builtin_amdgcn_readfirstlane(h0.x);
+        const uint32_t last = flags & (1u << 13);
+        const uint32_t adv = (flags >> 4) & 0xff;
+        if (adv) {
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)
+                if (q_issue <= q_last)
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+            if (q_issue - 1 <= q_last)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;
+        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;
+        const uint32_t tw[TB][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};
+        const uint32_t hom = x.x & x.y;
+#define IBDG_COV_PLANE_MT(k, cov)                                           \
+    {                                                                       \
+        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
+        c0[k] += __popc(u0);                                                \
+        c1[k] += __popc(u1);                                                \
+        ch[k] += __popc(hom & (cov));                                       \
+        _Pragma("unroll") for (int j = 0; j < TB; ++j)                      \
+        {                                                                   \
+            gq[j][0][k] += __popc(u0 & tw[j][0]);                           \
+            gq[j][1][k] += __popc(u1 & tw[j][0]);                           \
+            gq[j][2][k] += __popc(u0 & tw[j][1]);                           \
+            gq[j][3][k] += __popc(u1 & tw[j][1]);                           \
+        }                                                                   \
+    }
+        IBDG_COV_PLANE_MT(0, cov0)
+        IBDG_COV_PLANE_MT(1, cov1)
+        IBDG_COV_PLANE_MT(2, cov2)
+        A0[0] += __popc(x.x & alt0);
+        A1[0] += __popc(x.y & alt0);
+        A0[1] += __popc(x.x & alt1);
+        A1[1] += __popc(x.y & alt1);
+        if (flags & (1u << 12)) {                     // rare: weight bit-planes beyond the counted ones
+            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;
+            for (uint32_t k = FC; k < ncov; ++k) {
+                const uint32_t cov = lds_read_b32(rec_addr + (RM_COV3 - FC + k) * 4);
+                const uint32_t u0 = x.x & cov, u1 = x.y & cov;
+                c0[0] += (uint32_t)__popc(u0) << k;
+                c1[0] += (uint32_t)__popc(u1) << k;
+                ch[0] += (uint32_t)__popc(hom & cov) << k;
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    gq[j][0][0] += (uint32_t)__popc(u0 & tw[j][0]) << k;
+                    gq[j][1][0] += (uint32_t)__popc(u1 & tw[j][0]) << k;
+                    gq[j][2][0] += (uint32_t)__popc(u0 & tw[j][1]) << k;
+                    gq[j][3][0] += (uint32_t)__popc(u1 & tw[j][1]) << k;
+                }
+            }
+            for (uint32_t k = FA; k < nalt; ++k) {
+                const uint32_t alt = lds_read_b32(rec_addr + (RM_ALT2 - FA + k) * 4);
+                A0[0] += (uint32_t)__popc(x.x & alt) << k;
+                A1[0] += (uint32_t)__popc(x.y & alt) << k;
+            }
+        }
+#undef IBDG_COV_PLANE_MT
+
+        if (last) {
+            const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_addr + RM_WIN * 4));
+            const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
+            uint4 k0, k1;
+            lds_read2(k0, k1, wc_addr, wc_addr + 16);
+            const int eK = (int)k0.z;
+            const uint32_t AT = k1.x;
+            const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
+            const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
+            double P2;
+            {
+                const uint32_t E3 = C0 + C1 - 2 * CH, E2 = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
+                uint4 p1, p2;
+                if (TAB_LDS) {
+                    lds_read2(p1, p2, tab1 + E2 * 16, tab2 + E3 * 16);
+                } else {
+                    p1 = pow_1me[E2];
+                    p2 = pow_eps[E3];
+                }
+                P2 = ld_value(eK, p1, p2);
+            }
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const uint4 kt = lds_read_b128(wc_addr + 32 + j * 16);
+                const uint32_t a0cov = kt.x, a1cov = kt.y, a0alt = kt.z, a1alt = kt.w;
+                const uint32_t G00 = planes_sum<FC>(gq[j][0]), G01 = planes_sum<FC>(gq[j][1]);
+                const uint32_t G10 = planes_sum<FC>(gq[j][2]), G11 = planes_sum<FC>(gq[j][3]);
+                uint32_t E2[4], E3[4];
+                E3[0] = a0cov + C0 - 2 * G00;  E2[0] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
+                E3[1] = a0cov + C1 - 2 * G01;  E2[1] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
+                E3[2] = a1cov + C0 - 2 * G10;  E2[2] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
+                E3[3] = a1cov + C1 - 2 * G11;  E2[3] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+                uint4 pw[8];
+                if (TAB_LDS) {
+                    uint32_t ad[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ad[2 * i] = tab1 + E2[i] * 16;
+                        ad[2 * i + 1] = tab2 + E3[i] * 16;
+                    }
+                    lds_read_pow8(pw, ad);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pw[2 * i] = pow_1me[E2[i]];
+                        pw[2 * i + 1] = pow_eps[E3[i]];
+                    }
+                }
+                const double Q00 = ld_value(eK, pw[0], pw[1]);
+                const double Q01 = ld_value(eK, pw[2], pw[3]);
+                const double Q10 = ld_value(eK, pw[4], pw[5]);
+                const double Q11 = ld_value(eK, pw[6], pw[7]);
+                double s0 = wgt[j] * P2;                                   // :743
+                double s1 = wgt[j] * (((Q00 + Q01) + Q10) + Q11);          // :744-745
+                s0 = wave_sum_to_lane63(s0);
+                s1 = wave_sum_to_lane63(s1);
+                if (lane == 63) {
+                    double *o = a.partial + (((size_t)(a.t_base + g * TB + j) * a.n_win + w) * a.n_chunks + c) * 2;
+                    o[0] = s0;
+                    o[1] = s1;
+                }
+#pragma unroll
+                for (int k = 0; k < FC; ++k)
+                    gq[j][0][k] = gq[j][1][k] = gq[j][2][k] = gq[j][3][k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < FC; ++k)
+                c0[k] = c1[k] = ch[k] = 0;
+#pragma unroll
+            for (int k = 0; k < FA; ++k)
+                A0[k] = A1[k] = 0;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Sum the per-chunk partials of a window and take the background average (src/ibdgem.c:751-752).
@@ -605,9 +974,11 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
 
 // LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
-                             int ring_slots)
+                             int ring_slots, int multi_target)
 {
-    size_t head = ((size_t)max_seg * IBDG_REC_WORDS + (size_t)win_per_group * IBDG_WC_WORDS) * 4 + 15;
+    const size_t rec_words = multi_target ? IBDG_RECM_WORDS : IBDG_REC_WORDS;
+    const size_t wc_words = multi_target ? IBDG_WCM_WORDS : IBDG_WC_WORDS;
+    size_t head = ((size_t)max_seg * rec_words + (size_t)win_per_group * wc_words) * 4 + 15;
     if (tab_in_lds)
         head += (size_t)tab_len * 32;
     return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024;
@@ -616,7 +987,7 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
 template <int NS, bool TAB>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
 {
-    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS);
+    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 0);
     auto kern = k_ld_popcount<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
@@ -636,6 +1007,43 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (a.ring_slots == 4)
         return a.tab_in_lds ? launch_pop<4, true>(a, grid, st) : launch_pop<4, false>(a, grid, st);
     return a.tab_in_lds ? launch_pop<8, true>(a, grid, st) : launch_pop<8, false>(a, grid, st);
+}
+
+// The same for groups of IBDG_MT comparison individuals (a.t_base = first of them, n_groups groups)
+int ld_popcount_mt_width(void) { return IBDG_MT; }
+size_t ld_popcount_mt_rec_bytes(void) { return IBDG_RECM_WORDS * 4; }
+size_t ld_popcount_mt_wc_bytes(void) { return IBDG_WCM_WORDS * 4; }
+
+void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
+{
+    if (a.n_win == 0 || n_groups == 0)
+        return;
+    const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
+    hipLaunchKernelGGL(k_win_target_mt, dim3((n + 255) / 256, n_groups), dim3(256), 0, st, a,
+                       const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+}
+
+template <int NS, bool TAB>
+static int launch_pop_mt(const PopArgs &a, dim3 grid, hipStream_t st)
+{
+    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 1);
+    auto kern = k_ld_popcount_mt<NS, TAB>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return 1;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
+                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
+    return 0;
+}
+
+int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
+{
+    if (a.n_win == 0 || n_groups == 0)
+        return 0;
+    dim3 grid(a.n_runs * a.n_cgroups, 1, n_groups);
+    if (a.ring_slots == 4)
+        return a.tab_in_lds ? launch_pop_mt<4, true>(a, grid, st) : launch_pop_mt<4, false>(a, grid, st);
+    return a.tab_in_lds ? launch_pop_mt<8, true>(a, grid, st) : launch_pop_mt<8, false>(a, grid, st);
 }
 
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st)

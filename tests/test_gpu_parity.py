@@ -257,6 +257,38 @@ def test_counting_inside_run_and_determinism():
             assert_bits(a, b, "run-to-run / option determinism")
 
 
+@pytest.mark.parametrize("M,cov,T", [(20, 2.0, 9), (40, 9.0, 6), (20, 2.0, 4)])
+def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
+    """T >= 4: groups of four comparison individuals go through k_ld_popcount_mt (target-independent
+    counts taken once per group), the rest one per workgroup -- every bit as with the option off."""
+    N, L = 150, 2600
+    rng = np.random.default_rng(500 + M)
+    f = rng.beta(0.4, 1.0, size=L).clip(1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
+    bg = rng.integers(0, 3, size=N).astype(np.uint8)
+    got = {}
+    for mt in (1, 0):
+        with E.Engine(0, 0.02, M) as eng:
+            eng.set_option("ld_variant", 2)
+            eng.set_option("multi_target", mt)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, 100)
+            eng.run(targets, ld=True, bg_count=bg, pu_id=targets[1])
+            assert eng.last_ld_variant() == 2
+            got[mt] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(T)]
+    for i, t in enumerate(targets):
+        assert_bits(got[1][i][0], got[0][i][0], f"site target {t}")
+        assert_bits(got[1][i][1], got[0][i][1], f"window target {t}")
+    for i in (0, T - 1):
+        res = oracle.compare(alle, nr, na, targets[i], window=100, ld=True, max_cov=M,
+                             refids=np.repeat(np.arange(N), bg), pu_id=targets[1])
+        assert_ld_close(got[1][i][1][:, :2], res["win"][:, :2], f"M={M} target {targets[i]}")
+
+
 def test_async_runs_queue_in_order():
     """"async": ibdg_run only enqueues; results and per-run timings are those of the synchronous calls."""
     N, L = 300, 2500
