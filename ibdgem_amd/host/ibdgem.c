@@ -723,7 +723,12 @@ typedef struct {
     const double *fo;
     size_t a, b;
     unsigned window;
-    uint32_t target;
+    /* When the site list does not depend on the comparison individual (no -v, no -D), the engine
+     * evaluates a batch of them per call (groups of four share a workgroup in the --LD kernel):
+     * the first individual of a batch uploads (once) and runs, the others only fetch their slice. */
+    const uint32_t *targets;                 /* the batch */
+    size_t n_targets, t_local;               /* its size; which of them this call is for */
+    int do_upload, do_run;
     const uint8_t *bg_count;
     int pu_id, ld;
     /* outputs, written at the slice's offsets of the comparison-wide arrays */
@@ -739,9 +744,10 @@ static void *shard_run(void *arg)
     shard_job *j = arg;
     const size_t n = j->b - j->a;
     j->failed = 1;
-    if (ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a, j->fo ? j->fo + j->a : NULL, n,
-                          j->window) ||
-        ibdg_run(j->eng, &j->target, 1, j->bg_count, j->pu_id, j->ld))
+    if (j->do_upload && ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a,
+                                          j->fo ? j->fo + j->a : NULL, n, j->window))
+        return NULL;
+    if (j->do_run && ibdg_run(j->eng, j->targets, j->n_targets, j->bg_count, j->pu_id, j->ld))
         return NULL;
     j->n_win = ibdg_num_windows(j->eng);
     j->w_first = malloc((j->n_win + 1) * 4);
@@ -749,7 +755,8 @@ static void *shard_run(void *arg)
     j->w_ncov = malloc((j->n_win + 1) * 4);
     j->win_ll = malloc((j->n_win + 1) * 24);
     if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_site_af(j->eng, j->site_af + j->a) ||
-        ibdg_get_site_ll(j->eng, 0, j->site_ll + 3 * j->a) || ibdg_get_window_ll(j->eng, 0, j->win_ll))
+        ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a) ||
+        ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
         return NULL;
     j->failed = 0;
     return NULL;
@@ -774,6 +781,7 @@ static void window_cuts(const uint8_t *nr, const uint8_t *na, size_t n, unsigned
     cuts[parts] = n;
 }
 
+#define TARGET_BATCH 16      /* comparison individuals per engine call when their site lists coincide */
 #define DIE(...)                          \
     do {                                  \
         fprintf(stderr, __VA_ARGS__);     \
@@ -993,6 +1001,9 @@ int main(int argc, char **argv)
     uint8_t *s_nr = malloc(n_cand ? n_cand : 1), *s_na = malloc(n_cand ? n_cand : 1);
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
     double *site_af = malloc((n_cand ? n_cand : 1) * 8), *site_ll = malloc((n_cand ? n_cand : 1) * 24);
+    /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
+     * reads anew for each (src/ibdgem.c:584, :627-628) */
+    const int batchable = !opt_plan && !has_v && cull_p == 1.0;
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
         const char *tname = ids.names[tgt];
@@ -1050,7 +1061,20 @@ int main(int argc, char **argv)
                 shard_job *j = &jobs[d];
                 memset(j, 0, sizeof *j);
                 j->eng = engs[d]; j->row = s_row; j->nr = s_nr; j->na = s_na; j->fo = s_fo;
-                j->a = cuts[d]; j->b = cuts[d + 1]; j->window = (unsigned)opt_window; j->target = tgt;
+                j->a = cuts[d]; j->b = cuts[d + 1]; j->window = (unsigned)opt_window;
+                if (batchable) {
+                    const size_t b0 = ti - ti % TARGET_BATCH;
+                    j->targets = targets.idx + b0;
+                    j->n_targets = targets.n - b0 < TARGET_BATCH ? targets.n - b0 : TARGET_BATCH;
+                    j->t_local = ti - b0;
+                    j->do_upload = ti == 0;
+                    j->do_run = ti == b0;
+                } else {
+                    j->targets = &targets.idx[ti];
+                    j->n_targets = 1;
+                    j->t_local = 0;
+                    j->do_upload = j->do_run = 1;
+                }
                 j->bg_count = bg_count; j->pu_id = (int)pu_id; j->ld = opt_ld;
                 j->site_af = site_af; j->site_ll = site_ll;
                 if (n_eng == 1)

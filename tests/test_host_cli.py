@@ -273,3 +273,30 @@ def test_cli_vcf_with_several_comparison_individuals(tmp_path):
         for pos, l in tv.items():
             assert ta[pos] == l
         assert len(_read(str(outV / f"UNKWN.{name}.summary.txt"))) > 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0", "0,0,0"])
+def test_cli_batches_comparison_individuals_when_their_site_lists_coincide(devices, tmp_path):
+    """No -v and no -D: the host hands the engine up to 16 comparison individuals per call (groups of
+    four share a workgroup of the --LD kernel).  The files of the two individuals the reference was
+    run for are byte-identical to its own, and every file equals the one of a run for that individual
+    alone (after the command line)."""
+    meta = G.cases("synA")
+    cwd = os.path.join(G.GOLD, "synA", "input")
+    names = ["ind3", "ind10", "ind11", "ind64", "ind20", "ind0", "ind5", "ind47", "ind31"]
+    batch = tmp_path / "batch"
+    batch.mkdir()
+    _run_full(meta["base_args"] + ["--LD", "-s", ",".join(names), "--devices", devices], cwd, batch)
+    ref = os.path.join(G.GOLD, "synA", "ld_default", "ref7")
+    for fn in sorted(os.listdir(ref)):
+        got, want = _read(str(batch / fn[:-3])), _read(os.path.join(ref, fn))
+        assert (got[1:] if fn.endswith(".tab.txt.gz") else got) == want, fn
+    for name in names[1:3] + names[-1:]:
+        solo = tmp_path / name
+        solo.mkdir()
+        _run_full(meta["base_args"] + ["--LD", "-s", name], cwd, solo)
+        for kind in ("tab", "summary"):
+            fn = f"UNKWN.{name}.{kind}.txt"
+            a, b = _read(str(batch / fn)), _read(str(solo / fn))
+            assert a[1:] == b[1:], fn
