@@ -113,6 +113,7 @@ struct ibdg_ctx {
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
+    long opt_peel = 1;     // k_ld_popcount_peel (no counter reset per window); 0 = k_ld_popcount
     long opt_guided = 1;   // shrink the runs towards the end of the grid
     long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
@@ -905,6 +906,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
         pa.stamps = nullptr;
+        pa.peel = (uint32_t)c->opt_peel;
 #if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
         pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;   // ablation builds only
         if (getenv("IBDG_STAMPS")) {
@@ -1088,6 +1090,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
+    if (!strcmp(name, "peel")) { c->opt_peel = value != 0; return 0; }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {

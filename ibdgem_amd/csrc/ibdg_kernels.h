@@ -108,6 +108,7 @@ struct PopArgs {
     uint32_t tab_len;           // entries per power table = (max cov_total) + 1
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
     unsigned long long *stamps; // ablation builds only: per-wave stamp sums (8 x u64 per wave), else NULL
+    uint32_t peel;              // 1: k_ld_popcount_peel (first segment of a window starts the counters)
     uint32_t debug;             // timing experiments only (env IBDG_DEBUG): 1 skip window math, 2 skip counting
 };
 

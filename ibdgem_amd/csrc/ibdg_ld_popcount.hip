@@ -556,6 +556,230 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 #endif
 }
 
+// One segment: fetch its record and tile words, advance the ring, count.  OP is `=` for the first
+// segment of a window (the counters start there, so nothing has to be zeroed) and `+=` after it.
+#define IBDG_COV_PLANE_OP(OP, k, cov)                                       \
+    {                                                                       \
+        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
+        c0[k] OP __popc(u0);                                                \
+        c1[k] OP __popc(u1);                                                \
+        ch[k] OP __popc(hom & (cov));                                       \
+        g00[k] OP __popc(u0 & at.x);                                        \
+        g01[k] OP __popc(u1 & at.x);                                        \
+        g10[k] OP __popc(u0 & at.y);                                        \
+        g11[k] OP __popc(u1 & at.y);                                        \
+    }
+#define IBDG_SEGMENT(OP)                                                                                        \
+    {                                                                                                           \
+        uint4 h0, h1;                                                                                           \
+        uint2 x;                                                                                                \
+        lds_fetch(h0, h1, x, rec_addr, ring_lane + x_off);                                                      \
+        flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
+        const uint32_t adv = (flags >> 4) & 0xff;                                                               \
+        if (adv) {                                                                                              \
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
+                if (q_issue <= q_last)                                                                          \
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
+            if (q_issue - 1 <= q_last)                                                                          \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
+            else                                                                                                \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                       \
+        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;                                                    \
+        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;                         \
+        const uint2 at = make_uint2(h1.z, h1.w);                                                                \
+        const uint32_t hom = x.x & x.y;                                                                         \
+        IBDG_COV_PLANE_OP(OP, 0, cov0)                                                                          \
+        IBDG_COV_PLANE_OP(OP, 1, cov1)                                                                          \
+        IBDG_COV_PLANE_OP(OP, 2, cov2)                                                                          \
+        A0[0] OP __popc(x.x & alt0);                                                                            \
+        A1[0] OP __popc(x.y & alt0);                                                                            \
+        A0[1] OP __popc(x.x & alt1);                                                                            \
+        A1[1] OP __popc(x.y & alt1);                                                                            \
+        if (flags & (1u << 12)) {                                                                               \
+            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
+            for (uint32_t k = FC; k < ncov; ++k) {                                                              \
+                const uint32_t cov = lds_read_b32(rec_addr + (RC_COV3 - FC + k) * 4);                           \
+                const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
+                c0[0] += (uint32_t)__popc(u0) << k;                                                             \
+                c1[0] += (uint32_t)__popc(u1) << k;                                                             \
+                ch[0] += (uint32_t)__popc(hom & cov) << k;                                                      \
+                g00[0] += (uint32_t)__popc(u0 & at.x) << k;                                                     \
+                g01[0] += (uint32_t)__popc(u1 & at.x) << k;                                                     \
+                g10[0] += (uint32_t)__popc(u0 & at.y) << k;                                                     \
+                g11[0] += (uint32_t)__popc(u1 & at.y) << k;                                                     \
+            }                                                                                                   \
+            for (uint32_t k = FA; k < nalt; ++k) {                                                              \
+                const uint32_t alt = lds_read_b32(rec_addr + (RC_ALT2 - FA + k) * 4);                           \
+                A0[0] += (uint32_t)__popc(x.x & alt) << k;                                                      \
+                A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
+            }                                                                                                   \
+        }                                                                                                       \
+        rec_prev = rec_addr;                                                                                    \
+        rec_addr += IBDG_REC_WORDS * 4;                                                                         \
+        ++s;                                                                                                    \
+    }
+
+template <int NS, bool TAB_LDS>
+__global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restrict__ t32,
+                                                     const Seg *__restrict__ segs,
+                                                     const uint32_t *__restrict__ rec_ready,
+                                                     const WinConst *__restrict__ wconst,
+                                                     const uint32_t *__restrict__ wc_ready,
+                                                     const uint4 *__restrict__ pow_1me,
+                                                     const uint4 *__restrict__ pow_eps,
+                                                     const uint32_t *__restrict__ run_begin,
+                                                     PopArgs a)
+{
+    constexpr int FC = 3, FA = 2;      // weight bit-planes with counters of their own (cov, alt)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned t = blockIdx.z;
+    // workgroups of one run are neighbours in blockIdx order (and so in dispatch order): the
+    // runs at the end of the grid are the short ones (host: guided run lengths)
+    const uint32_t run = blockIdx.x / a.n_cgroups, cgroup = blockIdx.x - run * a.n_cgroups;
+    const uint32_t w0 = run_begin[run], w1 = run_begin[run + 1];
+    const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
+    const uint32_t nseg = seg1 - seg0;
+    if (nseg == 0)
+        return;
+
+    // ---- LDS carve-up (see ld_popcount_lds_bytes)
+    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][22]
+    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_REC_WORDS;               // [win_per_group][12]
+    uint4 *tab_lds = reinterpret_cast<uint4 *>(
+        smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
+    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
+    char *ring0 = smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
+
+    // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
+    // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
+    // two start-up latencies of a workgroup overlap instead of adding up.
+    const unsigned c = cgroup * 8 + wave;
+    const bool has_chunk = c < a.n_chunks;
+    char *ring = ring0 + (size_t)wave * NS * 1024;
+    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
+    const uint32_t tile0 = segs[seg0].tile;
+    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
+    uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
+    if (has_chunk) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i, ++q_issue)
+            if (q_issue <= q_last)
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+    }
+
+    // ---- stage the run's records, window constants and tables (whole workgroup)
+    {
+        // plain contiguous copies (k_win_target prepared the LDS images): every load of a thread is
+        // independent of the others, so the whole staging costs about one memory latency
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * 5;
+        uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
+        for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
+            rdst[i] = rsrc[i];
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * 3;
+        uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 3; i += blockDim.x)
+            wdst[i] = wsrc[i];
+        if (TAB_LDS)
+            for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
+                tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
+    }
+    __syncthreads();
+
+    if (!has_chunk)
+        return;
+    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+    const uint32_t tab2 = tab1 + a.tab_len * 16;
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+
+    const double wgt = a.weight[(size_t)(a.t_base + t) * a.lanes + c * 64 + lane];
+
+    // Counters per weight bit-plane: three planes for the cov-weighted sums, two for the
+    // alt-weighted ones are kept apart (one v_bcnt_u32_b32 accumulates into them directly);
+    // the rare higher planes are shifted into plane 0 as they are counted.
+    uint32_t c0[FC], c1[FC], ch[FC], g00[FC], g01[FC], g10[FC], g11[FC], A0[FA], A1[FA];
+
+    // the first pair must have landed (it was requested before the staging loads, so it has)
+    if (q_issue - 1 <= q_last)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // Where a segment's tile words sit in the ring and how far the ring must advance before the
+    // NEXT segment are precomputed by the host into each record's flag word (ring slot relative to
+    // the run's first pair), so the loop carries no tile/pair arithmetic:
+    //   flags = next slot (3) | next half (1) | pairs to advance (8) | rare planes (1) | last (1) | .. | ncov (8) | nalt (8)
+    uint32_t x_off = (tile0 & 1) * 8;                // ring byte offset of the current segment's words (slot 0)
+    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
+    const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
+    uint32_t s = 0, rec_prev = rec_addr;
+    while (s < nseg) {                                   // one window per turn
+        uint32_t flags;
+        IBDG_SEGMENT(=)                                  // its first segment starts the counters
+        while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
+            IBDG_SEGMENT(+=)
+        {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_prev + RC_WIN * 4));
+        {
+            uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
+            lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
+            const int eK = (int)k0.z;
+            const uint32_t AT = k1.x;
+            const uint32_t a0cov = k1.y, a1cov = k1.z, a0alt = k1.w, a1alt = k2.x;
+            const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
+            const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
+            const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
+            const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
+            uint32_t E2[5], E3[5];
+            E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
+            E3[1] = a0cov + C0 - 2 * G00;  E2[1] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
+            E3[2] = a0cov + C1 - 2 * G01;  E2[2] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
+            E3[3] = a1cov + C0 - 2 * G10;  E2[3] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
+            E3[4] = a1cov + C1 - 2 * G11;  E2[4] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+            uint4 pw[10];
+            if (TAB_LDS) {
+                uint32_t ad[10];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    ad[2 * i] = tab1 + E2[i] * 16;
+                    ad[2 * i + 1] = tab2 + E3[i] * 16;
+                }
+                lds_read_pow10(pw, ad);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    pw[2 * i] = pow_1me[E2[i]];
+                    pw[2 * i + 1] = pow_eps[E3[i]];
+                }
+            }
+            const double P2 = ld_value(eK, pw[0], pw[1]);
+            const double Q00 = ld_value(eK, pw[2], pw[3]);
+            const double Q01 = ld_value(eK, pw[4], pw[5]);
+            const double Q10 = ld_value(eK, pw[6], pw[7]);
+            const double Q11 = ld_value(eK, pw[8], pw[9]);
+            double s0 = wgt * P2;                                   // :743
+            double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
+            s0 = wave_sum_to_lane63(s0);
+            s1 = wave_sum_to_lane63(s1);
+            if (lane == 63) {
+                double *o = a.partial + (((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2;
+                o[0] = s0;
+                o[1] = s1;
+            }
+        }
+        }
+    }
+    // leave no direct-to-LDS load in flight when the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#undef IBDG_SEGMENT
+#undef IBDG_COV_PLANE_OP
+
 // ---------------------------------------------------------------------------
 // Several comparison individuals per workgroup (BASELINE.json configs[4]: hundreds of them against
 // one panel).  Of the nine sums per background individual and window only the four G(x,t) depend
@@ -988,7 +1212,7 @@ template <int NS, bool TAB>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
 {
     const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 0);
-    auto kern = k_ld_popcount<NS, TAB>;
+    auto kern = a.peel ? k_ld_popcount_peel<NS, TAB> : k_ld_popcount<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
