@@ -915,6 +915,76 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
                  : "memory");
 }
 
+// One segment for TB comparison individuals (OP as in IBDG_SEGMENT of k_ld_popcount_peel)
+#define IBDG_COV_PLANE_MT(OP, k, cov)                                       \
+    {                                                                       \
+        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
+        c0[k] OP __popc(u0);                                                \
+        c1[k] OP __popc(u1);                                                \
+        ch[k] OP __popc(hom & (cov));                                       \
+        _Pragma("unroll") for (int j = 0; j < TB; ++j)                      \
+        {                                                                   \
+            gq[j][0][k] OP __popc(u0 & tw[j][0]);                           \
+            gq[j][1][k] OP __popc(u1 & tw[j][0]);                           \
+            gq[j][2][k] OP __popc(u0 & tw[j][1]);                           \
+            gq[j][3][k] OP __popc(u1 & tw[j][1]);                           \
+        }                                                                   \
+    }
+#define IBDG_SEGMENT_MT(OP)                                                                                     \
+    {                                                                                                           \
+        uint4 h0, h1, h2, h3;                                                                                   \
+        uint2 x;                                                                                                \
+        lds_fetch_mt(h0, h1, h2, h3, x, rec_addr, ring_lane + x_off);                                           \
+        flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
+        const uint32_t adv = (flags >> 4) & 0xff;                                                               \
+        if (adv) {                                                                                              \
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
+                if (q_issue <= q_last)                                                                          \
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
+            if (q_issue - 1 <= q_last)                                                                          \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
+            else                                                                                                \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                       \
+        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;                                                    \
+        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;                         \
+        const uint32_t tw[TB][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};                    \
+        const uint32_t hom = x.x & x.y;                                                                         \
+        IBDG_COV_PLANE_MT(OP, 0, cov0)                                                                          \
+        IBDG_COV_PLANE_MT(OP, 1, cov1)                                                                          \
+        IBDG_COV_PLANE_MT(OP, 2, cov2)                                                                          \
+        A0[0] OP __popc(x.x & alt0);                                                                            \
+        A1[0] OP __popc(x.y & alt0);                                                                            \
+        A0[1] OP __popc(x.x & alt1);                                                                            \
+        A1[1] OP __popc(x.y & alt1);                                                                            \
+        if (flags & (1u << 12)) {                                                                               \
+            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
+            for (uint32_t k = FC; k < ncov; ++k) {                                                              \
+                const uint32_t cov = lds_read_b32(rec_addr + (RM_COV3 - FC + k) * 4);                           \
+                const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
+                c0[0] += (uint32_t)__popc(u0) << k;                                                             \
+                c1[0] += (uint32_t)__popc(u1) << k;                                                             \
+                ch[0] += (uint32_t)__popc(hom & cov) << k;                                                      \
+                _Pragma("unroll") for (int j = 0; j < TB; ++j)                                                  \
+                {                                                                                               \
+                    gq[j][0][0] += (uint32_t)__popc(u0 & tw[j][0]) << k;                                        \
+                    gq[j][1][0] += (uint32_t)__popc(u1 & tw[j][0]) << k;                                        \
+                    gq[j][2][0] += (uint32_t)__popc(u0 & tw[j][1]) << k;                                        \
+                    gq[j][3][0] += (uint32_t)__popc(u1 & tw[j][1]) << k;                                        \
+                }                                                                                               \
+            }                                                                                                   \
+            for (uint32_t k = FA; k < nalt; ++k) {                                                              \
+                const uint32_t alt = lds_read_b32(rec_addr + (RM_ALT2 - FA + k) * 4);                           \
+                A0[0] += (uint32_t)__popc(x.x & alt) << k;                                                      \
+                A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
+            }                                                                                                   \
+        }                                                                                                       \
+        rec_prev = rec_addr;                                                                                    \
+        rec_addr += IBDG_RECM_WORDS * 4;                                                                        \
+        ++s;                                                                                                    \
+    }
+
 template <int NS, bool TAB_LDS>
 __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict__ t32,
                                                         const Seg *__restrict__ segs,
@@ -988,17 +1058,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
 
     uint32_t c0[FC], c1[FC], ch[FC], A0[FA], A1[FA];
     uint32_t gq[TB][4][FC];          // G(x0,t0) G(x1,t0) G(x0,t1) G(x1,t1) per individual and plane
-#pragma unroll
-    for (int k = 0; k < FC; ++k) {
-        c0[k] = c1[k] = ch[k] = 0;
-#pragma unroll
-        for (int j = 0; j < TB; ++j)
-            gq[j][0][k] = gq[j][1][k] = gq[j][2][k] = gq[j][3][k] = 0;
-    }
-#pragma unroll
-    for (int k = 0; k < FA; ++k)
-        A0[k] = A1[k] = 0;
-
     if (q_issue - 1 <= q_last)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
     else
@@ -1007,147 +1066,81 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     uint32_t x_off = (tile0 & 1) * 8;
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
-    for (uint32_t s = 0; s < nseg; ++s, rec_addr += IBDG_RECM_WORDS * 4) {
-        uint4 h0, h1, h2, h3;
-        uint2 x;
-        lds_fetch_mt(h0, h1, h2, h3, x, rec_addr, ring_lane + x_off);
-        const uint32_t flags = __builtin_amdgcn_readfirstlane(h0.x);
-        const uint32_t last = flags & (1u << 13);
-        const uint32_t adv = (flags >> 4) & 0xff;
-        if (adv) {
-            for (uint32_t i = 0; i < adv; ++i, ++q_issue)
-                if (q_issue <= q_last)
-                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
-                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
-            if (q_issue - 1 <= q_last)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t s = 0, rec_prev = rec_addr;
+    while (s < nseg) {                                   // one window per turn
+        uint32_t flags;
+        IBDG_SEGMENT_MT(=)                               // its first segment starts the counters
+        while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
+            IBDG_SEGMENT_MT(+=)
+        {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_prev + RM_WIN * 4));
+        const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
+        uint4 k0, k1;
+        lds_read2(k0, k1, wc_addr, wc_addr + 16);
+        const int eK = (int)k0.z;
+        const uint32_t AT = k1.x;
+        const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
+        const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
+        double P2;
+        {
+            const uint32_t E3 = C0 + C1 - 2 * CH, E2 = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
+            uint4 p1, p2;
+            if (TAB_LDS) {
+                lds_read2(p1, p2, tab1 + E2 * 16, tab2 + E3 * 16);
+            } else {
+                p1 = pow_1me[E2];
+                p2 = pow_eps[E3];
+            }
+            P2 = ld_value(eK, p1, p2);
         }
-        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;
-        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;
-        const uint32_t tw[TB][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};
-        const uint32_t hom = x.x & x.y;
-#define IBDG_COV_PLANE_MT(k, cov)                                           \
-    {                                                                       \
-        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
-        c0[k] += __popc(u0);                                                \
-        c1[k] += __popc(u1);                                                \
-        ch[k] += __popc(hom & (cov));                                       \
-        _Pragma("unroll") for (int j = 0; j < TB; ++j)                      \
-        {                                                                   \
-            gq[j][0][k] += __popc(u0 & tw[j][0]);                           \
-            gq[j][1][k] += __popc(u1 & tw[j][0]);                           \
-            gq[j][2][k] += __popc(u0 & tw[j][1]);                           \
-            gq[j][3][k] += __popc(u1 & tw[j][1]);                           \
-        }                                                                   \
-    }
-        IBDG_COV_PLANE_MT(0, cov0)
-        IBDG_COV_PLANE_MT(1, cov1)
-        IBDG_COV_PLANE_MT(2, cov2)
-        A0[0] += __popc(x.x & alt0);
-        A1[0] += __popc(x.y & alt0);
-        A0[1] += __popc(x.x & alt1);
-        A1[1] += __popc(x.y & alt1);
-        if (flags & (1u << 12)) {                     // rare: weight bit-planes beyond the counted ones
-            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;
-            for (uint32_t k = FC; k < ncov; ++k) {
-                const uint32_t cov = lds_read_b32(rec_addr + (RM_COV3 - FC + k) * 4);
-                const uint32_t u0 = x.x & cov, u1 = x.y & cov;
-                c0[0] += (uint32_t)__popc(u0) << k;
-                c1[0] += (uint32_t)__popc(u1) << k;
-                ch[0] += (uint32_t)__popc(hom & cov) << k;
 #pragma unroll
-                for (int j = 0; j < TB; ++j) {
-                    gq[j][0][0] += (uint32_t)__popc(u0 & tw[j][0]) << k;
-                    gq[j][1][0] += (uint32_t)__popc(u1 & tw[j][0]) << k;
-                    gq[j][2][0] += (uint32_t)__popc(u0 & tw[j][1]) << k;
-                    gq[j][3][0] += (uint32_t)__popc(u1 & tw[j][1]) << k;
+        for (int j = 0; j < TB; ++j) {
+            const uint4 kt = lds_read_b128(wc_addr + 32 + j * 16);
+            const uint32_t a0cov = kt.x, a1cov = kt.y, a0alt = kt.z, a1alt = kt.w;
+            const uint32_t G00 = planes_sum<FC>(gq[j][0]), G01 = planes_sum<FC>(gq[j][1]);
+            const uint32_t G10 = planes_sum<FC>(gq[j][2]), G11 = planes_sum<FC>(gq[j][3]);
+            uint32_t E2[4], E3[4];
+            E3[0] = a0cov + C0 - 2 * G00;  E2[0] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
+            E3[1] = a0cov + C1 - 2 * G01;  E2[1] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
+            E3[2] = a1cov + C0 - 2 * G10;  E2[2] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
+            E3[3] = a1cov + C1 - 2 * G11;  E2[3] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+            uint4 pw[8];
+            if (TAB_LDS) {
+                uint32_t ad[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ad[2 * i] = tab1 + E2[i] * 16;
+                    ad[2 * i + 1] = tab2 + E3[i] * 16;
+                }
+                lds_read_pow8(pw, ad);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pw[2 * i] = pow_1me[E2[i]];
+                    pw[2 * i + 1] = pow_eps[E3[i]];
                 }
             }
-            for (uint32_t k = FA; k < nalt; ++k) {
-                const uint32_t alt = lds_read_b32(rec_addr + (RM_ALT2 - FA + k) * 4);
-                A0[0] += (uint32_t)__popc(x.x & alt) << k;
-                A1[0] += (uint32_t)__popc(x.y & alt) << k;
+            const double Q00 = ld_value(eK, pw[0], pw[1]);
+            const double Q01 = ld_value(eK, pw[2], pw[3]);
+            const double Q10 = ld_value(eK, pw[4], pw[5]);
+            const double Q11 = ld_value(eK, pw[6], pw[7]);
+            double s0 = wgt[j] * P2;                                   // :743
+            double s1 = wgt[j] * (((Q00 + Q01) + Q10) + Q11);          // :744-745
+            s0 = wave_sum_to_lane63(s0);
+            s1 = wave_sum_to_lane63(s1);
+            if (lane == 63) {
+                double *o = a.partial + (((size_t)(a.t_base + g * TB + j) * a.n_win + w) * a.n_chunks + c) * 2;
+                o[0] = s0;
+                o[1] = s1;
             }
         }
-#undef IBDG_COV_PLANE_MT
-
-        if (last) {
-            const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_addr + RM_WIN * 4));
-            const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
-            uint4 k0, k1;
-            lds_read2(k0, k1, wc_addr, wc_addr + 16);
-            const int eK = (int)k0.z;
-            const uint32_t AT = k1.x;
-            const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
-            const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
-            double P2;
-            {
-                const uint32_t E3 = C0 + C1 - 2 * CH, E2 = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
-                uint4 p1, p2;
-                if (TAB_LDS) {
-                    lds_read2(p1, p2, tab1 + E2 * 16, tab2 + E3 * 16);
-                } else {
-                    p1 = pow_1me[E2];
-                    p2 = pow_eps[E3];
-                }
-                P2 = ld_value(eK, p1, p2);
-            }
-#pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                const uint4 kt = lds_read_b128(wc_addr + 32 + j * 16);
-                const uint32_t a0cov = kt.x, a1cov = kt.y, a0alt = kt.z, a1alt = kt.w;
-                const uint32_t G00 = planes_sum<FC>(gq[j][0]), G01 = planes_sum<FC>(gq[j][1]);
-                const uint32_t G10 = planes_sum<FC>(gq[j][2]), G11 = planes_sum<FC>(gq[j][3]);
-                uint32_t E2[4], E3[4];
-                E3[0] = a0cov + C0 - 2 * G00;  E2[0] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
-                E3[1] = a0cov + C1 - 2 * G01;  E2[1] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
-                E3[2] = a1cov + C0 - 2 * G10;  E2[2] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
-                E3[3] = a1cov + C1 - 2 * G11;  E2[3] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
-                uint4 pw[8];
-                if (TAB_LDS) {
-                    uint32_t ad[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        ad[2 * i] = tab1 + E2[i] * 16;
-                        ad[2 * i + 1] = tab2 + E3[i] * 16;
-                    }
-                    lds_read_pow8(pw, ad);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        pw[2 * i] = pow_1me[E2[i]];
-                        pw[2 * i + 1] = pow_eps[E3[i]];
-                    }
-                }
-                const double Q00 = ld_value(eK, pw[0], pw[1]);
-                const double Q01 = ld_value(eK, pw[2], pw[3]);
-                const double Q10 = ld_value(eK, pw[4], pw[5]);
-                const double Q11 = ld_value(eK, pw[6], pw[7]);
-                double s0 = wgt[j] * P2;                                   // :743
-                double s1 = wgt[j] * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-                s0 = wave_sum_to_lane63(s0);
-                s1 = wave_sum_to_lane63(s1);
-                if (lane == 63) {
-                    double *o = a.partial + (((size_t)(a.t_base + g * TB + j) * a.n_win + w) * a.n_chunks + c) * 2;
-                    o[0] = s0;
-                    o[1] = s1;
-                }
-#pragma unroll
-                for (int k = 0; k < FC; ++k)
-                    gq[j][0][k] = gq[j][1][k] = gq[j][2][k] = gq[j][3][k] = 0;
-            }
-#pragma unroll
-            for (int k = 0; k < FC; ++k)
-                c0[k] = c1[k] = ch[k] = 0;
-#pragma unroll
-            for (int k = 0; k < FA; ++k)
-                A0[k] = A1[k] = 0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+#undef IBDG_SEGMENT_MT
+#undef IBDG_COV_PLANE_MT
 
 // Sum the per-chunk partials of a window and take the background average (src/ibdgem.c:751-752).
 // One wave per window: lane c adds chunks c, c+64, .. (coalesced 16-byte loads), then the wave
