@@ -616,7 +616,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
             }                                                                                                   \
         }                                                                                                       \
-        rec_prev = rec_addr;                                                                                    \
         rec_addr += IBDG_REC_WORDS * 4;                                                                         \
         ++s;                                                                                                    \
     }
@@ -716,14 +715,13 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
     uint32_t x_off = (tile0 & 1) * 8;                // ring byte offset of the current segment's words (slot 0)
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
-    uint32_t s = 0, rec_prev = rec_addr;
-    while (s < nseg) {                                   // one window per turn
+    uint32_t s = 0;
+    for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
         IBDG_SEGMENT(=)                                  // its first segment starts the counters
         while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
             IBDG_SEGMENT(+=)
         {
-        const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_prev + RC_WIN * 4));
         {
             uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
             lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
@@ -980,7 +978,6 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
                 A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
             }                                                                                                   \
         }                                                                                                       \
-        rec_prev = rec_addr;                                                                                    \
         rec_addr += IBDG_RECM_WORDS * 4;                                                                        \
         ++s;                                                                                                    \
     }
@@ -1066,14 +1063,13 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     uint32_t x_off = (tile0 & 1) * 8;
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
-    uint32_t s = 0, rec_prev = rec_addr;
-    while (s < nseg) {                                   // one window per turn
+    uint32_t s = 0;
+    for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
         IBDG_SEGMENT_MT(=)                               // its first segment starts the counters
         while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
             IBDG_SEGMENT_MT(+=)
         {
-        const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_prev + RM_WIN * 4));
         const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
         uint4 k0, k1;
         lds_read2(k0, k1, wc_addr, wc_addr + 16);
