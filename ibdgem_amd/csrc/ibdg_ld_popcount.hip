@@ -41,6 +41,9 @@
 #define IBDG_TIMING_EXPERIMENT 0
 #endif
 
+// LDS image of a window's constants (8 words): eK AT <t0,cov> <t1,cov> | AT-<t0,alt> AT-<t1,alt> - -
+#define IBDG_WC_WORDS 8
+
 namespace ibdg {
 
 // ---------------------------------------------------------------------------
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
         }
         if ((i & 7) == 0) {
             const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);    // mK(2) eK ct at seg_begin
-            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * 12);
-            o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
-            o[1] = make_uint4(wcs[4], a0cov, a1cov, a0alt);
-            o[2] = make_uint4(a1alt, 0, 0, 0);
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WC_WORDS);
+            const uint32_t AT = wcs[4];
+            o[0] = make_uint4(wcs[2], AT, a0cov, a1cov);
+            o[1] = make_uint4(AT - a0alt, AT - a1alt, 0, 0);
         }
     }
 }
@@ -214,8 +217,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 // and a wave-uniform mask is just as good in a VGPR.
 #define IBDG_REC_WORDS 20
 enum { RC_WIN = 8, RC_COV3 = 9, RC_ALT2 = 14 };
-// LDS image of a window's constants (12 words): mK(2) eK CT | AT a0cov a1cov a0alt | a1alt - - -
-#define IBDG_WC_WORDS 12
 
 // Issue and wait in ONE statement: an asm output must be final when the statement ends,
 // because hipcc is free to copy it to another register right afterwards (it did, with the
@@ -232,14 +233,20 @@ __device__ __forceinline__ void lds_fetch(uint4 &h0, uint4 &h1, uint2 &x, uint32
                  : "memory");
 }
 
-__device__ __forceinline__ void lds_read_wc(uint4 &w0, uint4 &w1, uint4 &w2, uint32_t addr)
+__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr)
 {
-    asm volatile("ds_read_b128 %0, %3\n\t"
-                 "ds_read_b128 %1, %3 offset:16\n\t"
-                 "ds_read_b128 %2, %3 offset:32\n\t"
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, uint32_t addr1)
+{
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %3\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w0), "=&v"(w1), "=&v"(w2)
-                 : "v"(addr)
+                 : "=&v"(w0), "=&v"(w1)
+                 : "v"(addr0), "v"(addr1)
                  : "memory");
 }
 
@@ -360,9 +367,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
         for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
             rdst[i] = rsrc[i];
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * 3;
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 3; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
             wdst[i] = wsrc[i];
         if (TAB_LDS)
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
@@ -489,21 +496,21 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             if (!(a.debug & 1))
 #endif
             {
-                uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
-                lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
-                const int eK = (int)k0.z;
-                const uint32_t AT = k1.x;
-                const uint32_t a0cov = k1.y, a1cov = k1.z, a0alt = k1.w, a1alt = k2.x;
+                uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
+                lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
+                const int eK = (int)k0.x;
+                const uint32_t AT = k0.y;
+                const uint32_t a0cov = k0.z, a1cov = k0.w, b0 = k1.x, b1 = k1.y;   // b = AT - <t,alt>
                 const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
                 const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
                 const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
                 const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
                 uint32_t E2[5], E3[5];
                 E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
-                E3[1] = a0cov + C0 - 2 * G00;  E2[1] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
-                E3[2] = a0cov + C1 - 2 * G01;  E2[2] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
-                E3[3] = a1cov + C0 - 2 * G10;  E2[3] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
-                E3[4] = a1cov + C1 - 2 * G11;  E2[4] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+                E3[1] = a0cov + C0 - 2 * G00;  E2[1] = b0 - a0 + G00;                // pDg[A0+h0] (:716)
+                E3[2] = a0cov + C1 - 2 * G01;  E2[2] = b0 - a1 + G01;                // pDg[A0+h1] (:717)
+                E3[3] = a1cov + C0 - 2 * G10;  E2[3] = b1 - a0 + G10;                // pDg[A1+h0] (:718)
+                E3[4] = a1cov + C1 - 2 * G11;  E2[4] = b1 - a1 + G11;                // pDg[A1+h1] (:719)
                 uint4 pw[10];
                 if (TAB_LDS) {
                     uint32_t ad[10];
@@ -679,9 +686,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
         for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
             rdst[i] = rsrc[i];
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * 3;
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 3; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
             wdst[i] = wsrc[i];
         if (TAB_LDS)
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
@@ -723,21 +730,21 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
             IBDG_SEGMENT(+=)
         {
         {
-            uint4 k0, k1, k2;                       // the window's constants, broadcast into VGPRs
-            lds_read_wc(k0, k1, k2, wc_base + (w - w0) * (IBDG_WC_WORDS * 4));
-            const int eK = (int)k0.z;
-            const uint32_t AT = k1.x;
-            const uint32_t a0cov = k1.y, a1cov = k1.z, a0alt = k1.w, a1alt = k2.x;
+            uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
+            lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
+            const int eK = (int)k0.x;
+            const uint32_t AT = k0.y;
+            const uint32_t a0cov = k0.z, a1cov = k0.w, b0 = k1.x, b1 = k1.y;   // b = AT - <t,alt>
             const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
             const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
             const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
             const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
             uint32_t E2[5], E3[5];
             E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
-            E3[1] = a0cov + C0 - 2 * G00;  E2[1] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
-            E3[2] = a0cov + C1 - 2 * G01;  E2[2] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
-            E3[3] = a1cov + C0 - 2 * G10;  E2[3] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
-            E3[4] = a1cov + C1 - 2 * G11;  E2[4] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+            E3[1] = a0cov + C0 - 2 * G00;  E2[1] = b0 - a0 + G00;                // pDg[A0+h0] (:716)
+            E3[2] = a0cov + C1 - 2 * G01;  E2[2] = b0 - a1 + G01;                // pDg[A0+h1] (:717)
+            E3[3] = a1cov + C0 - 2 * G10;  E2[3] = b1 - a0 + G10;                // pDg[A1+h0] (:718)
+            E3[4] = a1cov + C1 - 2 * G11;  E2[4] = b1 - a1 + G11;                // pDg[A1+h1] (:719)
             uint4 pw[10];
             if (TAB_LDS) {
                 uint32_t ad[10];
@@ -876,23 +883,6 @@ __device__ __forceinline__ void lds_fetch_mt(uint4 &h0, uint4 &h1, uint4 &h2, ui
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(x)
                  : "v"(rec_addr), "v"(x_addr)
-                 : "memory");
-}
-
-__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr)
-{
-    uint4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
-__device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, uint32_t addr1)
-{
-    asm volatile("ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %3\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w0), "=&v"(w1)
-                 : "v"(addr0), "v"(addr1)
                  : "memory");
 }
 
