@@ -114,7 +114,8 @@ struct ibdg_ctx {
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
     long opt_peel = 1;     // k_ld_popcount_peel (no counter reset per window); 0 = k_ld_popcount
-    long opt_guided = 1;   // shrink the runs towards the end of the grid
+    long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
+                           // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
@@ -427,7 +428,7 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         // self-scheduling: remaining windows / workgroups in flight): workgroups are handed out in
         // blockIdx order, so the last ones to start are short and the CUs run dry together instead
         // of waiting for one last full-length run.
-        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * 2 / ((c->n_chunks + 7) / 8)));
+        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * 2 / ((c->n_chunks + 7) / 8)) * (uint32_t)std::max<long>(1, c->opt_guided) / 4);
         std::vector<uint32_t> runs;
         for (;; g = (g + 1) / 2) {
             uint32_t mx = 0;
@@ -1091,7 +1092,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
     if (!strcmp(name, "peel")) { c->opt_peel = value != 0; return 0; }
-    if (!strcmp(name, "guided_runs")) { c->opt_guided = value != 0; return 0; }
+    if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");
