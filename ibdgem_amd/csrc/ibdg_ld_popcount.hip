@@ -180,8 +180,14 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 // The --LD loop.
 //
 // Work split: a workgroup = 8 waves = 8 chunks of 64 background individuals (one individual
-// per lane) x one run of `win_per_group` consecutive windows.  Each wave streams its chunk's
-// tile pairs exactly once.
+// per lane) x one run of consecutive windows (run_begin[]: up to `win_per_group` windows, fewer
+// towards the end of the grid -- the host's guided run lengths; workgroups of a run are adjacent
+// in blockIdx order).  Each wave streams its chunk's tile pairs exactly once.
+//
+// Three kernels share this design: k_ld_popcount_peel (default: a window's first segment starts
+// the counters, no reset per window), k_ld_popcount (counters reset after every window; carries
+// the in-kernel stamps of the ablation builds) and k_ld_popcount_mt (four comparison individuals
+// per workgroup).  All three perform the same operations in the same order per result.
 //
 // Data movement (all of it asynchronous to the arithmetic):
 //   * once per workgroup the run's segment records (+ the target's haplotype words per
@@ -201,8 +207,9 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 // and 4 for the two alt-weighted ones; three cov planes and two alt planes unconditionally,
 // higher planes (rare) under one uniform test.
 // At the end of each window the lane turns its counts into the five products, the wave sums
-// count[n]*product over its 64 individuals (fixed shuffle order) and lane 0 stores the
-// per-chunk partial; k_ld_finalize adds the chunks in ascending order and divides.
+// count[n]*product over its 64 individuals (DPP moves, fixed order) and lane 63 stores the
+// per-chunk partial; k_ld_finalize adds the chunks (one wave per window, same fixed order),
+// applies the mantissa of K' and divides.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
 
