@@ -428,7 +428,8 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
         // self-scheduling: remaining windows / workgroups in flight): workgroups are handed out in
         // blockIdx order, so the last ones to start are short and the CUs run dry together instead
         // of waiting for one last full-length run.
-        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * 2 / ((c->n_chunks + 7) / 8)) * (uint32_t)std::max<long>(1, c->opt_guided) / 4);
+        const uint32_t n_cg = (c->n_chunks + 7) / 8, wpg_waves = (c->n_chunks + n_cg - 1) / n_cg;
+        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * (16 / wpg_waves) / n_cg) * (uint32_t)std::max<long>(1, c->opt_guided) / 4);
         std::vector<uint32_t> runs;
         for (;; g = (g + 1) / 2) {
             uint32_t mx = 0;
@@ -895,6 +896,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.run_begin = (const uint32_t *)c->runs.p;
         pa.n_runs = c->n_runs;
         pa.n_cgroups = (c->n_chunks + 7) / 8;
+        pa.waves_per_group = (c->n_chunks + pa.n_cgroups - 1) / pa.n_cgroups;   // 40 chunks: 5 x 8; 9: 5 + 4; 2: 1 x 2
         pa.wc_ready = (const uint32_t *)c->wtarget.p;
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;

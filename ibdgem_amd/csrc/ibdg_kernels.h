@@ -95,7 +95,8 @@ struct PopArgs {
     uint32_t win_per_group;     // most windows in one run (LDS sizing)
     const uint32_t *run_begin;  // [n_runs + 1] first window of every run; workgroup = (run, group of 8 chunks)
     uint32_t n_runs;
-    uint32_t n_cgroups;         // groups of 8 chunks
+    uint32_t n_cgroups;         // groups of waves_per_group chunks (one workgroup each per run)
+    uint32_t waves_per_group;   // 1..8: chunks = waves per workgroup, balanced over the groups
     const uint32_t *wc_ready;   // [T][n_win][12] LDS-ready window constants (written by k_win_target)
     const PowEntry *pow_1me;    // [(max cov_total)+1]
     const PowEntry *pow_eps;

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
     // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
     // two start-up latencies of a workgroup overlap instead of adding up.
-    const unsigned c = cgroup * 8 + wave;
+    const unsigned c = cgroup * a.waves_per_group + wave;
     const bool has_chunk = c < a.n_chunks;
     char *ring = ring0 + (size_t)wave * NS * 1024;
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
     // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
     // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
     // two start-up latencies of a workgroup overlap instead of adding up.
-    const unsigned c = cgroup * 8 + wave;
+    const unsigned c = cgroup * a.waves_per_group + wave;
     const bool has_chunk = c < a.n_chunks;
     char *ring = ring0 + (size_t)wave * NS * 1024;
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     char *ring0 = smem + ((head + tab_bytes + 1023) & ~(size_t)1023);
 
     // ---- prime the ring, then stage (see k_ld_popcount)
-    const unsigned c = cgroup * 8 + wave;
+    const unsigned c = cgroup * a.waves_per_group + wave;
     const bool has_chunk = c < a.n_chunks;
     char *ring = ring0 + (size_t)wave * NS * 1024;
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;
@@ -1202,7 +1202,7 @@ static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
                        a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
     return 0;
 }
@@ -1241,7 +1241,7 @@ static int launch_pop_mt(const PopArgs &a, dim3 grid, hipStream_t st)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
                        a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
     return 0;
 }
