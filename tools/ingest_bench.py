@@ -81,6 +81,10 @@ if os.path.exists("/dev/kfd"):
         os.makedirs(o, exist_ok=True)
         dt = timed([exe, *base, "--LD", "-O", o, "--threads", str(th)])
         out["end_to_end_LD"][f"threads_{th}"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
+    o = os.path.join(work, "out_warm")
+    os.makedirs(o, exist_ok=True)
+    dt = timed([exe, *base, "--LD", "-O", o, "--threads", "16", "--panel-cache", cache])   # cache written above
+    out["end_to_end_LD"]["threads_16_panel_cache"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
     if os.path.exists(ref):
         o = os.path.join(work, "ref_out_ld")
         os.makedirs(o, exist_ok=True)
