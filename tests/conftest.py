@@ -30,6 +30,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# On a machine without a GPU the HIP runtime that libibdgem_hip.so links against has nothing to talk
+# to, and its exit-time teardown has been seen to abort (once in ~15 runs) AFTER every test had
+# passed and the summary was printed -- turning a green run into exit code 134.  The CPU tier
+# therefore leaves through os._exit with pytest's own status once reporting is done; where a GPU
+# exists the normal interpreter shutdown is kept.
+_exit_status = [None]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _exit_status[0] = int(exitstatus)
+
+
+def pytest_unconfigure(config):
+    if _exit_status[0] is not None and not os.path.exists("/dev/kfd"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(_exit_status[0])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """ctypes handle on oracle/liboracle.so (the CPU checker), built on demand."""
