@@ -116,7 +116,7 @@ struct ibdg_ctx {
     long opt_peel = 1;     // k_ld_popcount_peel (no counter reset per window); 0 = k_ld_popcount
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
-    long opt_ring = 4;     // LDS ring slots per wave (4 or 8)
+    long opt_ring = 3;     // LDS ring slots per wave (3, 4 or 8)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
 
@@ -1109,7 +1109,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_variant = value; return 0;
     }
     if (!strcmp(name, "ring_slots")) {
-        if (value != 4 && value != 8) return fail(c, "[::] ERROR in ibdg_set_option: ring_slots must be 4 or 8");
+        if (value != 3 && value != 4 && value != 8) return fail(c, "[::] ERROR in ibdg_set_option: ring_slots must be 3, 4 or 8");
         c->opt_ring = value; return 0;
     }
     if (!strcmp(name, "record_lds_bytes")) {

@@ -166,6 +166,31 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     return v;
 }
 
+// Two wave-wide sums at once through a 1 KiB LDS scratch of the wave: every lane writes its two
+// addends into two arrays of 64 doubles; lane 32j+p then reads elements 2p, 2p+1 of sum j (one
+// 16-byte read at scratch + 16*lane), adds them, and the 32 lanes of half j finish with five DPP
+// steps.  Lane 31 ends up with the total of the first sum, lane 63 with the second.  Fixed order,
+// no barrier (the scratch is the wave's own and a wave's LDS operations execute in order);
+// 19 instructions for the two sums of a window instead of 36 for two full-wave DPP reductions.
+__device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, uint32_t scr_r)
+{
+    uint4 r;
+    asm volatile("ds_write_b64 %1, %2\n\t"
+                 "ds_write_b64 %1, %3 offset:512\n\t"
+                 "ds_read_b128 %0, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r)
+                 : "v"(scr_w), "v"(a), "v"(b), "v"(scr_r)
+                 : "memory");
+    double v = __hiloint2double((int)r.y, (int)r.x) + __hiloint2double((int)r.w, (int)r.z);
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a 16-lane row holds the row total
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3: lanes 16-31 / 48-63 hold the half totals
+    return v;
+}
+
 template <int KP>
 __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 {
@@ -391,6 +416,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+    // the wave's 1 KiB scratch for wave_sum2, behind the rings
+    const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
+    const uint32_t scr_w = scr + lane * 8, scr_r = scr + lane * 16;
 
     const double wgt = a.weight[(size_t)(a.t_base + t) * a.lanes + c * 64 + lane];
 
@@ -541,13 +569,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 const double Q11 = ld_value(eK, pw[8], pw[9]);
                 double s0 = wgt * P2;                                   // :743
                 double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-                s0 = wave_sum_to_lane63(s0);
-                s1 = wave_sum_to_lane63(s1);
-                if (lane == 63) {
-                    double *o = a.partial + (((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2;
-                    o[0] = s0;
-                    o[1] = s1;
-                }
+                const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // lane 31: sum of s0, lane 63: of s1
+                if ((lane & 31) == 31)
+                    a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
             }
 #pragma unroll
             for (int k = 0; k < FC; ++k)
@@ -708,6 +732,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+    // the wave's 1 KiB scratch for wave_sum2, behind the rings
+    const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
+    const uint32_t scr_w = scr + lane * 8, scr_r = scr + lane * 16;
 
     const double wgt = a.weight[(size_t)(a.t_base + t) * a.lanes + c * 64 + lane];
 
@@ -775,13 +802,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
             const double Q11 = ld_value(eK, pw[8], pw[9]);
             double s0 = wgt * P2;                                   // :743
             double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-            s0 = wave_sum_to_lane63(s0);
-            s1 = wave_sum_to_lane63(s1);
-            if (lane == 63) {
-                double *o = a.partial + (((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2;
-                o[0] = s0;
-                o[1] = s1;
-            }
+            const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // lane 31: sum of s0, lane 63: of s1
+            if ((lane & 31) == 31)
+                a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
         }
         }
     }
@@ -1044,6 +1067,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
     const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
+    // the wave's 1 KiB scratch for wave_sum2, behind the rings
+    const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
+    const uint32_t scr_w = scr + lane * 8, scr_r = scr + lane * 16;
 
     double wgt[TB];
 #pragma unroll
@@ -1119,13 +1145,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
             const double Q11 = ld_value(eK, pw[6], pw[7]);
             double s0 = wgt[j] * P2;                                   // :743
             double s1 = wgt[j] * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-            s0 = wave_sum_to_lane63(s0);
-            s1 = wave_sum_to_lane63(s1);
-            if (lane == 63) {
-                double *o = a.partial + (((size_t)(a.t_base + g * TB + j) * a.n_win + w) * a.n_chunks + c) * 2;
-                o[0] = s0;
-                o[1] = s1;
-            }
+            const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // lane 31: sum of s0, lane 63: of s1
+            if ((lane & 31) == 31)
+                a.partial[(((size_t)(a.t_base + g * TB + j) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
         }
         }
     }
@@ -1191,7 +1213,7 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
     size_t head = ((size_t)max_seg * rec_words + (size_t)win_per_group * wc_words) * 4 + 15;
     if (tab_in_lds)
         head += (size_t)tab_len * 32;
-    return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024;
+    return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024 + 8 * 1024;    // rings + wave_sum2 scratch
 }
 
 template <int NS, bool TAB>
@@ -1214,6 +1236,8 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (planes < 1 || planes > 8)
         return 1;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
+    if (a.ring_slots == 3)
+        return a.tab_in_lds ? launch_pop<3, true>(a, grid, st) : launch_pop<3, false>(a, grid, st);
     if (a.ring_slots == 4)
         return a.tab_in_lds ? launch_pop<4, true>(a, grid, st) : launch_pop<4, false>(a, grid, st);
     return a.tab_in_lds ? launch_pop<8, true>(a, grid, st) : launch_pop<8, false>(a, grid, st);
@@ -1251,6 +1275,8 @@ int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
     if (a.n_win == 0 || n_groups == 0)
         return 0;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_groups);
+    if (a.ring_slots == 3)
+        return a.tab_in_lds ? launch_pop_mt<3, true>(a, grid, st) : launch_pop_mt<3, false>(a, grid, st);
     if (a.ring_slots == 4)
         return a.tab_in_lds ? launch_pop_mt<4, true>(a, grid, st) : launch_pop_mt<4, false>(a, grid, st);
     return a.tab_in_lds ? launch_pop_mt<8, true>(a, grid, st) : launch_pop_mt<8, false>(a, grid, st);
