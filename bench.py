@@ -338,7 +338,7 @@ def main():
                        "rows": int(rows_total), "windowed_sites": int(cov_total), "n_ids": args.ids,
                        "window": args.window, "targets": len(targets), "epsilon": 0.02, "max_cov": 20,
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
-            "roofline": {"bound": "hbm", "kernel": "k_ld_popcount_peel" if ld_variant == 2 else "k_ld_window",
+            "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world),
                          "bytes_per_site": b_site, "sites_per_launch": n_cov, "launch_ms": ld_ms,

@@ -91,8 +91,6 @@ struct ibdg_ctx {
     bool pop_dense_enough = true; // covered rows / spanned rows high enough for it to be the faster kernel
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
-    void *stamp_ptr = nullptr;         // ablation builds: in-kernel stamp sums of the last --LD launch
-    size_t stamp_bytes = 0;
     // inputs of the previous ibdg_run whose device copies are still valid
     std::vector<uint32_t> prev_targets;
     std::vector<uint8_t> prev_bg;
@@ -113,10 +111,9 @@ struct ibdg_ctx {
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
-    long opt_peel = 1;     // k_ld_popcount_peel (no counter reset per window); 0 = k_ld_popcount
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
-    long opt_ring = 3;     // LDS ring slots per wave (3, 4 or 8)
+    long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
 };
 
@@ -876,8 +873,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const bool mt_fits = ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring,
                                                          1) <= 150 * 1024;
         const size_t n_grp = (c->opt_multi_target && mt_fits && T >= MT) ? T / MT : 0, T_one = T - n_grp * MT;
-        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 48) ||
-            ensure(c, c->twords, T_one * (size_t)c->n_segs * 80) ||
+        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
+            ensure(c, c->twords, T_one * (size_t)c->n_segs * 32) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
@@ -908,22 +905,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
-        pa.stamps = nullptr;
-        pa.peel = (uint32_t)c->opt_peel;
-#if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
-        pa.debug = getenv("IBDG_DEBUG") ? (uint32_t)atoi(getenv("IBDG_DEBUG")) : 0u;   // ablation builds only
-        if (getenv("IBDG_STAMPS")) {
-            const size_t n_w = (size_t)c->n_runs * ((c->n_chunks + 7) / 8) * T * 8;
-            static DevBuf stamp_buf;
-            if (ensure(c, stamp_buf, n_w * 64)) return 1;
-            HIP_TRY(c, hipMemsetAsync(stamp_buf.p, 0, n_w * 64, c->stream));
-            pa.stamps = (unsigned long long *)stamp_buf.p;
-            c->stamp_ptr = stamp_buf.p;
-            c->stamp_bytes = n_w * 64;
-        }
-#else
-        pa.debug = 0;
-#endif
         if (n_grp) {
             ibdg::PopArgs pm = pa;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
@@ -997,24 +978,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         return 1;
     c->n_targets = T;
     c->have_results = true;
-#if defined(IBDG_TIMING_EXPERIMENT) && IBDG_TIMING_EXPERIMENT
-    if (c->stamp_ptr && getenv("IBDG_STAMPS")) {
-        std::vector<unsigned long long> h(c->stamp_bytes / 8);
-        HIP_TRY(c, hipMemcpy(h.data(), c->stamp_ptr, c->stamp_bytes, hipMemcpyDeviceToHost));
-        unsigned long long sum[8] = {0};
-        size_t n = 0;
-        for (size_t i = 0; i + 8 <= h.size(); i += 8)
-            if (h[i + 5]) { for (int k = 0; k < 8; ++k) sum[k] += h[i + k]; ++n; }
-        FILE *f = fopen(getenv("IBDG_STAMPS"), "w");
-        if (f) {
-            fprintf(f, "waves %zu\nstage %.1f\ndma %.1f\nfetch %.1f\ncount %.1f\nfinalize %.1f\ntotal %.1f\nsegs %.1f\nwindows %.1f\n", n,
-                    (double)sum[0] / n, (double)sum[1] / n, (double)sum[2] / n, (double)sum[3] / n, (double)sum[4] / n,
-                    (double)sum[5] / n, (double)sum[6] / n, (double)sum[7] / n);
-            fclose(f);
-        }
-        c->stamp_ptr = nullptr;
-    }
-#endif
     return 0;
 }
 
@@ -1093,7 +1056,6 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
-    if (!strcmp(name, "peel")) { c->opt_peel = value != 0; return 0; }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
@@ -1109,7 +1071,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_variant = value; return 0;
     }
     if (!strcmp(name, "ring_slots")) {
-        if (value != 3 && value != 4 && value != 8) return fail(c, "[::] ERROR in ibdg_set_option: ring_slots must be 3, 4 or 8");
+        if (value != 2 && value != 3 && value != 4 && value != 8) return fail(c, "[::] ERROR in ibdg_set_option: ring_slots must be 2, 3, 4 or 8");
         c->opt_ring = value; return 0;
     }
     if (!strcmp(name, "record_lds_bytes")) {

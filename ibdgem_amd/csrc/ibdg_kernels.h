@@ -89,7 +89,7 @@ struct PopArgs {
     const Seg *segs;
     uint32_t n_segs;
     uint32_t max_seg;           // most segments in one run of win_per_group windows (LDS sizing)
-    const uint32_t *rec_ready;  // [T][n_segs][20] LDS-ready segment records (written by k_win_target)
+    const uint32_t *rec_ready;  // [T][n_segs][8] LDS-ready segment records (written by k_win_target)
     const WinConst *wconst;     // [n_win + 1] (the extra entry carries seg_begin = n_segs)
     uint32_t n_win;
     uint32_t win_per_group;     // most windows in one run (LDS sizing)
@@ -97,7 +97,7 @@ struct PopArgs {
     uint32_t n_runs;
     uint32_t n_cgroups;         // groups of waves_per_group chunks (one workgroup each per run)
     uint32_t waves_per_group;   // 1..8: chunks = waves per workgroup, balanced over the groups
-    const uint32_t *wc_ready;   // [T][n_win][12] LDS-ready window constants (written by k_win_target)
+    const uint32_t *wc_ready;   // [T][n_win][8] LDS-ready window constants (written by k_win_target)
     const PowEntry *pow_1me;    // [(max cov_total)+1]
     const PowEntry *pow_eps;
     const uint32_t *targets;    // [T]
@@ -108,9 +108,6 @@ struct PopArgs {
     uint32_t ring_slots;        // 4 or 8 tile pairs of LDS ring per wave
     uint32_t tab_len;           // entries per power table = (max cov_total) + 1
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
-    unsigned long long *stamps; // ablation builds only: per-wave stamp sums (8 x u64 per wave), else NULL
-    uint32_t peel;              // 1: k_ld_popcount_peel (first segment of a window starts the counters)
-    uint32_t debug;             // timing experiments only (env IBDG_DEBUG): 1 skip window math, 2 skip counting
 };
 
 struct PopFinalArgs {

@@ -35,12 +35,19 @@
 
 #include <hip/hip_runtime.h>
 
-// -DIBDG_TIMING_EXPERIMENT=1 builds the ablation switches read from PopArgs::debug
-// (env IBDG_DEBUG: 1 = skip the window math, 2 = skip the counting); never in a product build.
-#ifndef IBDG_TIMING_EXPERIMENT
-#define IBDG_TIMING_EXPERIMENT 0
-#endif
 
+// LDS image of a segment (8 words, 16-byte aligned):
+//   flags | cov0 cov1 cov2 | alt0 alt1 | target words t0 t1
+// The masks of the rare higher weight bit-planes (cov3.., alt2..) stay in the global Seg array and
+// are fetched with scalar loads by the few segments that have them (flags bit 12) -- keeping them
+// out of LDS is what lets a fourth workgroup fit on a CU.
+// flags = ring slot of the NEXT segment's pair (3) | its tile half (1) | pairs to advance before it (8)
+//       | rare planes present (1) | last segment of its window (1) | - | ncov (8) | nalt (8)   (host-built)
+// The hot half is read with two BROADCAST ds_read_b128 (every lane the same address), so the
+// masks land in VGPRs: on gfx950 a VALU instruction with an SGPR operand issues at half the rate
+// of one with VGPR operands only (tools/ubench/issue_rates.hip: v_and_b32 4.1 vs 2.4 cycles),
+// and a wave-uniform mask is just as good in a VGPR.
+#define IBDG_REC_WORDS 8
 // LDS image of a window's constants (8 words): eK AT <t0,cov> <t1,cov> | AT-<t0,alt> AT-<t1,alt> - -
 #define IBDG_WC_WORDS 8
 
@@ -104,12 +111,9 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
     if (i < a.n_segs) {                      // thread i: the record of segment i
         const Seg S = a.segs[i];
         const uint2 at = tile_words(tt, S.tile);
-        uint4 *o = reinterpret_cast<uint4 *>(rec_ready + ((size_t)t * a.n_segs + i) * 20);
-        o[0] = make_uint4(S.flags, S.cov[0], S.cov[1], S.cov[2]);          // hot half
+        uint4 *o = reinterpret_cast<uint4 *>(rec_ready + ((size_t)t * a.n_segs + i) * IBDG_REC_WORDS);
+        o[0] = make_uint4(S.flags, S.cov[0], S.cov[1], S.cov[2]);
         o[1] = make_uint4(S.alt[0], S.alt[1], at.x, at.y);
-        o[2] = make_uint4(S.win, S.cov[3], S.cov[4], S.cov[5]);            // cold half
-        o[3] = make_uint4(S.cov[6], S.cov[7], S.alt[2], S.alt[3]);
-        o[4] = make_uint4(S.alt[4], S.alt[5], S.alt[6], S.alt[7]);
     }
     if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w
         const uint32_t w = i >> 3;
@@ -209,10 +213,10 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 // towards the end of the grid -- the host's guided run lengths; workgroups of a run are adjacent
 // in blockIdx order).  Each wave streams its chunk's tile pairs exactly once.
 //
-// Three kernels share this design: k_ld_popcount_peel (default: a window's first segment starts
-// the counters, no reset per window), k_ld_popcount (counters reset after every window; carries
-// the in-kernel stamps of the ablation builds) and k_ld_popcount_mt (four comparison individuals
-// per workgroup).  All three perform the same operations in the same order per result.
+// Two kernels share this design: k_ld_popcount (one comparison individual per workgroup) and
+// k_ld_popcount_mt (four).  Both perform the same operations in the same order per result.
+// Their loops are written so that a window's first segment STARTS the counters (IBDG_SEGMENT(=))
+// and the others add to them (IBDG_SEGMENT(+=)): nothing is reset between windows.
 //
 // Data movement (all of it asynchronous to the arithmetic):
 //   * once per workgroup the run's segment records (+ the target's haplotype words per
@@ -238,17 +242,6 @@ __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
 
-// LDS image of a segment (20 words, 16-byte aligned):
-//   hot  [0..7]   flags' | cov0 cov1 cov2 | alt0 alt1 | target words t0 t1
-//   cold [8..19]  window index | cov3..cov7 | alt2..alt7
-// flags = ring slot of the NEXT segment's pair (3) | its tile half (1) | pairs to advance before it (8)
-//       | rare planes present (1) | last segment of its window (1) | - | ncov (8) | nalt (8)   (host-built)
-// The hot half is read with two BROADCAST ds_read_b128 (every lane the same address), so the
-// masks land in VGPRs: on gfx950 a VALU instruction with an SGPR operand issues at half the rate
-// of one with VGPR operands only (tools/ubench/issue_rates.hip: v_and_b32 4.1 vs 2.4 cycles),
-// and a wave-uniform mask is just as good in a VGPR.
-#define IBDG_REC_WORDS 20
-enum { RC_WIN = 8, RC_COV3 = 9, RC_ALT2 = 14 };
 
 // Issue and wait in ONE statement: an asm output must be final when the statement ends,
 // because hipcc is free to copy it to another register right afterwards (it did, with the
@@ -282,13 +275,6 @@ __device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, 
                  : "memory");
 }
 
-__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr)
-{
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
 // ten power-table entries (16 B each) for the five products of one window
 __device__ __forceinline__ void lds_read_pow10(uint4 (&p)[10], const uint32_t (&ad)[10])
 {
@@ -316,282 +302,6 @@ __device__ __forceinline__ double ld_value(int eK, const uint4 &p1, const uint4 
 {
     const double m1 = __hiloint2double((int)p1.y, (int)p1.x), m2 = __hiloint2double((int)p2.y, (int)p2.x);
     return __builtin_ldexp(m1 * m2, eK + (int)p1.z + (int)p2.z);
-}
-
-#if IBDG_TIMING_EXPERIMENT
-// In-kernel stamps (ablation builds only): shader-clock ticks, summed per wave and written to
-// PopArgs::stamps[wave_global][8]; never read by the kernel, never part of a product build.
-__device__ __forceinline__ unsigned long long stamp()
-{
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define IBDG_STAMP(var) const unsigned long long var = stamp()
-#define IBDG_ACC(sum, a_, b_) sum += (b_) - (a_)
-#else
-#define IBDG_STAMP(var)
-#define IBDG_ACC(sum, a_, b_)
-#endif
-
-template <int NS, bool TAB_LDS>
-__global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
-                                                     const Seg *__restrict__ segs,
-                                                     const uint32_t *__restrict__ rec_ready,
-                                                     const WinConst *__restrict__ wconst,
-                                                     const uint32_t *__restrict__ wc_ready,
-                                                     const uint4 *__restrict__ pow_1me,
-                                                     const uint4 *__restrict__ pow_eps,
-                                                     const uint32_t *__restrict__ run_begin,
-                                                     PopArgs a)
-{
-    constexpr int FC = 3, FA = 2;      // weight bit-planes with counters of their own (cov, alt)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned t = blockIdx.z;
-    // workgroups of one run are neighbours in blockIdx order (and so in dispatch order): the
-    // runs at the end of the grid are the short ones (host: guided run lengths)
-    const uint32_t run = blockIdx.x / a.n_cgroups, cgroup = blockIdx.x - run * a.n_cgroups;
-    const uint32_t w0 = run_begin[run], w1 = run_begin[run + 1];
-    const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
-    const uint32_t nseg = seg1 - seg0;
-    if (nseg == 0)
-        return;
-
-#if IBDG_TIMING_EXPERIMENT
-    unsigned long long t_stage = 0, t_dma = 0, t_fetch = 0, t_count = 0, t_fin = 0;
-#endif
-    IBDG_STAMP(ts0);
-    // ---- LDS carve-up (see ld_popcount_lds_bytes)
-    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][22]
-    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_REC_WORDS;               // [win_per_group][12]
-    uint4 *tab_lds = reinterpret_cast<uint4 *>(
-        smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
-    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
-    char *ring0 = smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
-
-    // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
-    // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
-    // two start-up latencies of a workgroup overlap instead of adding up.
-    const unsigned c = cgroup * a.waves_per_group + wave;
-    const bool has_chunk = c < a.n_chunks;
-    char *ring = ring0 + (size_t)wave * NS * 1024;
-    const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
-    const uint32_t tile0 = segs[seg0].tile;
-    const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
-    uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
-    if (has_chunk) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i, ++q_issue)
-            if (q_issue <= q_last)
-                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
-                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
-    }
-
-    // ---- stage the run's records, window constants and tables (whole workgroup)
-    {
-        // plain contiguous copies (k_win_target prepared the LDS images): every load of a thread is
-        // independent of the others, so the whole staging costs about one memory latency
-        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * 5;
-        uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
-        for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
-            rdst[i] = rsrc[i];
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
-        uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
-            wdst[i] = wsrc[i];
-        if (TAB_LDS)
-            for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
-                tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
-    }
-    __syncthreads();
-
-    if (!has_chunk)
-        return;
-    IBDG_STAMP(ts1);
-    IBDG_ACC(t_stage, ts0, ts1);
-    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
-    const uint32_t tab2 = tab1 + a.tab_len * 16;
-    const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
-    // the wave's 1 KiB scratch for wave_sum2, behind the rings
-    const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
-    const uint32_t scr_w = scr + lane * 8, scr_r = scr + lane * 16;
-
-    const double wgt = a.weight[(size_t)(a.t_base + t) * a.lanes + c * 64 + lane];
-
-    // Counters per weight bit-plane: three planes for the cov-weighted sums, two for the
-    // alt-weighted ones are kept apart (one v_bcnt_u32_b32 accumulates into them directly);
-    // the rare higher planes are shifted into plane 0 as they are counted.
-    uint32_t c0[FC], c1[FC], ch[FC], g00[FC], g01[FC], g10[FC], g11[FC], A0[FA], A1[FA];
-#pragma unroll
-    for (int k = 0; k < FC; ++k)
-        c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = 0;
-#pragma unroll
-    for (int k = 0; k < FA; ++k)
-        A0[k] = A1[k] = 0;
-
-    // the first pair must have landed (it was requested before the staging loads, so it has)
-    if (q_issue - 1 <= q_last)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // Where a segment's tile words sit in the ring and how far the ring must advance before the
-    // NEXT segment are precomputed by the host into each record's flag word (ring slot relative to
-    // the run's first pair), so the loop carries no tile/pair arithmetic:
-    //   flags = next slot (3) | next half (1) | pairs to advance (8) | rare planes (1) | last (1) | .. | ncov (8) | nalt (8)
-    uint32_t x_off = (tile0 & 1) * 8;                // ring byte offset of the current segment's words (slot 0)
-    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
-    const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
-    for (uint32_t s = 0; s < nseg; ++s, rec_addr += IBDG_REC_WORDS * 4) {
-        uint4 h0, h1;            // hot half of the record, the same in every lane
-        uint2 x;                 // this lane's haplotype words of the tile
-        IBDG_STAMP(tf0);
-        lds_fetch(h0, h1, x, rec_addr, ring_lane + x_off);
-        const uint32_t flags = __builtin_amdgcn_readfirstlane(h0.x);
-        IBDG_STAMP(tf1);
-        IBDG_ACC(t_fetch, tf0, tf1);
-        const uint32_t last = flags & (1u << 13);
-        // ---- advance the ring for the next segment: every pair left behind frees a slot, which is
-        // refilled NS pairs ahead; then its pair must have landed
-        const uint32_t adv = (flags >> 4) & 0xff;
-        if (adv) {
-            for (uint32_t i = 0; i < adv; ++i, ++q_issue)
-                if (q_issue <= q_last)
-                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
-                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
-            // the pair now at the head was issued NS-1 direct-to-LDS loads ago unless the run ends first
-            if (q_issue - 1 <= q_last)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;
-        IBDG_STAMP(td1);
-        IBDG_ACC(t_dma, tf1, td1);
-        const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;
-        const uint2 at = make_uint2(h1.z, h1.w);     // the target's two haplotype words of this tile
-#if IBDG_TIMING_EXPERIMENT
-        const bool count = !(a.debug & 2);
-#else
-        const bool count = true;
-#endif
-        const uint32_t hom = x.x & x.y;
-#define IBDG_COV_PLANE(k, cov)                                              \
-    {                                                                       \
-        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
-        c0[k] += __popc(u0);                                                \
-        c1[k] += __popc(u1);                                                \
-        ch[k] += __popc(hom & (cov));                                       \
-        g00[k] += __popc(u0 & at.x);                                        \
-        g01[k] += __popc(u1 & at.x);                                        \
-        g10[k] += __popc(u0 & at.y);                                        \
-        g11[k] += __popc(u1 & at.y);                                        \
-    }
-        if (count) {
-            // planes 0-2 of cov and 0-1 of alt are non-empty in nearly every segment: no test
-            // (an empty mask adds zero); higher planes are rare and go the slow way
-            IBDG_COV_PLANE(0, cov0)
-            IBDG_COV_PLANE(1, cov1)
-            IBDG_COV_PLANE(2, cov2)
-            A0[0] += __popc(x.x & alt0);
-            A1[0] += __popc(x.y & alt0);
-            A0[1] += __popc(x.x & alt1);
-            A1[1] += __popc(x.y & alt1);
-            if (flags & (1u << 12)) {                 // rare: weight bit-planes beyond the counted ones
-                const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;
-                for (uint32_t k = FC; k < ncov; ++k) {
-                    const uint32_t cov = lds_read_b32(rec_addr + (RC_COV3 - FC + k) * 4);
-                    const uint32_t u0 = x.x & cov, u1 = x.y & cov;
-                    c0[0] += (uint32_t)__popc(u0) << k;
-                    c1[0] += (uint32_t)__popc(u1) << k;
-                    ch[0] += (uint32_t)__popc(hom & cov) << k;
-                    g00[0] += (uint32_t)__popc(u0 & at.x) << k;
-                    g01[0] += (uint32_t)__popc(u1 & at.x) << k;
-                    g10[0] += (uint32_t)__popc(u0 & at.y) << k;
-                    g11[0] += (uint32_t)__popc(u1 & at.y) << k;
-                }
-                for (uint32_t k = FA; k < nalt; ++k) {
-                    const uint32_t alt = lds_read_b32(rec_addr + (RC_ALT2 - FA + k) * 4);
-                    A0[0] += (uint32_t)__popc(x.x & alt) << k;
-                    A1[0] += (uint32_t)__popc(x.y & alt) << k;
-                }
-            }
-        }
-#undef IBDG_COV_PLANE
-
-        IBDG_STAMP(tc1);
-        IBDG_ACC(t_count, td1, tc1);
-        if (last) {
-            const uint32_t w = __builtin_amdgcn_readfirstlane(lds_read_b32(rec_addr + RC_WIN * 4));
-#if IBDG_TIMING_EXPERIMENT
-            if (!(a.debug & 1))
-#endif
-            {
-                uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
-                lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
-                const int eK = (int)k0.x;
-                const uint32_t AT = k0.y;
-                const uint32_t a0cov = k0.z, a1cov = k0.w, b0 = k1.x, b1 = k1.y;   // b = AT - <t,alt>
-                const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
-                const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
-                const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
-                const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
-                uint32_t E2[5], E3[5];
-                E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
-                E3[1] = a0cov + C0 - 2 * G00;  E2[1] = b0 - a0 + G00;                // pDg[A0+h0] (:716)
-                E3[2] = a0cov + C1 - 2 * G01;  E2[2] = b0 - a1 + G01;                // pDg[A0+h1] (:717)
-                E3[3] = a1cov + C0 - 2 * G10;  E2[3] = b1 - a0 + G10;                // pDg[A1+h0] (:718)
-                E3[4] = a1cov + C1 - 2 * G11;  E2[4] = b1 - a1 + G11;                // pDg[A1+h1] (:719)
-                uint4 pw[10];
-                if (TAB_LDS) {
-                    uint32_t ad[10];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        ad[2 * i] = tab1 + E2[i] * 16;
-                        ad[2 * i + 1] = tab2 + E3[i] * 16;
-                    }
-                    lds_read_pow10(pw, ad);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        pw[2 * i] = pow_1me[E2[i]];
-                        pw[2 * i + 1] = pow_eps[E3[i]];
-                    }
-                }
-                const double P2 = ld_value(eK, pw[0], pw[1]);
-                const double Q00 = ld_value(eK, pw[2], pw[3]);
-                const double Q01 = ld_value(eK, pw[4], pw[5]);
-                const double Q10 = ld_value(eK, pw[6], pw[7]);
-                const double Q11 = ld_value(eK, pw[8], pw[9]);
-                double s0 = wgt * P2;                                   // :743
-                double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-                const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // lane 31: sum of s0, lane 63: of s1
-                if ((lane & 31) == 31)
-                    a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
-            }
-#pragma unroll
-            for (int k = 0; k < FC; ++k)
-                c0[k] = c1[k] = ch[k] = g00[k] = g01[k] = g10[k] = g11[k] = 0;
-#pragma unroll
-            for (int k = 0; k < FA; ++k)
-                A0[k] = A1[k] = 0;
-            IBDG_STAMP(tn1);
-            IBDG_ACC(t_fin, tc1, tn1);
-        }
-    }
-    // leave no direct-to-LDS load in flight when the wave ends
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if IBDG_TIMING_EXPERIMENT
-    if (a.stamps && lane == 0) {
-        const unsigned long long te = stamp();
-        unsigned long long *o = a.stamps + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 8;
-        o[0] = t_stage; o[1] = t_dma; o[2] = t_fetch; o[3] = t_count; o[4] = t_fin; o[5] = te - ts0; o[6] = nseg; o[7] = w1 - w0;
-    }
-#endif
 }
 
 // One segment: fetch its record and tile words, advance the ring, count.  OP is `=` for the first
@@ -638,7 +348,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         if (flags & (1u << 12)) {                                                                               \
             const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
             for (uint32_t k = FC; k < ncov; ++k) {                                                              \
-                const uint32_t cov = lds_read_b32(rec_addr + (RC_COV3 - FC + k) * 4);                           \
+                const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
                 const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
                 c0[0] += (uint32_t)__popc(u0) << k;                                                             \
                 c1[0] += (uint32_t)__popc(u1) << k;                                                             \
@@ -649,7 +359,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 g11[0] += (uint32_t)__popc(u1 & at.y) << k;                                                     \
             }                                                                                                   \
             for (uint32_t k = FA; k < nalt; ++k) {                                                              \
-                const uint32_t alt = lds_read_b32(rec_addr + (RC_ALT2 - FA + k) * 4);                           \
+                const uint32_t alt = segs[seg0 + s].alt[k];                                                     \
                 A0[0] += (uint32_t)__popc(x.x & alt) << k;                                                      \
                 A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
             }                                                                                                   \
@@ -659,7 +369,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     }
 
 template <int NS, bool TAB_LDS>
-__global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restrict__ t32,
+__global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
                                                      const uint32_t *__restrict__ rec_ready,
                                                      const WinConst *__restrict__ wconst,
@@ -713,9 +423,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
     {
         // plain contiguous copies (k_win_target prepared the LDS images): every load of a thread is
         // independent of the others, so the whole staging costs about one memory latency
-        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * 5;
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * (IBDG_REC_WORDS / 4);
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
-        for (uint32_t i = threadIdx.x; i < nseg * 5; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < nseg * (IBDG_REC_WORDS / 4); i += blockDim.x)
             rdst[i] = rsrc[i];
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
@@ -827,14 +537,12 @@ __global__ __launch_bounds__(512) void k_ld_popcount_peel(const uint4 *__restric
 // operations and order of k_ld_popcount, so the results are the same bits.
 //
 // LDS images (written by k_win_target_mt):
-//   segment, 12 + 2 TB + 4.. words: flags cov0 cov1 cov2 | alt0 alt1 - - | TB x {t0 t1} |
-//                                   window cov3..cov7 alt2..alt7            (IBDG_RECM_WORDS)
+//   segment, 8 + 2 TB words:        flags cov0 cov1 cov2 | alt0 alt1 - - | TB x {t0 t1}   (IBDG_RECM_WORDS)
 //   window, 8 + 4 TB words:         mK(2) eK CT | AT - - - | TB x {a0cov a1cov a0alt a1alt}
 // ---------------------------------------------------------------------------
 #define IBDG_MT 4
-#define IBDG_RECM_WORDS (8 + 2 * IBDG_MT + 12)
+#define IBDG_RECM_WORDS (8 + 2 * IBDG_MT)
 #define IBDG_WCM_WORDS (8 + 4 * IBDG_MT)
-enum { RM_TW = 8, RM_WIN = 8 + 2 * IBDG_MT, RM_COV3 = RM_WIN + 1, RM_ALT2 = RM_WIN + 6 };
 
 __global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__restrict__ rec_ready,
                                                        uint32_t *__restrict__ wc_ready)
@@ -858,9 +566,6 @@ __global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__re
             const uint2 ta = tile_words(tt[j], S.tile), tb = tile_words(tt[j + 1], S.tile);
             o[2 + j / 2] = make_uint4(ta.x, ta.y, tb.x, tb.y);
         }
-        o[2 + TB / 2] = make_uint4(S.win, S.cov[3], S.cov[4], S.cov[5]);
-        o[3 + TB / 2] = make_uint4(S.cov[6], S.cov[7], S.alt[2], S.alt[3]);
-        o[4 + TB / 2] = make_uint4(S.alt[4], S.alt[5], S.alt[6], S.alt[7]);
     }
     if ((i >> 3) < a.n_win) {
         const uint32_t w = i >> 3;
@@ -933,7 +638,7 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
                  : "memory");
 }
 
-// One segment for TB comparison individuals (OP as in IBDG_SEGMENT of k_ld_popcount_peel)
+// One segment for TB comparison individuals (OP as in IBDG_SEGMENT of k_ld_popcount)
 #define IBDG_COV_PLANE_MT(OP, k, cov)                                       \
     {                                                                       \
         const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
@@ -979,7 +684,7 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
         if (flags & (1u << 12)) {                                                                               \
             const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
             for (uint32_t k = FC; k < ncov; ++k) {                                                              \
-                const uint32_t cov = lds_read_b32(rec_addr + (RM_COV3 - FC + k) * 4);                           \
+                const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
                 const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
                 c0[0] += (uint32_t)__popc(u0) << k;                                                             \
                 c1[0] += (uint32_t)__popc(u1) << k;                                                             \
@@ -993,7 +698,7 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
                 }                                                                                               \
             }                                                                                                   \
             for (uint32_t k = FA; k < nalt; ++k) {                                                              \
-                const uint32_t alt = lds_read_b32(rec_addr + (RM_ALT2 - FA + k) * 4);                           \
+                const uint32_t alt = segs[seg0 + s].alt[k];                                                     \
                 A0[0] += (uint32_t)__popc(x.x & alt) << k;                                                      \
                 A1[0] += (uint32_t)__popc(x.y & alt) << k;                                                      \
             }                                                                                                   \
@@ -1220,7 +925,7 @@ template <int NS, bool TAB>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
 {
     const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 0);
-    auto kern = a.peel ? k_ld_popcount_peel<NS, TAB> : k_ld_popcount<NS, TAB>;
+    auto kern = k_ld_popcount<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
@@ -1236,6 +941,8 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (planes < 1 || planes > 8)
         return 1;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
+    if (a.ring_slots == 2)
+        return a.tab_in_lds ? launch_pop<2, true>(a, grid, st) : launch_pop<2, false>(a, grid, st);
     if (a.ring_slots == 3)
         return a.tab_in_lds ? launch_pop<3, true>(a, grid, st) : launch_pop<3, false>(a, grid, st);
     if (a.ring_slots == 4)
@@ -1275,6 +982,8 @@ int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
     if (a.n_win == 0 || n_groups == 0)
         return 0;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_groups);
+    if (a.ring_slots == 2)
+        return a.tab_in_lds ? launch_pop_mt<2, true>(a, grid, st) : launch_pop_mt<2, false>(a, grid, st);
     if (a.ring_slots == 3)
         return a.tab_in_lds ? launch_pop_mt<3, true>(a, grid, st) : launch_pop_mt<3, false>(a, grid, st);
     if (a.ring_slots == 4)

@@ -162,8 +162,8 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * 1 = strict, 2 = exponent counting, an error if not applicable);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
- * "ring_slots", "record_lds_bytes" (exponent-counting kernel; set before
- * ibdg_upload_sites), "peel" (0/1: which of its two loop forms); "multi_target" (0/1, default 1: with four or more
+  * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;
+ * set before ibdg_upload_sites); "multi_target" (0/1, default 1: with four or more
  * comparison individuals in one ibdg_run, groups of four share a workgroup of
  * the exponent-counting kernel -- same results, ~1.4x the throughput).  Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
