@@ -1,6 +1,6 @@
-# PMC pass over the LD kernel: usage tools/pmc_ld.sh <outdir> <IBDG_DEBUG> "<counters>"
+# PMC pass over the LD kernel: usage tools/pmc_ld.sh <outdir> 0 "<counters>"   (second argument unused, kept for old command lines)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-IBDG_DEBUG=$2 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $3 --output-format csv -d gpurun_out/$1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $3 --output-format csv -d gpurun_out/$1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$1.log 2>&1
 python - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(list)
