@@ -149,7 +149,8 @@ def synth(seed, L, N, cov_mean=2.0):
 
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("N,L,W", [(3, 257, 100), (64, 500, 100), (65, 300, 7), (100, 1500, 100),
-                                   (320, 700, 64), (321, 400, 100), (2504, 1200, 100), (700, 350, 350)])
+                                   (320, 700, 64), (321, 400, 100), (2504, 1200, 100), (700, 350, 350),
+                                   (1100, 300, 50), (5000, 260, 100)])      # 18 chunks: 3 groups of 6 waves; 79: 10 of 8
 def test_random_panels_against_oracle(oracle, N, L, W, variant):
     alle, nr, na = synth(1000 + N, L, N)
     targets = sorted({0, N // 2, N - 1})
