@@ -192,8 +192,8 @@ def traffic_bytes(args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)       # ~1 ms each; the clocks settle after ~30 steps
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=300)       # ~0.9 ms each; the clocks settle after ~30 steps
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--sites", type=int, default=4_000_000, help="SNP rows of the synthetic chromosome")
     ap.add_argument("--ids", type=int, default=2504)
     ap.add_argument("--window", type=int, default=100)
