@@ -47,7 +47,7 @@ static double opt_eps = 0.02, opt_min_qual = 0, opt_max_af = 1, opt_min_af = 0, 
 static unsigned opt_max_cov = 20;
 static int opt_window = 100;
 static const char *opt_sq = "UNKWN";
-static int opt_ld = 0, opt_plan = 0, in_impute = 0, in_vcf = 0;
+static int opt_ld = 0, opt_plan = 0, opt_summary_only = 0, in_impute = 0, in_vcf = 0;
 static int has_S = 0, has_s = 0, has_B = 0, has_A = 0, has_p = 0, has_v = 0, has_D = 0;
 static int opt_threads = 0;
 static const char *cache_fn = NULL, *dump_panel_fn = NULL;
@@ -55,6 +55,7 @@ static const char *cache_fn = NULL, *dump_panel_fn = NULL;
 static struct option longopts[] = {
     {"LD", no_argument, &opt_ld, 1},
     {"plan", no_argument, &opt_plan, 1},
+    {"summary-only", no_argument, &opt_summary_only, 1},
     {"rand-stream", required_argument, 0, 1000},
     {"devices", required_argument, 0, 1001},
     {"threads", required_argument, 0, 1002},
@@ -115,6 +116,8 @@ static void usage(int code)
           "                            (default: the CPUs available to the process, at most 16)\n"
           "  --panel-cache FILE        keep the bit-packed panel of the .hap file in FILE and reuse it\n"
           "                            while the .hap file is unchanged\n"
+          "  --summary-only            write the *.summary.txt files only (no per-site *.tab.txt files: the\n"
+          "                            per-site values are neither copied back from the device nor formatted)\n"
           "  --plan                    print the filtered rows and windows only (no device needed)\n"
           "  -h/--help\n\n"
           "Outputs <out>/<pileup-name>.<individual>.tab.txt with columns\n"
@@ -729,6 +732,7 @@ typedef struct {
     const uint32_t *targets;                 /* the batch */
     size_t n_targets, t_local;               /* its size; which of them this call is for */
     int do_upload, do_run;
+    int want_sites;                          /* 0: --summary-only, the per-site values stay on the device */
     const uint8_t *bg_count;
     int pu_id, ld;
     /* outputs, written at the slice's offsets of the comparison-wide arrays */
@@ -754,9 +758,10 @@ static void *shard_run(void *arg)
     j->w_last = malloc((j->n_win + 1) * 4);
     j->w_ncov = malloc((j->n_win + 1) * 4);
     j->win_ll = malloc((j->n_win + 1) * 24);
-    if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_site_af(j->eng, j->site_af + j->a) ||
-        ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a) ||
-        ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
+    if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
+        return NULL;
+    if (j->want_sites && (ibdg_get_site_af(j->eng, j->site_af + j->a) ||
+                          ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a)))
         return NULL;
     j->failed = 0;
     return NULL;
@@ -1062,6 +1067,7 @@ int main(int argc, char **argv)
                 memset(j, 0, sizeof *j);
                 j->eng = engs[d]; j->row = s_row; j->nr = s_nr; j->na = s_na; j->fo = s_fo;
                 j->a = cuts[d]; j->b = cuts[d + 1]; j->window = (unsigned)opt_window;
+                j->want_sites = !opt_summary_only;
                 if (batchable) {
                     const size_t b0 = ti - ti % TARGET_BATCH;
                     j->targets = targets.idx + b0;
@@ -1117,7 +1123,7 @@ int main(int argc, char **argv)
             if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
                 asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
                 exit(1);
-            tab = fopen(tab_fn, "w");
+            tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
             sum = fopen(sum_fn, "w");
             if (!tab || !sum) {
                 fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
@@ -1135,7 +1141,7 @@ int main(int argc, char **argv)
         fprintf(tab, "# CHR\trsID\tPOS\tREF\tALT\tAF\tDP\tSQ_NREF\tSQ_NALT\tGT_A0\tGT_A1\tLIBD0\tLIBD1\tLIBD2\n");
         if (!opt_plan)
             fprintf(sum, "# SEGMENT\tSTART\tEND\tLIBD0\tLIBD1\tLIBD2\tNUM_SITES\n");
-        {
+        if (!opt_summary_only) {
             fmt_job proto;
             memset(&proto, 0, sizeof proto);
             proto.cand = cand;

@@ -300,3 +300,17 @@ def test_cli_batches_comparison_individuals_when_their_site_lists_coincide(devic
             fn = f"UNKWN.{name}.{kind}.txt"
             a, b = _read(str(batch / fn)), _read(str(solo / fn))
             assert a[1:] == b[1:], fn
+
+
+@pytest.mark.gpu
+def test_cli_summary_only_writes_the_same_summary_files_and_no_tab_files(tmp_path):
+    """--summary-only (an addition to the reference's options, for all-against-all runs whose
+    per-site tables would be hundreds of GB): the summary files are the reference's, byte for byte."""
+    meta = G.cases("synA")
+    _run_full(meta["base_args"] + meta["cases"]["ld_default"] + ["--summary-only"], os.path.join(G.GOLD, "synA", "input"),
+              tmp_path)
+    ref = os.path.join(G.GOLD, "synA", "ld_default", "ref7")
+    want = sorted(f[:-3] for f in os.listdir(ref) if ".summary." in f)
+    assert sorted(os.listdir(tmp_path)) == want
+    for fn in want:
+        assert _read(str(tmp_path / fn)) == _read(os.path.join(ref, fn + ".gz")), fn
