@@ -85,6 +85,13 @@ if os.path.exists("/dev/kfd"):
     os.makedirs(o, exist_ok=True)
     dt = timed([exe, *base, "--LD", "-O", o, "--threads", "16", "--panel-cache", cache])   # cache written above
     out["end_to_end_LD"]["threads_16_panel_cache"] = {"s": round(dt, 3), "rows_per_s": round(rows / dt)}
+    # many comparison individuals against one pileup (BASELINE.json configs[4] shape): 64 of them, summary files only
+    o = os.path.join(work, "out_many")
+    os.makedirs(o, exist_ok=True)
+    many = ",".join(f"ind{7 + 5 * i}" for i in range(64))
+    dt = timed([exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", many, "--LD", "-O", o,
+                "--threads", "16", "--summary-only"])
+    out["end_to_end_LD"]["64_individuals_summary_only"] = {"s": round(dt, 3), "individual_rows_per_s": round(64 * rows / dt)}
     if os.path.exists(ref):
         o = os.path.join(work, "ref_out_ld")
         os.makedirs(o, exist_ok=True)
