@@ -540,8 +540,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 //   segment, 8 + 2 TB words:        flags cov0 cov1 cov2 | alt0 alt1 - - | TB x {t0 t1}   (IBDG_RECM_WORDS)
 //   window, 8 + 4 TB words:         mK(2) eK CT | AT - - - | TB x {a0cov a1cov a0alt a1alt}
 // ---------------------------------------------------------------------------
+#ifndef IBDG_MT
 #define IBDG_MT 4
-#define IBDG_RECM_WORDS (8 + 2 * IBDG_MT)
+#endif
+#define IBDG_RECM_WORDS (8 + 4 * ((IBDG_MT + 1) / 2))      /* target words padded to whole uint4 */
 #define IBDG_WCM_WORDS (8 + 4 * IBDG_MT)
 
 __global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__restrict__ rec_ready,
@@ -563,7 +565,8 @@ __global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__re
         o[1] = make_uint4(S.alt[0], S.alt[1], 0, 0);
 #pragma unroll
         for (int j = 0; j < TB; j += 2) {
-            const uint2 ta = tile_words(tt[j], S.tile), tb = tile_words(tt[j + 1], S.tile);
+            const uint2 ta = tile_words(tt[j], S.tile);
+            const uint2 tb = j + 1 < TB ? tile_words(tt[j + 1 < TB ? j + 1 : j], S.tile) : make_uint2(0, 0);
             o[2 + j / 2] = make_uint4(ta.x, ta.y, tb.x, tb.y);
         }
     }
@@ -672,7 +675,8 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
         }                                                                                                       \
         x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;                                                    \
         const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;                         \
-        const uint32_t tw[TB][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};                    \
+        const uint32_t tw4[4][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};                    \
+        const uint32_t (&tw)[4][2] = tw4;                                                                       \
         const uint32_t hom = x.x & x.y;                                                                         \
         IBDG_COV_PLANE_MT(OP, 0, cov0)                                                                          \
         IBDG_COV_PLANE_MT(OP, 1, cov1)                                                                          \
@@ -799,8 +803,18 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
             IBDG_SEGMENT_MT(+=)
         {
         const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
-        uint4 k0, k1;
-        lds_read2(k0, k1, wc_addr, wc_addr + 16);
+        static_assert(TB == 4, "the six-read statement below fetches 8 + 4*4 words");
+        uint4 k0, k1, kt4[4];                     // the window's constants of all TB individuals in one round trip
+        asm volatile("ds_read_b128 %0, %6\n\t"
+                     "ds_read_b128 %1, %6 offset:16\n\t"
+                     "ds_read_b128 %2, %6 offset:32\n\t"
+                     "ds_read_b128 %3, %6 offset:48\n\t"
+                     "ds_read_b128 %4, %6 offset:64\n\t"
+                     "ds_read_b128 %5, %6 offset:80\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(k0), "=&v"(k1), "=&v"(kt4[0]), "=&v"(kt4[1]), "=&v"(kt4[2]), "=&v"(kt4[3])
+                     : "v"(wc_addr)
+                     : "memory");
         const int eK = (int)k0.z;
         const uint32_t AT = k1.x;
         const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
@@ -819,7 +833,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
         }
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
-            const uint4 kt = lds_read_b128(wc_addr + 32 + j * 16);
+            const uint4 kt = kt4[j];
             const uint32_t a0cov = kt.x, a1cov = kt.y, a0alt = kt.z, a1alt = kt.w;
             const uint32_t G00 = planes_sum<FC>(gq[j][0]), G01 = planes_sum<FC>(gq[j][1]);
             const uint32_t G10 = planes_sum<FC>(gq[j][2]), G11 = planes_sum<FC>(gq[j][3]);

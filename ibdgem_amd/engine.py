@@ -9,7 +9,8 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libibdgem_hip.so")
+# IBDG_LIB: another build of the same ABI (used to A/B kernel variants on one box)
+LIB_PATH = os.environ.get("IBDG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libibdgem_hip.so")
 
 # every symbol include/ibdgem_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
