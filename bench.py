@@ -323,6 +323,17 @@ def main():
     dt_recount = (time.perf_counter() - t1) / 3
     alt_ms = eng.last_run_ms()["alt_count"]
     eng.set_option("count_in_run", 0)
+    # the survey's "engine clock": one run plus its results copied to host memory (not `value`)
+    eng.run(targets, ld=True)
+    t2 = time.perf_counter()
+    eng.run(targets, ld=True)
+    w_host = eng.window_ll(0)
+    t3 = time.perf_counter()
+    s_host = eng.site_ll(0)
+    t4 = time.perf_counter()
+    d2h = {"run_plus_window_results_ms": (t3 - t2) * 1e3, "per_site_results_ms": (t4 - t3) * 1e3,
+           "per_site_results_GBps": s_host.nbytes / (t4 - t3) / 1e9}
+    del w_host, s_host
     ld_variant = eng.last_ld_variant()
 
     tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64,
@@ -363,6 +374,7 @@ def main():
             "kernel_ms": kern,
             "host_queue_ms_per_step": dt_host / args.steps * 1e3,
             "alt_count_ms": alt_ms,
+            "results_to_host": d2h if world == 1 else None,
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
