@@ -44,6 +44,8 @@ struct ibdg_ctx {
     struct EvSet {
         hipEvent_t start_own = nullptr;     // recorded when the previous run's end cannot serve as start
         hipEvent_t ld_end = nullptr;        // main stream, after the last --LD launch
+        hipEvent_t k_start = nullptr, k_stop = nullptr;   // start / stop of the dominant --LD kernel's dispatch
+        bool has_kernel_times = false;
         hipEvent_t s2_start = nullptr;      // stream2: before its first kernel of the run
         hipEvent_t s2[3] = {};              // stream2: after alt-count, per-site, window-product kernels
         hipEvent_t start = nullptr;         // start_own or the previous run's ld_end
@@ -104,6 +106,9 @@ struct ibdg_ctx {
 
     // options
     long opt_count_in_run = 0;
+    long opt_dispatch_events = 0;   // 1: time the --LD launches through their own dispatch packets (hipExtLaunchKernel);
+                                    // gives the dominant kernel's own duration, but costs ~10 us per run more than
+                                    // one event record (measured), so it is off unless asked for
     long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
@@ -577,7 +582,7 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     for (auto &E : c->evs) {
-        for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
+        for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
     }
     {
@@ -617,7 +622,7 @@ void ibdg_destroy(ibdg_ctx *c)
                       &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &E : c->evs)
-        for (hipEvent_t ev : {E.start_own, E.ld_end, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
+        for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
             if (ev)
                 (void)hipEventDestroy(ev);
     if (c->stream2)
@@ -823,6 +828,15 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->prev_bg.assign(bg_count, bg_count + c->n_ids);
     }
 
+    bool use_pop = false;
+    if (ld_mode) {
+        const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
+        if (c->opt_variant == 2 && !can)
+            return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
+                           "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
+        use_pop = can && c->opt_variant != 1 && (c->opt_variant == 2 || c->pop_dense_enough);
+    }
+    c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     const bool recount = c->opt_count_in_run || !c->counts_valid;
     const int ev_slot = (c->ev_head + 1) % ibdg_ctx::EV_RING;      // becomes the head once the run is queued
     ibdg_ctx::EvSet &E = c->evs[ev_slot];
@@ -833,13 +847,25 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // the main stream does (a wait in stream2's queue costs the main stream nothing; it also orders
     // stream2 behind an upload of new targets); the main stream waits for stream2 when somebody
     // needs the results (join_streams), not once per run.
-    if (c->chain_ok && c->opt_async) {
-        E.start = c->evs[c->ev_head].ld_end;       // back-to-back runs: the previous end is this start
+    // Timing: normally one event record per run on the main stream (below).  With the option
+    // "dispatch_events" the exponent-counting launches carry events in their own dispatch packets
+    // instead (hipExtLaunchKernel: start of the first, stop of the last, and both of the dominant
+    // kernel -- the only way to time that kernel alone from inside the process).
+    const bool dispatch_events = use_pop && c->opt_dispatch_events && c->n_win > 0;
+    E.has_kernel_times = dispatch_events;
+    if (dispatch_events) {
+        E.start = E.start_own;                     // filled in by the first --LD dispatch
+        if (c->chain_ok && c->opt_async)           // stream2 keeps one run behind the main stream at most
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->evs[c->ev_head].ld_end, 0));
     } else {
-        HIP_TRY(c, hipEventRecord(E.start_own, c->stream));
-        E.start = E.start_own;
+        if (c->chain_ok && c->opt_async) {
+            E.start = c->evs[c->ev_head].ld_end;   // back-to-back runs: the previous end is this start
+        } else {
+            HIP_TRY(c, hipEventRecord(E.start_own, c->stream));
+            E.start = E.start_own;
+        }
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
 
     ibdg::SiteArgs sa;
     sa.panel = (const uint64_t *)c->panel.p;
@@ -857,15 +883,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.af = (double *)c->af.p;
     sa.site_ll = (double *)c->site_ll.p;
 
-    bool use_pop = false;
-    if (ld_mode) {
-        const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
-        if (c->opt_variant == 2 && !can)
-            return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
-                           "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
-        use_pop = can && c->opt_variant != 1 && (c->opt_variant == 2 || c->pop_dense_enough);
-    }
-    c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
     if (use_pop) {
         // Comparison individuals in groups of MT share one workgroup (and the counts that do not
         // depend on them) in k_ld_popcount_mt; what is left over goes one per workgroup.
@@ -905,18 +922,26 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
+        ibdg::KernelEvents first, dominant, last;  // all null unless dispatch_events
+        if (dispatch_events) {
+            first.start = E.start_own;
+            dominant.start = E.k_start;
+            dominant.stop = E.k_stop;
+            last.stop = E.ld_end;
+        }
         if (n_grp) {
             ibdg::PopArgs pm = pa;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
             pm.wc_ready = (const uint32_t *)c->wtarget_mt.p;
-            ibdg::launch_win_target_mt(pm, (unsigned)n_grp, c->stream);
-            if (ibdg::launch_ld_popcount_mt(pm, (unsigned)n_grp, c->stream))
+            ibdg::launch_win_target_mt(pm, (unsigned)n_grp, c->stream, first);
+            first = ibdg::KernelEvents();
+            if (ibdg::launch_ld_popcount_mt(pm, (unsigned)n_grp, c->stream, T_one ? ibdg::KernelEvents() : dominant))
                 return fail(c, "[::] ERROR in ibdg_run: the multi-target --LD kernel could not be launched");
         }
         if (T_one) {
             pa.t_base = (uint32_t)(n_grp * MT);
-            ibdg::launch_win_target(pa, (unsigned)T_one, c->stream);
-            if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream))
+            ibdg::launch_win_target(pa, (unsigned)T_one, c->stream, first);
+            if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream, dominant))
                 return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         }
         ibdg::PopFinalArgs fa;
@@ -926,7 +951,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         fa.n_chunks = c->n_chunks;
         fa.n_refpanel = (const int *)c->nrefpanel.p;
         fa.win_ll = (double *)c->win_ll.p;
-        ibdg::launch_ld_finalize(fa, (unsigned)T, c->stream);
+        ibdg::launch_ld_finalize(fa, (unsigned)T, c->stream, last);
     } else if (ld_mode) {
         ibdg::LdArgs la;
         la.panel = sa.panel;
@@ -944,7 +969,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
     }
-    HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
+    if (!dispatch_events)
+        HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
 
     // stream2, queued after the critical path so that the --LD launches reach the device first
     HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
@@ -1039,6 +1065,19 @@ int ibdg_run_ms(ibdg_ctx *c, unsigned back, float out[5])
     return 0;
 }
 
+int ibdg_run_kernel_ms(ibdg_ctx *c, unsigned back, float *ms)
+{
+    if (!c || !ms) return 1;
+    if (back + 1 >= (unsigned)ibdg_ctx::EV_RING || (long)back >= c->runs_done)
+        return fail(c, "[::] ERROR in ibdg_run_kernel_ms: no timing kept for the run %u calls back", back);
+    const ibdg_ctx::EvSet &E = c->evs[(c->ev_head + ibdg_ctx::EV_RING - (int)back) % ibdg_ctx::EV_RING];
+    if (!E.has_kernel_times)
+        return fail(c, "[::] ERROR in ibdg_run_kernel_ms: that run did not use the exponent-counting --LD kernel");
+    if (quiesce(c)) return 1;
+    HIP_TRY(c, hipEventElapsedTime(ms, E.k_start, E.k_stop));
+    return 0;
+}
+
 int ibdg_last_run_ms(ibdg_ctx *c, float out[5])
 {
     if (!c || !out) return 1;
@@ -1057,6 +1096,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
+    if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");

@@ -120,17 +120,21 @@ struct PopFinalArgs {
 
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
                         uint32_t n_pairs, uint32_t *t32, hipStream_t st);
-void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st);
-int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st);
+// events a dispatch updates with its own start / stop time (either may be null)
+struct KernelEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
+int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
                              int ring_slots, int multi_target);
 // groups of ld_popcount_mt_width() comparison individuals per workgroup (shared target-independent counts)
 int ld_popcount_mt_width(void);
 size_t ld_popcount_mt_rec_bytes(void);
 size_t ld_popcount_mt_wc_bytes(void);
-void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st);
-int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st);
-void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st);
+void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev = {});
+int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev = {});
+void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
 
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st);

@@ -34,6 +34,7 @@
 #include "ibdg_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 
 // LDS image of a segment (8 words, 16-byte aligned):
@@ -914,13 +915,15 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
                        n_rows, n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
 }
 
-void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st)
+// ev.start / ev.stop (may be null): events the dispatch itself updates with the kernel's start and
+// stop time (hipExtLaunchKernel) -- no event-record packet on the stream.
+void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev)
 {
     if (a.n_win == 0)
         return;
     const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
-    hipLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, a,
-                       const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+    hipExtLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a,
+                          const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
 }
 
 // LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
@@ -936,19 +939,20 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
 }
 
 template <int NS, bool TAB>
-static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st)
+static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st, KernelEvents ev)
 {
     const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 0);
     auto kern = k_ld_popcount<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
-                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), (uint32_t)lds, st, ev.start, ev.stop, 0,
+                          (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst, a.wc_ready, (const uint4 *)a.pow_1me,
+                          (const uint4 *)a.pow_eps, a.run_begin, a);
     return 0;
 }
 
-int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st)
+int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev)
 {
     if (a.n_win == 0)
         return 0;
@@ -956,12 +960,12 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
         return 1;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
     if (a.ring_slots == 2)
-        return a.tab_in_lds ? launch_pop<2, true>(a, grid, st) : launch_pop<2, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop<2, true>(a, grid, st, ev) : launch_pop<2, false>(a, grid, st, ev);
     if (a.ring_slots == 3)
-        return a.tab_in_lds ? launch_pop<3, true>(a, grid, st) : launch_pop<3, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop<3, true>(a, grid, st, ev) : launch_pop<3, false>(a, grid, st, ev);
     if (a.ring_slots == 4)
-        return a.tab_in_lds ? launch_pop<4, true>(a, grid, st) : launch_pop<4, false>(a, grid, st);
-    return a.tab_in_lds ? launch_pop<8, true>(a, grid, st) : launch_pop<8, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop<4, true>(a, grid, st, ev) : launch_pop<4, false>(a, grid, st, ev);
+    return a.tab_in_lds ? launch_pop<8, true>(a, grid, st, ev) : launch_pop<8, false>(a, grid, st, ev);
 }
 
 // The same for groups of IBDG_MT comparison individuals (a.t_base = first of them, n_groups groups)
@@ -969,47 +973,48 @@ int ld_popcount_mt_width(void) { return IBDG_MT; }
 size_t ld_popcount_mt_rec_bytes(void) { return IBDG_RECM_WORDS * 4; }
 size_t ld_popcount_mt_wc_bytes(void) { return IBDG_WCM_WORDS * 4; }
 
-void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
+void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev)
 {
     if (a.n_win == 0 || n_groups == 0)
         return;
     const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
-    hipLaunchKernelGGL(k_win_target_mt, dim3((n + 255) / 256, n_groups), dim3(256), 0, st, a,
-                       const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+    hipExtLaunchKernelGGL(k_win_target_mt, dim3((n + 255) / 256, n_groups), dim3(256), 0, st, ev.start, ev.stop, 0, a,
+                          const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
 }
 
 template <int NS, bool TAB>
-static int launch_pop_mt(const PopArgs &a, dim3 grid, hipStream_t st)
+static int launch_pop_mt(const PopArgs &a, dim3 grid, hipStream_t st, KernelEvents ev)
 {
     const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 1);
     auto kern = k_ld_popcount_mt<NS, TAB>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), lds, st, (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst,
-                       a.wc_ready, (const uint4 *)a.pow_1me, (const uint4 *)a.pow_eps, a.run_begin, a);
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * a.waves_per_group), (uint32_t)lds, st, ev.start, ev.stop, 0,
+                          (const uint4 *)a.t32, a.segs, a.rec_ready, a.wconst, a.wc_ready, (const uint4 *)a.pow_1me,
+                          (const uint4 *)a.pow_eps, a.run_begin, a);
     return 0;
 }
 
-int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st)
+int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev)
 {
     if (a.n_win == 0 || n_groups == 0)
         return 0;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_groups);
     if (a.ring_slots == 2)
-        return a.tab_in_lds ? launch_pop_mt<2, true>(a, grid, st) : launch_pop_mt<2, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop_mt<2, true>(a, grid, st, ev) : launch_pop_mt<2, false>(a, grid, st, ev);
     if (a.ring_slots == 3)
-        return a.tab_in_lds ? launch_pop_mt<3, true>(a, grid, st) : launch_pop_mt<3, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop_mt<3, true>(a, grid, st, ev) : launch_pop_mt<3, false>(a, grid, st, ev);
     if (a.ring_slots == 4)
-        return a.tab_in_lds ? launch_pop_mt<4, true>(a, grid, st) : launch_pop_mt<4, false>(a, grid, st);
-    return a.tab_in_lds ? launch_pop_mt<8, true>(a, grid, st) : launch_pop_mt<8, false>(a, grid, st);
+        return a.tab_in_lds ? launch_pop_mt<4, true>(a, grid, st, ev) : launch_pop_mt<4, false>(a, grid, st, ev);
+    return a.tab_in_lds ? launch_pop_mt<8, true>(a, grid, st, ev) : launch_pop_mt<8, false>(a, grid, st, ev);
 }
 
-void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st)
+void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev)
 {
     if (a.n_win == 0)
         return;
-    hipLaunchKernelGGL(k_ld_finalize, dim3((a.n_win + 3) / 4, n_targets), dim3(256), 0, st, a);
+    hipExtLaunchKernelGGL(k_ld_finalize, dim3((a.n_win + 3) / 4, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a);
 }
 
 }  // namespace ibdg

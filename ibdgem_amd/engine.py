@@ -37,6 +37,7 @@ SYMBOLS = {
     "ibdg_get_alt_counts": (C.c_int, [_P, C.c_size_t, C.c_size_t, _P]),
     "ibdg_last_run_ms": (C.c_int, [_P, _P]),
     "ibdg_run_ms": (C.c_int, [_P, C.c_uint, _P]),
+    "ibdg_run_kernel_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_last_ld_variant": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "ibdg_sync": (C.c_int, [_P]),
@@ -201,6 +202,12 @@ class Engine:
         out = (C.c_float * 5)()
         self._chk(self.lib.ibdg_run_ms(self.ctx, back, out))
         return dict(total=out[0], alt_count=out[1], site=out[2], ld=out[3], window=out[4])
+
+    def run_kernel_ms(self, back=0):
+        """Duration of the dominant --LD kernel of the run `back` calls ago (its own dispatch times)."""
+        out = C.c_float()
+        self._chk(self.lib.ibdg_run_kernel_ms(self.ctx, back, C.byref(out)))
+        return out.value
 
     def last_ld_variant(self):
         return self.lib.ibdg_last_ld_variant(self.ctx)

@@ -149,12 +149,19 @@ int ibdg_last_run_ms(ibdg_ctx *ctx, float out[5]);
  * way to time runs issued with the "async" option after ibdg_sync. */
 int ibdg_run_ms(ibdg_ctx *ctx, unsigned back, float out[5]);
 
+/* Duration (ms) of the dominant --LD kernel alone in that run (k_ld_popcount, or its
+ * multi-individual form), from the start / stop times of its own dispatch packet.  An error if the
+ * run used the strict kernel or was not an --LD run. */
+int ibdg_run_kernel_ms(ibdg_ctx *ctx, unsigned back, float *ms);
+
 /* Which --LD kernel the last ibdg_run used: 0 none (non-LD), 1 the strict
  * kernel (sequential fp64 products in the reference's order), 2 the
  * exponent-counting kernel (same values to ~1e-14). */
 int ibdg_last_ld_variant(const ibdg_ctx *ctx);
 
-/* Options: "async" (0/1: ibdg_run returns as soon as its kernels are queued;
+/* Options: "dispatch_events" (0/1: time the --LD launches through their own
+ * dispatch packets, which makes ibdg_run_kernel_ms available; costs ~10 us per
+ * run more than the default single event record); "async" (0/1: ibdg_run returns as soon as its kernels are queued;
  * ibdg_sync, ibdg_run_ms and every ibdg_get_* wait for them -- lets a caller
  * queue one run per comparison individual without a host round trip between
  * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,

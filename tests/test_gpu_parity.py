@@ -483,3 +483,31 @@ def test_sparse_pileup_rows_far_apart(oracle):
             res = oracle.compare(alle[keep], nrk, nak, 7, window=100, ld=True)
             assert_bits(eng.site_ll(0), res["site"], "site")
             assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"sparse variant={variant}")
+
+
+def test_dispatch_events_give_the_dominant_kernel_duration():
+    """Option "dispatch_events": the --LD launches are timed through their own dispatch packets; the
+    dominant kernel's duration lies inside the interval of the --LD launches, results unchanged."""
+    N, L = 300, 4000
+    alle, nr, na = synth(77, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([5], ld=True)
+        want = eng.window_ll(0)
+        with pytest.raises(E.EngineError, match="did not use"):
+            eng.set_option("ld_variant", 1)
+            eng.run([5], ld=True)
+            eng.run_kernel_ms(0)
+        eng.set_option("ld_variant", 0)
+        eng.set_option("dispatch_events", 1)
+        for async_mode in (0, 1):
+            eng.set_option("async", async_mode)
+            for _ in range(3):
+                eng.run([5], ld=True)
+            eng.sync()
+            for back in range(3):
+                k, ms = eng.run_kernel_ms(back), eng.run_ms(back)
+                assert 0 < k <= ms["ld"] <= ms["total"] + 1e-3, (k, ms)
+            assert_bits(eng.window_ll(0), want, "dispatch events")
+        eng.set_option("async", 0)

@@ -26,3 +26,7 @@ for rep in range(3):
     print(f"rep {rep}: queue {1e3*(t1-t0):.2f} ms, total {1e3*(t2-t0):.2f} ms, per step {1e3*(t2-t0)/steps:.4f}; "
           f"sum of ld intervals {sum(ms):.3f}")
     print("  ", " ".join(f"{m:.3f}" for m in ms))
+    try:
+        print("   kernel only:", " ".join(f"{eng.run_kernel_ms(b):.3f}" for b in range(min(steps, 32)))[:400])
+    except ibdgem_amd.EngineError as e:
+        print("   (no kernel-only times:", e, ")")
