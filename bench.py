@@ -396,7 +396,7 @@ def main():
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N=1 only
             s = sample_rows
             eng.upload_sites(np.arange(s, dtype=np.uint32), n_ref[:s], n_alt[:s], args.window)
             eng.run(targets, ld=True)
