@@ -400,8 +400,13 @@ int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t
             }
             ct += cv;
             at += a;
-            K = me_norm(K.m * (long double)c->nck_h[(size_t)cv * d + r], K.e);
+            // the coefficients are < 2^64 each: 64 of them cannot overflow a long double mantissa/exponent
+            // pair, so the (exact, power-of-two) renormalisation is needed only now and then
+            K.m *= (long double)c->nck_h[(size_t)cv * d + r];
+            if (((j - b) & 63) == 63)
+                K = me_norm(K.m, K.e);
         }
+        K = me_norm(K.m, K.e);
         segs.back().last = 1;
         // K' = K * (1-eps)^(all reads of the window): with it a product is K' * rho^E2 * sigma^E3,
         // rho = eps/(1-eps), sigma = 1/(2(1-eps))  (E1 = reads - E2 - E3 eliminated)

@@ -1,0 +1,14 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+import bench, ibdgem_amd
+dev = torch.device("cuda", 0)
+rows = 4_000_000
+panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
+eng = ibdgem_amd.Engine(0, 0.02, 20)
+t0 = time.perf_counter(); eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], 2504); t1 = time.perf_counter()
+print("upload_panel_dev (transpose + alt counts)", round(t1 - t0, 4), "s")
+idx = np.arange(rows, dtype=np.uint32)
+for _ in range(2):
+    t0 = time.perf_counter(); eng.upload_sites(idx, n_ref, n_alt, 100); t1 = time.perf_counter()
+    print("upload_sites 4M rows", round(t1 - t0, 4), "s")
