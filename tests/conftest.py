@@ -9,18 +9,6 @@ import sys
 
 import pytest
 
-# torch (used by the full-size tests and bench.py to generate synthetic panels on the device)
-# ships its own HIP runtime; load it before libibdgem_hip.so pulls in the system one, otherwise
-# the second runtime in the process sees no device.
-# Only where a GPU exists (/dev/kfd): on a CPU-only machine two HIP runtimes in one process abort
-# at the first device query, and nothing there needs torch before the library.
-if os.path.exists("/dev/kfd"):
-    try:
-        import torch
-        torch.cuda.is_available()
-    except Exception:                               # pragma: no cover
-        pass
-
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -28,25 +16,18 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-# On a machine without a GPU the HIP runtime that libibdgem_hip.so links against has nothing to talk
-# to, and its exit-time teardown has been seen to abort (once in ~15 runs) AFTER every test had
-# passed and the summary was printed -- turning a green run into exit code 134.  The CPU tier
-# therefore leaves through os._exit with pytest's own status once reporting is done; where a GPU
-# exists the normal interpreter shutdown is kept.
-_exit_status = [None]
-
-
-def pytest_sessionfinish(session, exitstatus):
-    _exit_status[0] = int(exitstatus)
-
-
-def pytest_unconfigure(config):
-    if _exit_status[0] is not None and not os.path.exists("/dev/kfd"):
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(_exit_status[0])
+    # GPU runtimes are brought up only for sessions that can run GPU tests (a GPU exists and the
+    # selection is not `-m "not gpu"`).  torch (used by the full-size tests to generate panels on the
+    # device) ships its own HIP runtime and must be loaded before libibdgem_hip.so pulls in the system
+    # one, otherwise the second runtime of the process sees no device.  A `-m "not gpu"` session stays
+    # free of any initialised runtime even on a GPU box.
+    markexpr = config.getoption("markexpr", "") or ""
+    if os.path.exists("/dev/kfd") and "not gpu" not in markexpr:
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:                           # pragma: no cover
+            pass
 
 
 @pytest.fixture(scope="session")

@@ -76,8 +76,9 @@ def test_row_packing(n_ids):
         out = np.zeros(rows.shape[1], dtype=np.uint64)
         assert lib.ibdg_pack_hap_text(text, n_ids, out.ctypes.data) == 0
         assert (out == rows[i]).all()
-    out = np.zeros(rows.shape[1], dtype=np.uint64)
+    out = np.zeros(lib.ibdg_row_words(n_ids + 1), dtype=np.uint64)       # the row is cleared at the width asked for
     assert lib.ibdg_pack_hap_text(b"0 1", n_ids + 1, out.ctypes.data) == 1          # too short
+    out = np.zeros(rows.shape[1], dtype=np.uint64)
     if n_ids >= 3:
         bad = bytearray(" ".join(map(str, alle[0])).encode())
         bad[4] = ord("2")
@@ -85,8 +86,8 @@ def test_row_packing(n_ids):
 
 
 def test_create_fails_loudly_without_a_device():
-    """Asks the HIP runtime for devices, so it runs in a process of its own: the test session itself
-    never initialises a runtime that has no device to talk to."""
+    """Asks the HIP runtime for devices; runs in a process of its own so that a `-m "not gpu"` session
+    never initialises a GPU runtime."""
     code = (
         "import sys; sys.path.insert(0, %r)\n"
         "from ibdgem_amd import engine as E\n"
