@@ -1,0 +1,105 @@
+"""Randomised END-TO-END comparison with the unmodified reference binary on a GPU box (needs
+oracle/_ref/ibdgem, which travels with the snapshot): random small panels and pileups with awkward
+rows, random flags (--LD in two of three cases, -v -D -M -F -f -w -e -c -p -A -B -N), then the full
+host program against the reference: every output file byte for byte after the command line.
+
+    python tools/fuzz_cli_full.py [n_cases] [seed]
+"""
+import os, random, subprocess, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import golden_io as G
+
+REF = os.path.join(REPO, "oracle", "_ref", "ibdgem")
+EXE = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+compared = rows_compared = 0
+for case in range(n_cases):
+    with tempfile.TemporaryDirectory() as d:
+        N = random.choice([1, 2, 5, 17, 40])
+        L = random.randint(1, 250)
+        names = [f"s{n}" for n in range(N)]
+        pos = sorted(random.sample(range(100, 100 + 12 * L + 50), L))
+        letters = "ACGT"
+        with open(os.path.join(d, "p.hap"), "w") as hf, open(os.path.join(d, "p.legend"), "w") as lf:
+            lf.write("id position a0 a1\n")
+            for p in pos:
+                f = random.choice([0.02, 0.2, 0.5, 0.9])
+                hf.write(" ".join(random.choices("01", weights=[1 - f, f], k=2 * N)) + "\n")
+                r = random.random()
+                if r < 0.05:
+                    ref, alt = "AT", "A"                       # indel: not a SNP
+                elif r < 0.08:
+                    ref, alt = "a", "G"                        # lower case: not a SNP
+                elif r < 0.10:
+                    ref, alt = "N", "C"
+                else:
+                    ref, alt = random.sample(letters, 2)
+                lf.write(f"rs{p} {p} {ref} {alt}\n")
+        with open(os.path.join(d, "p.indv"), "w") as fh:
+            fh.write("".join(n + "\n" for n in names))
+        chrom = random.choice(["1", "chr7"])
+        with open(os.path.join(d, "p.pileup"), "w") as fh:
+            for p in sorted(set(pos + random.sample(range(100, 100 + 12 * L + 50), max(1, L // 3)))):
+                if random.random() < 0.15:
+                    continue                                   # no pileup line at this position
+                cov = random.choice([0, 0, 1, 1, 2, 3, 5, 9, 25])
+                bases = "".join(random.choices("ACGTacgtN", k=cov)) if cov else "*"
+                q = "I" * cov if cov else "*"
+                fh.write(f"{chrom}\t{p}\tN\t{cov}\t{bases}\t{q}\t{q}\n")
+        args = ["-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup"]
+        if random.random() < 0.4: args += ["-v"]
+        if random.random() < 0.3: args += ["-D", random.choice(["0.5", "1.0", "3"])]
+        if random.random() < 0.4: args += ["-M", random.choice(["1", "3", "8", "30"])]
+        if random.random() < 0.3: args += ["-F", random.choice(["0.9", "0.5"])]
+        if random.random() < 0.3: args += ["-f", random.choice(["0.05", "0.3"])]
+        if random.random() < 0.6: args += ["-w", random.choice(["2", "3", "10", "64"])]
+        if random.random() < 0.2: args += ["-e", random.choice(["0.1", "0.001"])]
+        if random.random() < 0.3: args += ["-c", chrom]
+        if random.random() < 0.3: args += ["-N", random.choice(names + ["other"])]
+        if random.random() < 0.3:
+            with open(os.path.join(d, "pos.txt"), "w") as fh:
+                for p in random.sample(pos, max(1, L // 2)):
+                    fh.write(f"{chrom}\t{p}\n")
+            args += ["-p", "pos.txt"]
+        if random.random() < 0.3:
+            with open(os.path.join(d, "af.txt"), "w") as fh:
+                for p in sorted(random.sample(pos, max(1, L // 2))):
+                    fh.write(f"{chrom}\t{p}\t{random.random():.4f}\n")
+            args += ["-A", "af.txt"]
+        if random.random() < 0.3 and N > 1:
+            with open(os.path.join(d, "bg.txt"), "w") as fh:
+                fh.write("".join(n + "\n" for n in random.choices(names, k=random.randint(1, N))))
+            args += ["-B", "bg.txt"]
+        if random.random() < 0.67: args = ["--LD"] + args
+        targets = random.sample(names, random.randint(1, min(3, N)))
+        args += ["-s", ",".join(targets)]
+        sq = args[args.index("-N") + 1] if "-N" in args else "UNKWN"
+        out, out2 = os.path.join(d, "out"), os.path.join(d, "out2")
+        os.makedirs(out)
+        os.makedirs(out2)
+        r = subprocess.run([REF, *args, "-O", out], cwd=d, capture_output=True, text=True)
+        o = subprocess.run([EXE, *args, "-O", out2], cwd=d, capture_output=True, text=True)
+        try:
+            assert r.returncode == o.returncode, (r.returncode, o.returncode, r.stderr[-200:], o.stderr[-200:])
+            if r.returncode == 0:
+                assert sorted(os.listdir(out)) == sorted(os.listdir(out2))
+                for fn in sorted(os.listdir(out)):
+                    a_, b_ = open(os.path.join(out, fn)).read().split("\n"), open(os.path.join(out2, fn)).read().split("\n")
+                    if fn.endswith(".tab.txt"):
+                        a_, b_ = a_[1:], b_[1:]
+                    if a_ != b_:
+                        k = next(i for i, (x, y) in enumerate(zip(a_, b_)) if x != y) if len(a_) == len(b_) else -1
+                        raise AssertionError(f"{fn} differs at line {k}: {a_[k] if k >= 0 else len(a_)} | {b_[k] if k >= 0 else len(b_)}")
+                    compared += 1
+                    rows_compared += len(a_)
+        except Exception as e:                            # noqa: BLE001
+            bad += 1
+            print("MISMATCH case", case, " ".join(args), repr(e)[:400], flush=True)
+            if bad > 5:
+                break
+print(f"full CLI fuzz: {n_cases} cases, {compared} output files identical ({rows_compared} lines), {bad} failures")
+sys.exit(1 if bad else 0)
