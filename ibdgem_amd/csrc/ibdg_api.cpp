@@ -112,7 +112,10 @@ struct ibdg_ctx {
     long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
-    long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting
+    long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting, 3 strict products + serial sums in
+                           // the reference's order (bit-identical --LD columns)
+    std::vector<uint32_t> bg_order;   // optional: the background list in the reference's order (ibdg_set_background_order)
+    DevBuf vals, order;
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
@@ -624,7 +627,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->pow1, &c->pow2, &c->partial})
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial})
         release(*b);
     for (auto &E : c->evs)
         for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
@@ -839,9 +842,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (c->opt_variant == 2 && !can)
             return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
                            "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
-        use_pop = can && c->opt_variant != 1 && (c->opt_variant == 2 || c->pop_dense_enough);
+        use_pop = can && c->opt_variant != 1 && c->opt_variant != 3 && (c->opt_variant == 2 || c->pop_dense_enough);
     }
-    c->last_variant = ld_mode ? (use_pop ? 2 : 1) : 0;
+    c->last_variant = ld_mode ? (use_pop ? 2 : (c->opt_variant == 3 ? 3 : 1)) : 0;
     const bool recount = c->opt_count_in_run || !c->counts_valid;
     const int ev_slot = (c->ev_head + 1) % ibdg_ctx::EV_RING;      // becomes the head once the run is queued
     ibdg_ctx::EvSet &E = c->evs[ev_slot];
@@ -971,7 +974,49 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         la.weight = (const double *)c->weight.p;
         la.n_refpanel = (const int *)c->nrefpanel.p;
         la.win_ll = (double *)c->win_ll.p;
-        if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
+        la.t_base = 0;
+        la.vals = nullptr;
+        if (c->opt_variant == 3) {
+            // reference order: per comparison individual, the per-individual products of every window,
+            // then serial sums over the background list in the reference's order
+            std::vector<uint32_t> order;
+            if (!c->bg_order.empty()) {
+                order = c->bg_order;               // checked against bg_count below
+                std::vector<unsigned> cnt(c->n_ids, 0);
+                for (uint32_t n : order) {
+                    if (n >= c->n_ids)
+                        return fail(c, "[::] ERROR in ibdg_run: background order names individual %u of %u", n, c->n_ids);
+                    cnt[n]++;
+                }
+                for (unsigned n = 0; n < c->n_ids; ++n)
+                    if (cnt[n] != (bg_count ? bg_count[n] : 1u))
+                        return fail(c, "[::] ERROR in ibdg_run: background order and bg_count disagree for individual %u", n);
+            } else {
+                for (unsigned n = 0; n < c->n_ids; ++n)
+                    for (unsigned k = bg_count ? bg_count[n] : 1u; k > 0; --k)
+                        order.push_back(n);
+            }
+            if (ensure(c, c->vals, (size_t)c->n_win * lanes * 16) || ensure(c, c->order, order.size() * 4))
+                return 1;
+            HIP_TRY(c, hipMemcpyAsync(c->order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));        // `order` is a local
+            la.vals = (double2 *)c->vals.p;
+            for (size_t t = 0; t < T; ++t) {
+                la.t_base = (uint32_t)t;
+                if (ibdg::launch_ld(la, 1, c->cpw, (unsigned)c->opt_waves, c->stream))
+                    return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
+                ibdg::OrdArgs oa;
+                oa.vals = la.vals;
+                oa.lanes = (uint32_t)lanes;
+                oa.n_win = c->n_win;
+                oa.order = (const uint32_t *)c->order.p;
+                oa.n_order = (uint32_t)order.size();
+                oa.target = targets[t];
+                oa.pu_id = pu_id;
+                oa.win_ll = (double *)c->win_ll.p + t * (size_t)c->n_win * 3;
+                ibdg::launch_ld_ordered_sum(oa, c->stream);
+            }
+        } else if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
     }
     if (!dispatch_events)
@@ -1112,7 +1157,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_waves = value; return 0;
     }
     if (!strcmp(name, "ld_variant")) {
-        if (value < 0 || value > 2) return fail(c, "[::] ERROR in ibdg_set_option: ld_variant must be 0 (auto), 1 (strict) or 2 (exponent counting)");
+        if (value < 0 || value > 3) return fail(c, "[::] ERROR in ibdg_set_option: ld_variant must be 0 (auto), 1 (strict), 2 (exponent counting) or 3 (reference order)");
         c->opt_variant = value; return 0;
     }
     if (!strcmp(name, "ring_slots")) {
@@ -1128,6 +1173,14 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_wpg = value; c->opt_wpg_fixed = true; return 0;
     }
     return fail(c, "[::] ERROR in ibdg_set_option: unknown option '%s'", name);
+}
+
+int ibdg_set_background_order(ibdg_ctx *c, const uint32_t *ids, size_t n)
+{
+    if (!c) return 1;
+    if (n && !ids) return fail(c, "[::] ERROR in ibdg_set_background_order: ids is NULL");
+    c->bg_order.assign(ids, ids + n);
+    return 0;
 }
 
 int ibdg_sync(ibdg_ctx *c)

@@ -48,7 +48,23 @@ struct LdArgs {
     const double *weight;       // [T][n_groups*CPW*64] background multiplicity (0 = excluded)
     const int *n_refpanel;      // [T]
     double *win_ll;             // [T][n_win][3]
+    uint32_t t_base;            // comparison individual of blockIdx.y == 0
+    double2 *vals;              // reference-order mode: [n_win][lanes] {P2, (Q00+Q01)+Q10)+Q11} per background
+                                // individual of ONE comparison individual, written instead of the window sums
 };
+
+// Reference-order mode (ld_variant 3): the window averages of src/ibdgem.c:736-753 summed serially over
+// the background list in the reference's own order, from the per-individual products of k_ld_window.
+struct OrdArgs {
+    const double2 *vals;        // [n_win][lanes]
+    uint32_t lanes, n_win;
+    const uint32_t *order;      // [n_order] background individuals in list order (duplicates kept)
+    uint32_t n_order;
+    uint32_t target;            // individual excluded as the comparison individual
+    int pu_id;                  // individual excluded as the pileup's own, or -1
+    double *win_ll;             // this comparison individual's [n_win][3]
+};
+void launch_ld_ordered_sum(const OrdArgs &a, hipStream_t st);
 
 // ---- fast --LD variant: exponent counting on the tile-transposed panel -------------------
 // One segment = the covered rows of ONE window that fall into ONE 32-row tile.

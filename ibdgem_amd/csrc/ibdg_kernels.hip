@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned n_waves = blockDim.x >> 6;
     const unsigned lane = threadIdx.x & 63;
-    const unsigned w = blockIdx.x, t = blockIdx.y;
+    const unsigned w = blockIdx.x, t = blockIdx.y + a.t_base;
 
     const uint32_t begin = w * a.window;
     const uint32_t end = min(begin + a.window, a.n_cov);
@@ -251,6 +251,13 @@ __global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
             const uint64_t *m = row + 2 * CPW * g;
             ld_site<CPW>(m, A0, A1, p00, p01, p11, P2, Q00, Q01, Q10, Q11);
         }
+        if (a.vals) {          // reference-order mode: hand the per-individual values to k_ld_ordered_sum
+#pragma unroll
+            for (int c = 0; c < CPW; ++c)
+                a.vals[(size_t)w * a.n_groups * CPW * 64 + (g * CPW + c) * 64 + lane] =
+                    make_double2(P2[c], ((Q00[c] + Q01[c]) + Q10[c]) + Q11[c]);      // src/ibdgem.c:744-745
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const double cnt = wt[(g * CPW + c) * 64 + lane];
@@ -258,6 +265,8 @@ __global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
             s1 += cnt * (((Q00[c] + Q01[c]) + Q10[c]) + Q11[c]);
         }
     }
+    if (a.vals)
+        return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s0 += __shfl_xor(s0, off);
@@ -279,6 +288,39 @@ __global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
         o[0] = t0 / (double)nref;               // src/ibdgem.c:752
         o[1] = t1 / (double)(nref * 4);
     }
+}
+
+// Reference-order sums (src/ibdgem.c:741-750): one thread per window walks the background list in
+// the reference's order with two serial double accumulators, skipping the comparison individual
+// and the pileup's own sample and counting what is left -- the same additions in the same order
+// as the reference, hence the same bits.
+__global__ __launch_bounds__(64) void k_ld_ordered_sum(OrdArgs a)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.n_win)
+        return;
+    const double2 *v = a.vals + (size_t)w * a.lanes;
+    double s0 = 0.0, s1 = 0.0;
+    int n_refpanel = (int)a.n_order;
+    for (uint32_t k = 0; k < a.n_order; ++k) {
+        const uint32_t n = a.order[k];
+        if ((int)n != a.pu_id && n != a.target) {
+            const double2 x = v[n];
+            s0 += x.x;
+            s1 += x.y;
+        } else {
+            n_refpanel--;
+        }
+    }
+    a.win_ll[(size_t)w * 3] = s0 / n_refpanel;                 // :752
+    a.win_ll[(size_t)w * 3 + 1] = s1 / (n_refpanel * 4);
+}
+
+void launch_ld_ordered_sum(const OrdArgs &a, hipStream_t st)
+{
+    if (a.n_win == 0)
+        return;
+    hipLaunchKernelGGL(k_ld_ordered_sum, dim3((a.n_win + 63) / 64), dim3(64), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -40,6 +40,7 @@ SYMBOLS = {
     "ibdg_run_kernel_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_last_ld_variant": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
+    "ibdg_set_background_order": (C.c_int, [_P, _P, C.c_size_t]),
     "ibdg_sync": (C.c_int, [_P]),
 }
 
@@ -208,6 +209,11 @@ class Engine:
         out = C.c_float()
         self._chk(self.lib.ibdg_run_kernel_ms(self.ctx, back, C.byref(out)))
         return out.value
+
+    def set_background_order(self, ids):
+        """Background list in the reference's order (reference-order mode); None/empty clears it."""
+        a = np.ascontiguousarray([] if ids is None else ids, dtype=np.uint32)
+        self._chk(self.lib.ibdg_set_background_order(self.ctx, a.ctypes.data if len(a) else None, len(a)))
 
     def last_ld_variant(self):
         return self.lib.ibdg_last_ld_variant(self.ctx)

@@ -156,7 +156,10 @@ int ibdg_run_kernel_ms(ibdg_ctx *ctx, unsigned back, float *ms);
 
 /* Which --LD kernel the last ibdg_run used: 0 none (non-LD), 1 the strict
  * kernel (sequential fp64 products in the reference's order), 2 the
- * exponent-counting kernel (same values to ~1e-14). */
+ * exponent-counting kernel (same values to ~1e-14), 3 the
+ * reference-order mode (strict products, then the background sums taken
+ * serially in the reference's order: LIBD0/LIBD1 of every window bit-identical
+ * to the reference; ~12x the time of 2). */
 int ibdg_last_ld_variant(const ibdg_ctx *ctx);
 
 /* Options: "dispatch_events" (0/1: time the --LD launches through their own
@@ -166,7 +169,8 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * queue one run per comparison individual without a host round trip between
  * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it); "ld_variant" (0 = pick automatically,
- * 1 = strict, 2 = exponent counting, an error if not applicable);
+ * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference
+ * order);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;
@@ -174,6 +178,13 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * comparison individuals in one ibdg_run, groups of four share a workgroup of
  * the exponent-counting kernel -- same results, ~1.4x the throughput).  Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
+
+/* Reference-order mode only ("ld_variant" 3): the background individuals in the
+ * order the reference walks them -- the lines of the -B file, duplicates kept
+ * (data->refids, src/ibd-parse.c:262-308; src/ibdgem.c:741).  Must agree with
+ * the bg_count given to ibdg_run.  n = 0 clears it: ascending individuals, each
+ * bg_count[n] times, which is the reference's order when there is no -B. */
+int ibdg_set_background_order(ibdg_ctx *ctx, const uint32_t *ids, size_t n);
 
 /* Block until all work queued on the engine's stream is done. */
 int ibdg_sync(ibdg_ctx *ctx);

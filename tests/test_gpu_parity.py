@@ -99,7 +99,7 @@ def _syn_cases():
 VARIANTS = [1, 2]      # 1 = strict fp64 products, 2 = exponent counting (see include/ibdgem_hip.h)
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("variant", VARIANTS + [3])
 @pytest.mark.parametrize("tag,case", _syn_cases())
 def test_reference_17digit_outputs(tag, case, variant, oracle):
     flags, panel, names, refids, pu_id, per_target = G.case_setup(tag, case)
@@ -113,6 +113,7 @@ def test_reference_17digit_outputs(tag, case, variant, oracle):
             tab, summ, alle, fo, rows = per_target[name]
             t = panel.index(name)
             eng.upload_sites(rows, tab.n_ref, tab.n_alt, flags["window"], f_override=fo)
+            eng.set_background_order(refids if variant == 3 else None)
             eng.run([t], ld=flags["ld"], bg_count=bg_counts(refids, n_ids), pu_id=pu_id)
             assert eng.n_sites == len(tab.pos) == tab.processed
             assert eng.last_ld_variant() == (variant if flags["ld"] else 0)
@@ -126,7 +127,9 @@ def test_reference_17digit_outputs(tag, case, variant, oracle):
             if len(win):
                 assert (tab.pos[first] == summ.start).all() and (tab.pos[last] == summ.end).all()
             assert_bits(win[:, 2], summ.ll[:, 2], f"{tag}/{case}/{name} window LIBD2")
-            if flags["ld"]:
+            if flags["ld"] and variant == 3:     # reference order: the reference's own 17-digit values, bit for bit
+                assert_bits(win, summ.ll, f"{tag}/{case}/{name} LD window, reference order")
+            elif flags["ld"]:
                 assert_ld_close(win[:, :2], summ.ll[:, :2], f"{tag}/{case}/{name} LD window")
             else:
                 assert_bits(win, summ.ll, f"{tag}/{case}/{name} window")
@@ -288,6 +291,38 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
         res = oracle.compare(alle, nr, na, targets[i], window=100, ld=True, max_cov=M,
                              refids=np.repeat(np.arange(N), bg), pu_id=targets[1])
         assert_ld_close(got[1][i][1][:, :2], res["win"][:, :2], f"M={M} target {targets[i]}")
+
+
+@pytest.mark.parametrize("N,L,W,M,cov", [(70, 900, 100, 20, 2.0), (200, 500, 7, 40, 9.0), (131, 400, 64, 3, 1.0), (3, 60, 2, 20, 2.0)])
+def test_reference_order_mode_is_bit_identical_to_the_oracle(oracle, N, L, W, M, cov):
+    """ld_variant 3: strict per-individual products, then the background sums taken serially in the
+    reference's order (list order of -B with duplicates, exclusions counted out) -- every LIBD0/LIBD1
+    bit equals the oracle's, which equals the reference's (17-digit goldens above)."""
+    rng = np.random.default_rng(N * 7 + L)
+    f = rng.beta(0.4, 1.0, size=L).clip(1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    targets = [int(t) for t in rng.choice(N, size=min(3, N), replace=False)]
+    orders = [None, rng.permutation(np.repeat(np.arange(N), rng.integers(0, 3, size=N)))]
+    with E.Engine(0, 0.02, M) as eng:
+        eng.set_option("ld_variant", 3)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, W)
+        for order in orders:
+            for pu in (-1, targets[0]):
+                eng.set_background_order(order)
+                eng.run(targets, ld=True, bg_count=bg_counts(order, N), pu_id=pu)
+                assert eng.last_ld_variant() == 3
+                for i, t in enumerate(targets):
+                    res = oracle.compare(alle, nr, na, t, window=W, ld=True, max_cov=M, refids=order, pu_id=pu)
+                    assert_bits(eng.site_ll(i), res["site"], "site")
+                    assert_bits(eng.window_ll(i), res["win"], f"N={N} target {t} pu={pu} order={'list' if order is not None else 'default'}")
+        with pytest.raises(E.EngineError, match="disagree"):
+            eng.set_background_order([0])
+            eng.run(targets, ld=True)
+        eng.set_background_order(None)
 
 
 def test_async_runs_queue_in_order():

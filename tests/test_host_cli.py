@@ -314,3 +314,17 @@ def test_cli_summary_only_writes_the_same_summary_files_and_no_tab_files(tmp_pat
     assert sorted(os.listdir(tmp_path)) == want
     for fn in want:
         assert _read(str(tmp_path / fn)) == _read(os.path.join(ref, fn + ".gz")), fn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ld_default", "ld_bg_dup", "ld_bg_self_nan", "ld_pu_in_panel"])
+def test_cli_reference_order_mode(case, tmp_path):
+    """--reference-order: the background sums are taken serially in the reference's order (list order of
+    -B, duplicates kept), so the --LD columns are the reference's bits, not merely its 7 digits."""
+    meta = G.cases("synA")
+    _run_full(meta["base_args"] + meta["cases"][case] + ["--reference-order"], os.path.join(G.GOLD, "synA", "input"),
+              tmp_path)
+    ref = os.path.join(G.GOLD, "synA", case, "ref7")
+    for fn in sorted(os.listdir(ref)):
+        got, want = _read(str(tmp_path / fn[:-3])), _read(os.path.join(ref, fn))
+        assert (got[1:] if fn.endswith(".tab.txt.gz") else got) == want, fn

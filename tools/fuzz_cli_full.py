@@ -3,7 +3,10 @@ oracle/_ref/ibdgem, which travels with the snapshot): random small panels and pi
 rows, random flags (--LD in two of three cases, -v -D -M -F -f -w -e -c -p -A -B -N), then the full
 host program against the reference: every output file byte for byte after the command line.
 
-    python tools/fuzz_cli_full.py [n_cases] [seed]
+    python tools/fuzz_cli_full.py [n_cases] [seed] [--reference-order]
+
+With --reference-order the host is run in its reference-order mode, in which the --LD columns are
+bit-identical to the reference's, so that not even decimal ties can differ.
 """
 import os, random, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -15,6 +18,7 @@ REF = os.path.join(REPO, "oracle", "_ref", "ibdgem")
 EXE = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+EXTRA = ["--reference-order"] if "--reference-order" in sys.argv[3:] else []
 bad = 0
 compared = rows_compared = 0
 for case in range(n_cases):
@@ -82,7 +86,7 @@ for case in range(n_cases):
         os.makedirs(out)
         os.makedirs(out2)
         r = subprocess.run([REF, *args, "-O", out], cwd=d, capture_output=True, text=True)
-        o = subprocess.run([EXE, *args, "-O", out2], cwd=d, capture_output=True, text=True)
+        o = subprocess.run([EXE, *args, *EXTRA, "-O", out2], cwd=d, capture_output=True, text=True)
         try:
             assert r.returncode == o.returncode, (r.returncode, o.returncode, r.stderr[-200:], o.stderr[-200:])
             if r.returncode == 0:
