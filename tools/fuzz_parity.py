@@ -39,7 +39,10 @@ for case in range(n_cases):
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
     bg = None if rng.random() < 0.5 else rng.integers(0, 3, size=N).astype(np.uint8)
     pu = -1 if rng.random() < 0.6 else int(rng.integers(0, N))
-    variant = int(rng.choice([0, 0, 1, 2]))
+    variant = int(rng.choice([0, 0, 1, 2, 3]))
+    order = None
+    if variant == 3 and bg is not None and rng.random() < 0.7:
+        order = rng.permutation(np.repeat(np.arange(N), bg))        # the -B list in some file order
     opts = {}
     if rng.random() < 0.5:
         opts = {"ring_slots": int(rng.choice([2, 3, 4, 8])), "windows_per_wave": int(rng.choice([1, 2, 5, 16, 64])),
@@ -52,13 +55,14 @@ for case in range(n_cases):
             eng.set_option("ld_variant", variant)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
+            eng.set_background_order(order)
             try:
                 eng.run(targets, ld=True, bg_count=bg, pu_id=pu)
             except E.EngineError as e:
                 if variant == 2 and "not applicable" in str(e):
                     continue                      # forced exponent counting where the table is clamped etc.
                 raise
-            refids = None if bg is None else np.repeat(np.arange(N), bg)
+            refids = order if order is not None else (None if bg is None else np.repeat(np.arange(N), bg))
             for i, t in enumerate(targets):
                 res = orc.compare(alle[keep], nr[keep], na[keep], t, window=W, ld=True, eps=eps, max_cov=M,
                                   refids=refids, pu_id=pu)
@@ -74,6 +78,8 @@ for case in range(n_cases):
                     big = fin & ~tiny
                     rel = np.abs(g[big] - w_[big]) / np.abs(w_[big]) if big.any() else np.zeros(0)
                     ok = ok and nan_ok and (np.abs(g[tiny]) < TINY).all() and (rel.size == 0 or rel.max() <= 1e-10)
+                    if variant == 3:          # reference order: every bit
+                        ok = ok and ((g.view(np.uint64) == w_.view(np.uint64)) | (np.isnan(g) & np.isnan(w_))).all()
                 if not ok:
                     bad += 1
                     print("MISMATCH", desc, "target", t, flush=True)
