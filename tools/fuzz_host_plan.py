@@ -50,7 +50,23 @@ for case in range(n_cases):
                 if random.random() < 0.15:
                     continue                                   # no pileup line at this position
                 cov = random.choice([0, 0, 1, 1, 2, 3, 5, 9, 25])
-                bases = "".join(random.choices("ACGTacgtN", k=cov)) if cov else "*"
+                if cov and random.random() < 0.5:
+                    # samtools decorations: read starts (^ + mapping quality), read ends ($), indels (+n / -n
+                    # followed by n letters), deletions (*), reference matches (. ,), skips (< >)
+                    toks = []
+                    for _ in range(cov):
+                        t = random.choice("ACGTacgtN.,*<>")
+                        if random.random() < 0.15:
+                            t = "^" + random.choice("]I!~+-ACGT") + t
+                        if random.random() < 0.15:
+                            n = random.choice([1, 2, 12])
+                            t += random.choice("+-") + str(n) + "".join(random.choices("ACGTNacgtn", k=n))
+                        if random.random() < 0.15:
+                            t += "$"
+                        toks.append(t)
+                    bases = "".join(toks)
+                else:
+                    bases = "".join(random.choices("ACGTacgtN", k=cov)) if cov else "*"
                 q = "I" * cov if cov else "*"
                 fh.write(f"{chrom}\t{p}\tN\t{cov}\t{bases}\t{q}\t{q}\n")
         args = ["-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup"]
