@@ -1,5 +1,6 @@
+"""Host-side cost of the two uploads on the bench workload (run on the GPU box): python tools/time_uploads.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench, ibdgem_amd
 dev = torch.device("cuda", 0)
