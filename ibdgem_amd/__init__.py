@@ -6,4 +6,4 @@ ibdgem_amd/host.  This Python package is only the ctypes binding used by the
 tests and bench.py; it has no compute path of its own and fails loudly when
 the library is missing.
 """
-from .engine import Engine, EngineError, load_library, LIB_PATH  # noqa: F401
+from .engine import Engine, EngineError, PinnedArray, load_library, LIB_PATH  # noqa: F401

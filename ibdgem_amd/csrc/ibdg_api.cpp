@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -73,13 +74,27 @@ struct ibdg_ctx {
 
     // sites of the current comparison
     DevBuf rec_all, rec_cov, cov_site, fo;
+    DevBuf in_row, in_ref, in_alt;      // device copies of the caller's arrays (ibdg_upload_sites)
+    DevBuf scan_tmp, info_dev, wraw, nck_dev, powb, win_first, win_last;
+    ibdg::PrepInfo *info_h = nullptr;   // pinned
     bool have_fo = false;
     size_t n_sites = 0;
     uint32_t n_cov = 0, window = 0, n_win = 0;
-    std::vector<uint32_t> cov_site_h;
+    std::vector<uint32_t> win_first_h, win_last_h;   // fetched on the first ibdg_get_windows after an upload
+    bool win_bounds_valid = false;
+    bool sites_valid = false;           // an upload of sites has succeeded since the last upload of a panel
+    std::vector<uint32_t> runs_h;
+    // power tables (functions of epsilon only; grown on demand, see grow_pow_tables)
+    std::vector<ibdg::PowEntry> p1_h, p2_h;
+    std::vector<ibdg::WinRaw> pb_h;
+    size_t tab_dev = 0;                 // entries the device copies hold
+    size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
+    hipEvent_t ev_up[3] = {};           // before the host-to-device copies, after them, after the last prep kernel
+    float up_ms[3] = {0.f, 0.f, 0.f};   // copies, preparation on the device (with its host round trips), whole call
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
     DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, partial;
+    // pow1/pow2: rho^n, sigma^n as {f64 mantissa, i32 exponent}; powb: (1-eps)^n in the x87 format
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
     DevBuf runs;
@@ -175,6 +190,9 @@ int ensure(ibdg_ctx *c, DevBuf &b, size_t bytes)
     if (b.cap >= bytes)
         return 0;
     if (b.p) {
+        // queued runs ("async") may still use the buffer: wait for them rather than rely on hipFree doing so
+        if ((c->s2_pending || c->chain_ok) && quiesce(c))
+            return 1;
         HIP_TRY(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -320,6 +338,15 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
     c->counts_valid = false;
     c->have_results = false;
     c->pop_sites_ok = false;
+    // the device copies of targets / background weights were laid out for the previous panel
+    c->prev_targets.clear();
+    c->prev_bg.clear();
+    c->prev_pu = -2;
+    c->prev_has_bg = -1;
+    c->prev_lanes = 0;
+    c->n_sites = 0;
+    c->n_cov = c->n_win = 0;
+    c->sites_valid = false;
     c->n_pairs = (uint32_t)(((n_rows + 255) / 256) * 4);     // 64-row tile pairs, padded to whole 8-tile octs
     if (ensure(c, c->panel, n_rows * (size_t)c->stride * 8) || ensure(c, c->alt_count, n_rows * 4))
         return 1;
@@ -365,169 +392,170 @@ int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
     return 0;
 }
 
-// Segments, per-window constants and power tables of the fast --LD kernel
-// (host integer work over the covered rows, once per ibdg_upload_sites).
-int build_segments(ibdg_ctx *c, const std::vector<uint2> &rec_cov, const uint8_t *n_ref, const uint8_t *n_alt)
+// Runs of consecutive windows for the workgroups of the exponent-counting kernel: g windows each,
+// except towards the end of the grid, where they shrink (guided self-scheduling: remaining
+// windows / workgroups in flight): workgroups are handed out in blockIdx order, so the last
+// ones to start are short and the CUs run dry together instead of waiting for one last
+// full-length run.  A function of the window count alone.
+void make_runs(const ibdg_ctx *c, uint32_t g, std::vector<uint32_t> &runs)
+{
+    const uint32_t n_cg = (c->n_chunks + 7) / 8, wpg_waves = (c->n_chunks + n_cg - 1) / n_cg;
+    const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * (16 / wpg_waves) / n_cg) * (uint32_t)std::max<long>(1, c->opt_guided) / 4);
+    runs.clear();
+    for (uint32_t w = 0; w < c->n_win;) {
+        runs.push_back(w);
+        uint32_t len = g;
+        if (c->opt_guided)
+            len = std::min(g, std::max<uint32_t>(1, (c->n_win - w + in_flight - 1) / in_flight));
+        w = std::min(w + len, c->n_win);
+    }
+    runs.push_back(c->n_win);
+}
+
+// rho^n, sigma^n and (1-eps)^n for n < need, in extended precision; the bases come from the doubles
+// the reference uses (epsilon and 1-epsilon, src/ibd-math.c:58-61).  The tables depend on epsilon
+// only, so a context builds every entry once and keeps it.  Returns false when an exponent leaves
+// the range of the 32-bit fields (the strict kernel then serves).
+bool grow_pow_tables(ibdg_ctx *c, size_t need)
+{
+    if (need > c->tab_fail_from)
+        return false;
+    if (need <= c->p1_h.size())
+        return true;
+    const size_t old = c->p1_h.size();
+    const size_t n = std::max(need, std::min<size_t>(old + old / 2 + 256, c->tab_fail_from));
+    const long double one_me = (long double)(double)(1 - c->eps);
+    const ME rho = me_norm((long double)c->eps / one_me, 0), sigma = me_norm(0.5L / one_me, 0);
+    c->p1_h.resize(n);
+    c->p2_h.resize(n);
+    c->pb_h.resize(n);
+    for (size_t k = old; k < n; ++k) {
+        const ME x = me_powl(rho, k), y = me_powl(sigma, k), z = me_pow(1 - c->eps, k);
+        if (x.e < -2000000000LL || y.e < -2000000000LL || z.e < -2000000000LL) {
+            c->tab_fail_from = k;
+            c->p1_h.resize(k);
+            c->p2_h.resize(k);
+            c->pb_h.resize(k);
+            c->tab_dev = std::min(c->tab_dev, k);
+            return need <= k;
+        }
+        c->p1_h[k].m = (double)x.m; c->p1_h[k].e = (int32_t)x.e; c->p1_h[k].pad = 0;
+        c->p2_h[k].m = (double)y.m; c->p2_h[k].e = (int32_t)y.e; c->p2_h[k].pad = 0;
+        c->pb_h[k].m = (uint64_t)ldexpl(z.m, 64);        // exact: a 64-bit mantissa in [2^63, 2^64)
+        c->pb_h[k].e = (int32_t)z.e;
+        c->pb_h[k].pad = 0;
+    }
+    return true;
+}
+
+// Copy the device's PrepInfo to the pinned host copy and wait for it.
+int read_info(ibdg_ctx *c)
+{
+    HIP_TRY(c, hipMemcpyAsync(c->info_h, c->info_dev.p, sizeof(ibdg::PrepInfo), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Segments, per-window constants, control words and power tables of the fast --LD kernel, built on
+// the device from the covered-row list (ibdg_prep.hip); the host keeps what depends on the window
+// count only (the run structure) and the epsilon-only power tables.
+int build_segments(ibdg_ctx *c)
 {
     c->pop_sites_ok = false;
     if (!c->pop_lut_ok || c->n_cov == 0)
         return 0;
-    for (size_t j = 1; j < rec_cov.size(); ++j)
-        if (rec_cov[j].x <= rec_cov[j - 1].x)
-            return 0;                      // not in file order: only the strict kernel applies
-    const size_t d = (size_t)c->max_cov + 1;
-    std::vector<ibdg::Seg> segs;
-    std::vector<ibdg::WinConst> wc(c->n_win + 1);
-    segs.reserve(c->n_cov / 8 + c->n_win + 16);
-    uint32_t ct_max = 0;
-    for (uint32_t w = 0; w < c->n_win; ++w) {
-        const uint32_t b = w * c->window, e = (uint32_t)std::min<uint64_t>((uint64_t)b + c->window, c->n_cov);
-        ME K = me_norm(1.0L, 0);
-        uint32_t ct = 0, at = 0;
-        wc[w].seg_begin = (uint32_t)segs.size();
-        for (uint32_t j = b; j < e; ++j) {
-            const uint32_t s = c->cov_site_h[j];
-            const unsigned r = n_ref[s], a = n_alt[s], cv = r + a;
-            const uint32_t row = rec_cov[j].x, tile = row >> 5, bit = 1u << (row & 31);
-            if (segs.size() == wc[w].seg_begin || segs.back().tile != tile) {
-                ibdg::Seg sg;
-                memset(&sg, 0, sizeof sg);
-                sg.tile = tile;
-                sg.win = w;
-                segs.push_back(sg);
-            }
-            ibdg::Seg &sg = segs.back();
-            for (int k = 0; k < 8; ++k) {
-                if ((cv >> k) & 1) sg.cov[k] |= bit;
-                if ((a >> k) & 1) sg.alt[k] |= bit;
-            }
-            ct += cv;
-            at += a;
-            // the coefficients are < 2^64 each: 64 of them cannot overflow a long double mantissa/exponent
-            // pair, so the (exact, power-of-two) renormalisation is needed only now and then
-            K.m *= (long double)c->nck_h[(size_t)cv * d + r];
-            if (((j - b) & 63) == 63)
-                K = me_norm(K.m, K.e);
-        }
-        K = me_norm(K.m, K.e);
-        segs.back().last = 1;
-        // K' = K * (1-eps)^(all reads of the window): with it a product is K' * rho^E2 * sigma^E3,
-        // rho = eps/(1-eps), sigma = 1/(2(1-eps))  (E1 = reads - E2 - E3 eliminated)
-        const ME B = me_pow(1 - c->eps, ct);
-        const ME Kp = me_norm(K.m * B.m, K.e + B.e);
-        wc[w].mK = (double)Kp.m;
-        wc[w].eK = (int32_t)Kp.e;
-        wc[w].cov_total = ct;
-        wc[w].alt_total = at;
-        ct_max = std::max(ct_max, ct);
-    }
-    wc[c->n_win].seg_begin = (uint32_t)segs.size();
-    // windows per workgroup run: as many as keep the run's records within the LDS budget
-    {
-        uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
-        if (!c->opt_guided && !c->opt_wpg_fixed) {
-            // uniform runs and few windows (a shard of a chromosome, a small region): shorter runs, so that
-            // the grid still holds several rounds of workgroups for every CU
-            const uint64_t rows_of_blocks = (c->n_chunks + 7) / 8;
-            const uint64_t want_blocks = (uint64_t)c->n_cu * 2 * 5;          // CUs x resident blocks x rounds
-            const uint64_t g_fit = std::max<uint64_t>(1, (uint64_t)c->n_win * rows_of_blocks / want_blocks);
-            if (g_fit < g)
-                g = (uint32_t)g_fit;
-        }
-        // Runs of g windows, except towards the end of the grid, where they shrink (guided
-        // self-scheduling: remaining windows / workgroups in flight): workgroups are handed out in
-        // blockIdx order, so the last ones to start are short and the CUs run dry together instead
-        // of waiting for one last full-length run.
-        const uint32_t n_cg = (c->n_chunks + 7) / 8, wpg_waves = (c->n_chunks + n_cg - 1) / n_cg;
-        const uint32_t in_flight = std::max<uint32_t>(1, (uint32_t)(c->n_cu * (16 / wpg_waves) / n_cg) * (uint32_t)std::max<long>(1, c->opt_guided) / 4);
-        std::vector<uint32_t> runs;
-        for (;; g = (g + 1) / 2) {
-            uint32_t mx = 0;
-            runs.clear();
-            for (uint32_t w = 0; w < c->n_win;) {
-                runs.push_back(w);
-                uint32_t len = g;
-                if (c->opt_guided)
-                    len = std::min(g, std::max<uint32_t>(1, (c->n_win - w + in_flight - 1) / in_flight));
-                const uint32_t wn = std::min(w + len, c->n_win);
-                mx = std::max(mx, wc[wn].seg_begin - wc[w].seg_begin);
-                w = wn;
-            }
-            runs.push_back(c->n_win);
-            if ((size_t)mx * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1) {
-                c->wpg = g;
-                c->max_seg = mx;
-                break;
-            }
-        }
-        c->n_runs = (uint32_t)runs.size() - 1;
-        if (ensure(c, c->runs, runs.size() * 4))
-            return 1;
-        HIP_TRY(c, hipMemcpyAsync(c->runs.p, runs.data(), runs.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));        // `runs` is a local
-        // per-segment control word (see ibdg::Seg::flags): needs the run structure chosen above
-        const uint32_t NS = (uint32_t)c->opt_ring;
-        for (uint32_t r = 0; r < c->n_runs; ++r) {
-            const uint32_t s0 = wc[runs[r]].seg_begin, s1 = wc[runs[r + 1]].seg_begin;
-            if (s0 == s1)
-                continue;
-            const uint32_t q0 = segs[s0].tile >> 1;
-            for (uint32_t i = s0; i < s1; ++i) {
-                ibdg::Seg &sg = segs[i];
-                uint32_t nc = 0, na = 0;
-                for (int k = 0; k < 8; ++k) {
-                    if (sg.cov[k]) nc = k + 1;
-                    if (sg.alt[k]) na = k + 1;
-                }
-                uint32_t nslot = 0, nhalf = 0, adv = 0;
-                if (i + 1 < s1) {
-                    const uint32_t qn = segs[i + 1].tile >> 1;
-                    adv = qn - (sg.tile >> 1);
-                    if (adv > 255)
-                        return 0;          // rows too far apart for the record format: strict kernel
-                    nslot = (qn - q0) % NS;
-                    nhalf = segs[i + 1].tile & 1;
-                }
-                sg.flags = nslot | (nhalf << 3) | (adv << 4) | ((nc > 3 || na > 2) ? 1u << 12 : 0u) |
-                           (sg.last ? 1u << 13 : 0u) | (nc << 16) | (na << 24);
-            }
-        }
-        c->seg_ring = (int)NS;
-        c->tab_in_lds = (size_t)(ct_max + 1) * 32 <= 24 * 1024;
-        if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, ct_max + 1, c->tab_in_lds, c->seg_ring, 0) > 150 * 1024)
-            return 0;                      // a single window with thousands of tiles: strict kernel
-    }
-    wc[c->n_win].mK = 0;
-    wc[c->n_win].eK = 0;
-    wc[c->n_win].cov_total = wc[c->n_win].alt_total = 0;
-    c->n_segs = (uint32_t)segs.size();
-    c->ct_max = ct_max;
-    std::vector<ibdg::PowEntry> p1(ct_max + 1), p2(ct_max + 1);
-    // rho^n and sigma^n in extended precision; the bases come from the doubles the reference uses
-    // (epsilon and 1-epsilon, src/ibd-math.c:58-61)
-    const long double one_me = (long double)(double)(1 - c->eps);
-    const ME rho = me_norm((long double)c->eps / one_me, 0), sigma = me_norm(0.5L / one_me, 0);
-    for (uint32_t n = 0; n <= ct_max; ++n) {
-        const ME x = me_powl(rho, n), y = me_powl(sigma, n);
-        if (x.e < -2000000000LL || y.e < -2000000000LL)
-            return 0;
-        p1[n].m = (double)x.m; p1[n].e = (int32_t)x.e; p1[n].pad = 0;
-        p2[n].m = (double)y.m; p2[n].e = (int32_t)y.e; p2[n].pad = 0;
-    }
-    if (ensure(c, c->segs, segs.size() * sizeof(ibdg::Seg)) || ensure(c, c->wconst, wc.size() * sizeof(ibdg::WinConst)) ||
-        ensure(c, c->pow1, p1.size() * sizeof(ibdg::PowEntry)) || ensure(c, c->pow2, p2.size() * sizeof(ibdg::PowEntry)))
+    const ibdg::PrepInfo &I = *c->info_h;
+    // segments <= windows + tiles spanned when the rows are in file order (otherwise the device stops
+    // writing at the capacity and the exponent-counting kernel is not used)
+    uint64_t seg_cap = c->n_cov;
+    if (I.last_row >= I.first_row)
+        seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((I.last_row >> 5) - (I.first_row >> 5)) + 1);
+    if (ensure(c, c->segs, seg_cap * sizeof(ibdg::Seg)) || ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
+        ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)) ||
+        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(c->n_sites, 1)) * 4))
         return 1;
-    HIP_TRY(c, hipMemcpyAsync(c->segs.p, segs.data(), segs.size() * sizeof(ibdg::Seg), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->wconst.p, wc.data(), wc.size() * sizeof(ibdg::WinConst), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->pow1.p, p1.data(), p1.size() * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->pow2.p, p2.data(), p2.size() * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->nck_dev.p) {
+        if (ensure(c, c->nck_dev, c->nck_h.size() * 8)) return 1;
+        HIP_TRY(c, hipMemcpyAsync(c->nck_dev.p, c->nck_h.data(), c->nck_h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    ibdg::PrepSegArgs sa;
+    sa.rec_cov = (const uint2 *)c->rec_cov.p;
+    sa.n_cov = c->n_cov;
+    sa.window = c->window;
+    sa.n_win = c->n_win;
+    sa.max_cov = c->max_cov;
+    sa.nck = (const unsigned long long *)c->nck_dev.p;
+    sa.segs = (ibdg::Seg *)c->segs.p;
+    sa.seg_cap = (uint32_t)seg_cap;
+    sa.wconst = (ibdg::WinConst *)c->wconst.p;
+    sa.raw = (ibdg::WinRaw *)c->wraw.p;
+    sa.block_tmp = (uint32_t *)c->scan_tmp.p;
+    sa.info = (ibdg::PrepInfo *)c->info_dev.p;
+    ibdg::launch_prep_segments(sa, c->stream);
+    HIP_TRY(c, hipGetLastError());
+
+    // windows per workgroup run: as many as keep the run's records within the LDS budget
+    uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
+    if (!c->opt_guided && !c->opt_wpg_fixed) {
+        // uniform runs and few windows (a shard of a chromosome, a small region): shorter runs, so that
+        // the grid still holds several rounds of workgroups for every CU
+        const uint64_t rows_of_blocks = (c->n_chunks + 7) / 8;
+        const uint64_t want_blocks = (uint64_t)c->n_cu * 2 * 5;          // CUs x resident blocks x rounds
+        const uint64_t g_fit = std::max<uint64_t>(1, (uint64_t)c->n_win * rows_of_blocks / want_blocks);
+        if (g_fit < g)
+            g = (uint32_t)g_fit;
+    }
+    const uint32_t NS = (uint32_t)c->opt_ring;
+    for (;; g = (g + 1) / 2) {
+        make_runs(c, g, c->runs_h);
+        c->n_runs = (uint32_t)c->runs_h.size() - 1;
+        if (ensure(c, c->runs, c->runs_h.size() * 4))
+            return 1;
+        // runs_h is a member: it outlives the copy (the next wait is read_info below)
+        HIP_TRY(c, hipMemcpyAsync(c->runs.p, c->runs_h.data(), c->runs_h.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(&((ibdg::PrepInfo *)c->info_dev.p)->max_seg, 0, 8, c->stream));   // max_seg, adv_overflow
+        ibdg::launch_prep_seg_flags(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        if (read_info(c))
+            return 1;
+        if (I.out_of_order || I.n_segs > seg_cap)
+            return 0;                      // not in file order: only the strict kernel applies
+        if ((size_t)I.max_seg * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1)
+            break;
+    }
+    if (I.adv_overflow)
+        return 0;                          // rows too far apart for the record format: strict kernel
+    c->wpg = g;
+    c->max_seg = I.max_seg;
+    c->seg_ring = (int)NS;
+    c->n_segs = I.n_segs;
+    c->ct_max = I.ct_max;
+    c->tab_in_lds = (size_t)(c->ct_max + 1) * 32 <= 24 * 1024;
+    if (ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 0) > 150 * 1024)
+        return 0;                          // a single window with thousands of tiles: strict kernel
+    if (!grow_pow_tables(c, (size_t)c->ct_max + 1))
+        return 0;
+    if (c->tab_dev < c->p1_h.size()) {     // new entries since the last upload
+        const size_t n = c->p1_h.size();
+        if (ensure(c, c->pow1, n * sizeof(ibdg::PowEntry)) || ensure(c, c->pow2, n * sizeof(ibdg::PowEntry)) ||
+            ensure(c, c->powb, n * sizeof(ibdg::WinRaw)))
+            return 1;
+        HIP_TRY(c, hipMemcpyAsync(c->pow1.p, c->p1_h.data(), n * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->pow2.p, c->p2_h.data(), n * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->powb.p, c->pb_h.data(), n * sizeof(ibdg::WinRaw), hipMemcpyHostToDevice, c->stream));
+        c->tab_dev = n;
+    }
+    // K' = K * (1-eps)^(all reads of the window): with it a product is K' * rho^E2 * sigma^E3,
+    // rho = eps/(1-eps), sigma = 1/(2(1-eps))  (E1 = reads - E2 - E3 eliminated)
+    ibdg::launch_prep_win_kp(c->n_win, (const ibdg::WinRaw *)c->wraw.p, (const ibdg::WinRaw *)c->powb.p,
+                             (ibdg::WinConst *)c->wconst.p, c->stream);
+    HIP_TRY(c, hipGetLastError());
     c->pop_sites_ok = true;
     // Sparse coverage: the exponent-counting kernel streams every 32-row tile between a window's first
     // and last row (~175 issue cycles per tile and chunk) while the strict kernel touches covered rows
     // only (~49 cycles per row and chunk): below ~1 covered row in 9 the strict kernel is the faster one.
     {
-        const uint64_t span = (uint64_t)rec_cov.back().x - rec_cov.front().x + 1;
+        const uint64_t span = (uint64_t)I.last_row - I.first_row + 1;
         c->pop_dense_enough = (uint64_t)c->n_cov * 9 >= span;
     }
     return 0;
@@ -593,6 +621,10 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
         for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
     }
+    for (hipEvent_t &ev : c->ev_up)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void **)&c->info_h, sizeof(ibdg::PrepInfo), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
     {
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
@@ -627,8 +659,15 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial})
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial,
+                      &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
+                      &c->win_first, &c->win_last})
         release(*b);
+    for (hipEvent_t ev : c->ev_up)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->info_h)
+        (void)hipHostFree(c->info_h);
     for (auto &E : c->evs)
         for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
             if (ev)
@@ -692,58 +731,64 @@ int ibdg_upload_panel_dev(ibdg_ctx *c, const void *dev_rows, size_t n_rows, unsi
     return copy_rows(c, dev_rows, n_rows, hipMemcpyDeviceToDevice);
 }
 
-int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_ref, const uint8_t *n_alt,
-                      const double *f_override, size_t n_sites, unsigned window)
+// Everything an upload of sites does once the three input arrays are on the device.
+static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *d_ref, const uint8_t *d_alt,
+                             const double *f_override, size_t n_sites, unsigned window)
 {
-    if (!c) return 1;
-    if (!c->panel.p || c->n_ids == 0) return fail(c, "[::] ERROR in ibdg_upload_sites: no panel uploaded");
-    if (window < 1) return fail(c, "[::] ERROR: Invalid window size (-w) of %u (must be >= 1).", window);
-    if (n_sites && (!row_index || !n_ref || !n_alt))
-        return fail(c, "[::] ERROR in ibdg_upload_sites: NULL input array");
-    if (n_sites > 0xffffffffull)
-        return fail(c, "[::] ERROR in ibdg_upload_sites: more than 2^32-1 rows in one call");
-    if (quiesce(c)) return 1;
-    const unsigned d = c->max_cov + 1;
-    std::vector<uint2> rec_all(n_sites), rec_cov;
-    rec_cov.reserve(n_sites);
-    c->cov_site_h.clear();
-    c->cov_site_h.reserve(n_sites);
-    for (size_t s = 0; s < n_sites; ++s) {
-        const unsigned r = n_ref[s], a = n_alt[s];
-        if (row_index[s] >= c->n_rows)
-            return fail(c, "[::] ERROR in ibdg_upload_sites: row_index[%zu]=%u outside the panel (%zu rows)", s,
-                        row_index[s], c->n_rows);
-        if (r + a > c->max_cov)
-            return fail(c, "[::] ERROR in ibdg_upload_sites: site %zu has n_ref+n_alt=%u > max_cov=%u", s, r + a,
-                        c->max_cov);
-        uint2 rc;
-        rc.x = row_index[s];
-        rc.y = (r * d + a) * 24u;
-        rec_all[s] = rc;
-        if (r + a >= 1) {
-            rec_cov.push_back(rc);
-            c->cov_site_h.push_back((uint32_t)s);
-        }
-    }
     c->n_sites = n_sites;
-    c->n_cov = (uint32_t)rec_cov.size();
     c->window = window;
-    c->n_win = (c->n_cov + window - 1) / window;
+    c->n_cov = 0;
+    c->n_win = 0;
+    c->sites_valid = false;
     c->have_results = false;
-    if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, rec_cov.size() * 8) ||
-        ensure(c, c->cov_site, rec_cov.size() * 4))
-        return 1;
-    if (n_sites)
-        HIP_TRY(c, hipMemcpyAsync(c->rec_all.p, rec_all.data(), n_sites * 8, hipMemcpyHostToDevice, c->stream));
-    if (c->n_cov) {
-        HIP_TRY(c, hipMemcpyAsync(c->rec_cov.p, rec_cov.data(), rec_cov.size() * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->cov_site.p, c->cov_site_h.data(), rec_cov.size() * 4, hipMemcpyHostToDevice,
-                                  c->stream));
-    }
+    c->pop_sites_ok = false;
+    c->win_bounds_valid = false;
     c->have_fo = false;
-    std::vector<double> fo;
+    if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
+        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
+        ensure(c, c->info_dev, sizeof(ibdg::PrepInfo)))
+        return 1;
+    memset(c->info_h, 0, sizeof(ibdg::PrepInfo));
+    c->info_h->err_row_site = c->info_h->err_cov_site = 0xffffffffu;
+    HIP_TRY(c, hipMemcpyAsync(c->info_dev.p, c->info_h, sizeof(ibdg::PrepInfo), hipMemcpyHostToDevice, c->stream));
+    ibdg::PrepSiteArgs pa;
+    pa.row_index = d_row;
+    pa.n_ref = d_ref;
+    pa.n_alt = d_alt;
+    pa.n_sites = n_sites;
+    pa.n_rows = c->n_rows;
+    pa.max_cov = c->max_cov;
+    pa.rec_all = (uint2 *)c->rec_all.p;
+    pa.rec_cov = (uint2 *)c->rec_cov.p;
+    pa.cov_site = (uint32_t *)c->cov_site.p;
+    pa.block_tmp = (uint32_t *)c->scan_tmp.p;
+    pa.info = (ibdg::PrepInfo *)c->info_dev.p;
+    ibdg::launch_prep_sites(pa, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    if (read_info(c))
+        return 1;
+    const ibdg::PrepInfo &I = *c->info_h;
+    if (I.err_row_site != 0xffffffffu || I.err_cov_site != 0xffffffffu) {
+        // the first offending site in file order, its row checked before its counts (as a loop over the sites would)
+        c->n_sites = 0;
+        if (I.err_row_site <= I.err_cov_site) {
+            uint32_t row = 0;
+            HIP_TRY(c, hipMemcpy(&row, d_row + I.err_row_site, 4, hipMemcpyDeviceToHost));
+            return fail(c, "[::] ERROR in ibdg_upload_sites: row_index[%zu]=%u outside the panel (%zu rows)",
+                        (size_t)I.err_row_site, row, c->n_rows);
+        }
+        uint8_t r = 0, a = 0;
+        HIP_TRY(c, hipMemcpy(&r, d_ref + I.err_cov_site, 1, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(&a, d_alt + I.err_cov_site, 1, hipMemcpyDeviceToHost));
+        return fail(c, "[::] ERROR in ibdg_upload_sites: site %zu has n_ref+n_alt=%u > max_cov=%u",
+                    (size_t)I.err_cov_site, (unsigned)r + a, c->max_cov);
+    }
+    c->n_cov = I.n_cov;
+    c->n_win = (uint32_t)(((uint64_t)c->n_cov + window - 1) / window);
+    if (build_segments(c))
+        return 1;
     if (f_override) {
-        fo.resize(3 * n_sites);
+        std::vector<double> fo(3 * n_sites);
         for (size_t s = 0; s < n_sites; ++s) {
             const double f = f_override[s];
             fo[3 * s] = f;
@@ -758,24 +803,131 @@ int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_r
         if (c->have_fo) {
             if (ensure(c, c->fo, fo.size() * 8)) return 1;
             HIP_TRY(c, hipMemcpyAsync(c->fo.p, fo.data(), fo.size() * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));          // `fo` is a local
         }
     }
+    return 0;
+}
+
+static int upload_sites_check(ibdg_ctx *c, const void *n_ref, const void *n_alt, bool have_rows, size_t n_sites,
+                              unsigned window)
+{
+    if (!c->panel.p || c->n_ids == 0) return fail(c, "[::] ERROR in ibdg_upload_sites: no panel uploaded");
+    if (window < 1) return fail(c, "[::] ERROR: Invalid window size (-w) of %u (must be >= 1).", window);
+    if (n_sites && (!n_ref || !n_alt))
+        return fail(c, "[::] ERROR in ibdg_upload_sites: NULL input array");
+    if (n_sites > 0xffffffffull)
+        return fail(c, "[::] ERROR in ibdg_upload_sites: more than 2^32-1 rows in one call");
+    if (!have_rows && n_sites > c->n_rows)
+        return fail(c, "[::] ERROR in ibdg_upload_sites: row_index[%zu]=%zu outside the panel (%zu rows)", c->n_rows,
+                    c->n_rows, c->n_rows);
+    return 0;
+}
+
+static double wall_ms(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// After the last kernel of an upload: wait, then keep the three clocks of ibdg_upload_ms.
+static int upload_sites_finish(ibdg_ctx *c, int rc, std::chrono::steady_clock::time_point t0)
+{
+    if (rc)
+        return rc;
+    c->sites_valid = true;
+    HIP_TRY(c, hipEventRecord(c->ev_up[2], c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return build_segments(c, rec_cov, n_ref, n_alt);
+    HIP_TRY(c, hipEventElapsedTime(&c->up_ms[0], c->ev_up[0], c->ev_up[1]));
+    HIP_TRY(c, hipEventElapsedTime(&c->up_ms[1], c->ev_up[1], c->ev_up[2]));
+    c->up_ms[2] = (float)wall_ms(t0);
+    return 0;
+}
+
+int ibdg_upload_sites(ibdg_ctx *c, const uint32_t *row_index, const uint8_t *n_ref, const uint8_t *n_alt,
+                      const double *f_override, size_t n_sites, unsigned window)
+{
+    if (!c) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (upload_sites_check(c, n_ref, n_alt, row_index != nullptr, n_sites, window)) return 1;
+    if (quiesce(c)) return 1;
+    if (ensure(c, c->in_ref, n_sites) || ensure(c, c->in_alt, n_sites) || (row_index && ensure(c, c->in_row, n_sites * 4)))
+        return 1;
+    HIP_TRY(c, hipEventRecord(c->ev_up[0], c->stream));
+    if (n_sites) {
+        // 6 bytes per row (2 when the rows are the panel's own); pinned arrays (ibdg_host_alloc) go at link speed
+        if (row_index)
+            HIP_TRY(c, hipMemcpyAsync(c->in_row.p, row_index, n_sites * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->in_ref.p, n_ref, n_sites, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->in_alt.p, n_alt, n_sites, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_up[1], c->stream));
+    return upload_sites_finish(c, upload_sites_core(c, row_index ? (const uint32_t *)c->in_row.p : nullptr,
+                                                    (const uint8_t *)c->in_ref.p, (const uint8_t *)c->in_alt.p,
+                                                    f_override, n_sites, window), t0);
+}
+
+int ibdg_upload_sites_dev(ibdg_ctx *c, const void *dev_row_index, const void *dev_n_ref, const void *dev_n_alt,
+                          const double *f_override, size_t n_sites, unsigned window)
+{
+    if (!c) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (upload_sites_check(c, dev_n_ref, dev_n_alt, dev_row_index != nullptr, n_sites, window)) return 1;
+    if (quiesce(c)) return 1;
+    // the arrays may have been produced on another stream (e.g. torch's): make them visible first
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipEventRecord(c->ev_up[0], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_up[1], c->stream));
+    return upload_sites_finish(c, upload_sites_core(c, (const uint32_t *)dev_row_index, (const uint8_t *)dev_n_ref,
+                                                    (const uint8_t *)dev_n_alt, f_override, n_sites, window), t0);
+}
+
+int ibdg_upload_ms(ibdg_ctx *c, float out[3])
+{
+    if (!c || !out) return 1;
+    for (int i = 0; i < 3; ++i) out[i] = c->up_ms[i];
+    return 0;
+}
+
+void *ibdg_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    return p;
+}
+
+void ibdg_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
 }
 
 size_t ibdg_num_sites(const ibdg_ctx *c) { return c ? c->n_sites : 0; }
 size_t ibdg_num_windows(const ibdg_ctx *c) { return c ? c->n_win : 0; }
 
-int ibdg_get_windows(const ibdg_ctx *c, uint32_t *first, uint32_t *last, uint32_t *n_covered)
+int ibdg_get_windows(ibdg_ctx *c, uint32_t *first, uint32_t *last, uint32_t *n_covered)
 {
     if (!c) return 1;
+    if (c->n_win && (first || last) && !c->win_bounds_valid) {
+        if (quiesce(c)) return 1;
+        if (ensure(c, c->win_first, (size_t)c->n_win * 4) || ensure(c, c->win_last, (size_t)c->n_win * 4))
+            return 1;
+        ibdg::launch_prep_win_bounds((const uint32_t *)c->cov_site.p, c->n_cov, c->window, c->n_win,
+                                     (uint32_t *)c->win_first.p, (uint32_t *)c->win_last.p, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        c->win_first_h.resize(c->n_win);
+        c->win_last_h.resize(c->n_win);
+        HIP_TRY(c, hipMemcpyAsync(c->win_first_h.data(), c->win_first.p, (size_t)c->n_win * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->win_last_h.data(), c->win_last.p, (size_t)c->n_win * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->win_bounds_valid = true;
+    }
     for (uint32_t w = 0; w < c->n_win; ++w) {
-        const uint32_t b = w * c->window;
-        const uint32_t e = std::min<uint64_t>((uint64_t)b + c->window, c->n_cov);
-        if (first) first[w] = c->cov_site_h[b];
-        if (last) last[w] = c->cov_site_h[e - 1];
-        if (n_covered) n_covered[w] = e - b;
+        const uint64_t b = (uint64_t)w * c->window;
+        const uint64_t e = std::min<uint64_t>(b + c->window, c->n_cov);
+        if (first) first[w] = c->win_first_h[w];
+        if (last) last[w] = c->win_last_h[w];
+        if (n_covered) n_covered[w] = (uint32_t)(e - b);
     }
     return 0;
 }
@@ -784,7 +936,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
 {
     if (!c) return 1;
     if (!c->panel.p || c->n_ids == 0) return fail(c, "[::] ERROR in ibdg_run: no panel uploaded");
-    if (!c->rec_all.p) return fail(c, "[::] ERROR in ibdg_run: no sites uploaded");
+    if (!c->sites_valid) return fail(c, "[::] ERROR in ibdg_run: no sites uploaded");
     if (T == 0 || !targets) return fail(c, "[::] ERROR in ibdg_run: no targets");
     if (T > 65535) return fail(c, "[::] ERROR in ibdg_run: at most 65535 targets per call");
     for (size_t t = 0; t < T; ++t)
@@ -801,7 +953,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // timing steps): their device copies are rebuilt only when the inputs differ
     const bool same_inputs = c->prev_targets.size() == T && std::equal(targets, targets + T, c->prev_targets.begin()) &&
                              c->prev_pu == pu_id && c->prev_has_bg == (bg_count ? 1 : 0) && c->prev_lanes == lanes &&
-                             (!bg_count || std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin())) &&
+                             (!bg_count || (c->prev_bg.size() == c->n_ids &&
+                                            std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin()))) &&
                              (!ld_mode || c->weight.p);
     if (!same_inputs) {
         // stream2 may still read the previous targets: the main stream waits for it before overwriting

@@ -152,6 +152,64 @@ void launch_win_target_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, K
 int launch_ld_popcount_mt(const PopArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev = {});
 void launch_ld_finalize(const PopFinalArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
 
+// ---- per-comparison site preparation on the device (ibdg_prep.hip) ------------------------
+// What the host learns from it (one small device-to-host copy per stage).
+struct PrepInfo {
+    uint32_t n_cov;          // covered rows (n_ref+n_alt >= 1)
+    uint32_t err_row_site;   // smallest site whose row_index lies outside the panel, 0xffffffff if none
+    uint32_t err_cov_site;   // smallest site with n_ref+n_alt > max_cov, 0xffffffff if none
+    uint32_t out_of_order;   // 1: some covered row is not behind its predecessor in the panel
+    uint32_t first_row, last_row;   // panel rows of the first / last covered site
+    uint32_t n_segs;         // (window, 32-row tile) segments
+    uint32_t ct_max;         // most reads in one window
+    uint32_t max_seg;        // most segments in one run of windows
+    uint32_t adv_overflow;   // 1: two consecutive segments of a run are more than 255 tile pairs apart
+    uint32_t pad[2];
+};
+
+// a number in the x87 extended format, normalised: value = m / 2^64 * 2^e, m in [2^63, 2^64)
+struct WinRaw {
+    uint64_t m;
+    int32_t e;
+    int32_t pad;
+};
+
+struct PrepSiteArgs {
+    const uint32_t *row_index;  // device; NULL: site s is panel row s
+    const uint8_t *n_ref, *n_alt;
+    size_t n_sites, n_rows;
+    uint32_t max_cov;
+    uint2 *rec_all, *rec_cov;
+    uint32_t *cov_site;
+    uint32_t *block_tmp;        // prep_scan_blocks(n_sites) words
+    PrepInfo *info;
+};
+
+struct PrepSegArgs {
+    const uint2 *rec_cov;
+    uint32_t n_cov, window, n_win, max_cov;
+    const unsigned long long *nck;   // [(max_cov+1)^2] binomial coefficients
+    Seg *segs;                  // room for seg_cap segments
+    uint32_t seg_cap;           // segments beyond it are counted but not written (rows out of file order only)
+    WinConst *wconst;           // [n_win + 1]
+    WinRaw *raw;                // [n_win] K = prod C(cov, n_ref) per window
+    uint32_t *block_tmp;        // prep_scan_blocks(n_cov) words
+    PrepInfo *info;
+};
+
+size_t prep_scan_blocks(size_t n);
+// stage A: rec_all, rec_cov, cov_site, info->{n_cov, err_*, first_row, last_row}
+void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st);
+// stage B: segment masks, per-window reads / alt reads / K, info->{n_segs, ct_max, out_of_order}
+void launch_prep_segments(const PrepSegArgs &a, hipStream_t st);
+// control words for a given run structure, info->{max_seg, adv_overflow}
+void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring,
+                           hipStream_t st);
+// wconst[w].{mK, eK} = K * pow_1me[reads of w]
+void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st);
+void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t window, uint32_t n_win, uint32_t *first,
+                            uint32_t *last, hipStream_t st);
+
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st);
 void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st);

@@ -1,0 +1,489 @@
+// ibdg_prep.hip -- per-comparison site preparation on the device.
+//
+// What the reference does row by row inside its window loop -- telling covered rows from
+// zero-coverage rows (src/ibdgem.c:657-663), cutting windows of `window` covered rows
+// (:562-570, :723-730) and looking up the binomial coefficient of every row (src/ibd-math.c:55)
+// -- is done here once per ibdg_upload_sites for all rows at once:
+//   stage A  covered-row flags -> exclusive scan -> site records, covered-row list
+//   stage B  (window, 32-row tile) segment starts -> scan -> segment masks, per-window constants,
+//            control words of the exponent-counting --LD kernel (ibdg_ld_popcount.hip)
+// Both scans are the plain three-kernel kind (per-block totals, one block scans the totals, the
+// blocks redo their flags and scatter): 6-12 bytes per row, a few microseconds per kernel.
+//
+// K = prod C(cov, n_ref) over a window is taken in the x87 extended format the host used to
+// take it in (64-bit mantissa, round to nearest even after every factor, in row order), done in
+// integer arithmetic: the bits of K' = K (1-eps)^reads are the same as a `long double` loop on the
+// host would give.
+#include "ibdg_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace ibdg {
+
+namespace {
+
+constexpr int PREP_THREADS = 256;
+constexpr int PREP_ITEMS = 16;                       // rows of 256 consecutive elements per block
+constexpr int PREP_BLOCK = PREP_THREADS * PREP_ITEMS;
+
+// exclusive prefix over the 64 lanes of a wave; *total = the wave's sum (all lanes)
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total)
+{
+    const unsigned lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= (unsigned)off)
+            x += y;
+    }
+    *total = __shfl(x, 63);
+    return x - v;
+}
+
+// ---- the block-level part both stages share ---------------------------------------------------
+// A block owns PREP_BLOCK consecutive elements; thread t looks at elements base + i*256 + t, so
+// every access is coalesced.  flag_of(e) says whether element e is kept.
+// count: number of kept elements of the block.
+template <class F>
+__device__ __forceinline__ uint32_t block_count(size_t base, size_t n, F flag_of)
+{
+    __shared__ uint32_t wave_cnt[PREP_THREADS / 64];
+    uint32_t cnt = 0;
+#pragma unroll 4
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const bool f = e < n && flag_of(e);
+        cnt += (uint32_t)__popcll(__ballot(f));           // the same number in every lane of the wave
+    }
+    if ((threadIdx.x & 63) == 0)
+        wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < PREP_THREADS / 64; ++w)
+        tot += wave_cnt[w];
+    return tot;
+}
+
+// scatter: calls emit(e, k) for every kept element e of the block, k = its rank among all kept
+// elements (block_off = kept elements before this block), and other(e) for every element.
+template <class F, class E>
+__device__ __forceinline__ void block_scatter(size_t base, size_t n, uint32_t block_off, F flag_of, E emit)
+{
+    constexpr int NW = PREP_THREADS / 64;
+    __shared__ uint32_t pre[PREP_ITEMS * NW];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ballots[PREP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const bool f = e < n && flag_of(e);
+        ballots[i] = __ballot(f);
+        if (lane == 0)
+            pre[i * NW + wave] = (uint32_t)__popcll(ballots[i]);
+    }
+    __syncthreads();
+    if (wave == 0) {                                   // PREP_ITEMS * NW == 64 entries: one wave scans them
+        static_assert(PREP_ITEMS * NW == 64, "one wave scans the per-(row, wave) totals");
+        uint32_t tot;
+        const uint32_t v = pre[lane];
+        const uint32_t x = wave_excl_scan(v, &tot);
+        pre[lane] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        if (e < n && ((ballots[i] >> lane) & 1)) {
+            const uint32_t below = (uint32_t)__popcll(ballots[i] & ((1ull << lane) - 1));
+            emit(e, block_off + pre[i * NW + wave] + below);
+        }
+    }
+}
+
+// ---- stage A: rows -> records ----------------------------------------------------------------
+struct SiteIn {
+    const uint32_t *row_index;      // NULL: row s of the panel is site s
+    const uint8_t *n_ref, *n_alt;
+    size_t n_sites;
+    size_t n_rows;
+    uint32_t max_cov;
+};
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_site_count(SiteIn in, uint32_t *__restrict__ block_cnt,
+                                                                  PrepInfo *__restrict__ info)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    const uint32_t tot = block_count(base, in.n_sites, [&](size_t s) {
+        const unsigned r = in.n_ref[s], a = in.n_alt[s];
+        if (r + a > in.max_cov)
+            atomicMin(&info->err_cov_site, (uint32_t)s);
+        if (in.row_index && in.row_index[s] >= in.n_rows)
+            atomicMin(&info->err_row_site, (uint32_t)s);
+        return r + a >= 1;
+    });
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = tot;
+}
+
+// One block: exclusive scan of cnt[0..n) in place, the grand total to *total.
+__global__ __launch_bounds__(1024) void k_prep_scan(uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? cnt[i] : 0;
+        uint32_t wt;
+        const uint32_t x = wave_excl_scan(v, &wt);
+        if (lane == 0)
+            wave_tot[wave] = wt;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (unsigned w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        if (i < n)
+            cnt[i] = off + x;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry_s = off + x + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *total = carry_s;
+}
+
+struct SiteOut {
+    uint2 *rec_all;         // [n_sites] {row, lut byte offset}
+    uint2 *rec_cov;         // [n_cov] the same for covered rows
+    uint32_t *cov_site;     // [n_cov] site index of every covered row
+};
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, const uint32_t *__restrict__ block_off,
+                                                                    SiteOut out, PrepInfo *__restrict__ info)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    const uint32_t d = in.max_cov + 1;
+    const uint32_t n_cov = info->n_cov;
+    block_scatter(
+        base, in.n_sites, block_off[blockIdx.x],
+        [&](size_t s) {
+            const unsigned r = in.n_ref[s], a = in.n_alt[s];
+            // every row gets its record (an out-of-range pair is reported by the host and never used)
+            uint2 rc;
+            rc.x = in.row_index ? in.row_index[s] : (uint32_t)s;
+            rc.y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
+            out.rec_all[s] = rc;
+            return r + a >= 1;
+        },
+        [&](size_t s, uint32_t j) {
+            const unsigned r = in.n_ref[s], a = in.n_alt[s];
+            uint2 rc;
+            rc.x = in.row_index ? in.row_index[s] : (uint32_t)s;
+            rc.y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
+            out.rec_cov[j] = rc;
+            out.cov_site[j] = (uint32_t)s;
+            if (j == 0)
+                info->first_row = rc.x;
+            if (j + 1 == n_cov)
+                info->last_row = rc.x;
+        });
+}
+
+// ---- stage B: covered rows -> segments --------------------------------------------------------
+// Covered row j starts a segment when it starts a window (j % window == 0) or lies in another
+// 32-row tile than row j-1.
+struct SegIn {
+    const uint2 *rec_cov;
+    uint32_t n_cov;
+    uint32_t window;
+    uint32_t d;             // max_cov + 1
+};
+
+__device__ __forceinline__ bool seg_start(const SegIn &in, size_t j)
+{
+    if (j % in.window == 0)
+        return true;
+    return (in.rec_cov[j].x >> 5) != (in.rec_cov[j - 1].x >> 5);
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint32_t *__restrict__ block_cnt,
+                                                                 PrepInfo *__restrict__ info)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    const uint32_t tot = block_count(base, in.n_cov, [&](size_t j) {
+        if (j > 0 && in.rec_cov[j].x <= in.rec_cov[j - 1].x)
+            info->out_of_order = 1;                    // not in file order: only the strict kernel applies
+        return seg_start(in, j);
+    });
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = tot;
+}
+
+// The thread of a segment's first row walks the segment (at most 32 rows) and writes its masks.
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const uint32_t *__restrict__ block_off,
+                                                                 Seg *__restrict__ segs, uint32_t seg_cap,
+                                                                 WinConst *__restrict__ wconst)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    block_scatter(
+        base, in.n_cov, block_off[blockIdx.x], [&](size_t j) { return seg_start(in, j); },
+        [&](size_t j, uint32_t i) {
+            const uint32_t w = (uint32_t)(j / in.window);
+            const uint64_t wend64 = (uint64_t)(w + 1) * in.window;
+            const uint32_t wend = wend64 < in.n_cov ? (uint32_t)wend64 : in.n_cov;
+            const uint32_t tile = in.rec_cov[j].x >> 5;
+            uint32_t cov[8] = {0, 0, 0, 0, 0, 0, 0, 0}, alt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t jj = (uint32_t)j;
+            for (; jj < wend; ++jj) {
+                const uint2 rc = in.rec_cov[jj];
+                if ((rc.x >> 5) != tile)
+                    break;
+                const uint32_t idx = rc.y / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
+                const uint32_t bit = 1u << (rc.x & 31);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((cv >> k) & 1) cov[k] |= bit;
+                    if ((a >> k) & 1) alt[k] |= bit;
+                }
+            }
+            if (j % in.window == 0)
+                wconst[w].seg_begin = i;
+            if (i >= seg_cap)
+                return;                    // rows out of file order: the host drops these segments
+            uint4 *o = reinterpret_cast<uint4 *>(segs + i);
+            o[0] = make_uint4(tile, w, jj == wend ? 1u : 0u, 0u);         // tile, win, last, flags (k_prep_seg_flags)
+            o[1] = make_uint4(cov[0], cov[1], cov[2], cov[3]);
+            o[2] = make_uint4(cov[4], cov[5], cov[6], cov[7]);
+            o[3] = make_uint4(alt[0], alt[1], alt[2], alt[3]);
+            o[4] = make_uint4(alt[4], alt[5], alt[6], alt[7]);
+        });
+}
+
+// x = m / 2^64 * 2^e with m in [2^63, 2^64): a normalised x87 extended number
+struct X87 {
+    uint64_t m;
+    int32_t e;
+};
+
+// a * b rounded to nearest even at 64 bits, renormalised (what fmul + frexpl give on the host)
+__device__ __forceinline__ X87 x87_mul(X87 a, uint64_t bm, int32_t be)
+{
+    uint64_t hi = __umul64hi(a.m, bm), lo = a.m * bm;
+    int32_t e = a.e + be;
+    if (!(hi >> 63)) {                 // product in [2^126, 2^127): one bit up
+        hi = (hi << 1) | (lo >> 63);
+        lo <<= 1;
+        e -= 1;
+    }
+    const uint64_t half = 1ull << 63;
+    if (lo > half || (lo == half && (hi & 1))) {
+        hi += 1;
+        if (hi == 0) {                 // carried out of the mantissa
+            hi = half;
+            e += 1;
+        }
+    }
+    X87 r;
+    r.m = hi;
+    r.e = e;
+    return r;
+}
+
+// One thread per window: reads, alt reads and K = prod C(cov, n_ref) of its rows in row order
+// (src/ibd-math.c:55 factors of every P(D|G) of the window).
+__global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win, const unsigned long long *__restrict__ nck,
+                                                      WinConst *__restrict__ wconst, WinRaw *__restrict__ raw,
+                                                      PrepInfo *__restrict__ info)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > n_win)
+        return;
+    if (w == n_win) {                  // the entry behind the last window carries seg_begin = n_segs
+        wconst[w].mK = 0.0;
+        wconst[w].eK = 0;
+        wconst[w].cov_total = wconst[w].alt_total = 0;
+        wconst[w].seg_begin = info->n_segs;
+        return;
+    }
+    const uint64_t b = (uint64_t)w * in.window;
+    const uint64_t e64 = b + in.window;
+    const uint32_t e = e64 < in.n_cov ? (uint32_t)e64 : in.n_cov;
+    X87 K;
+    K.m = 1ull << 63;                  // 1.0 = 0.5 * 2^1
+    K.e = 1;
+    uint32_t ct = 0, at = 0;
+    for (uint32_t j = (uint32_t)b; j < e; ++j) {
+        const uint32_t idx = in.rec_cov[j].y / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
+        ct += cv;
+        at += a;
+        const uint64_t c = nck[(size_t)cv * in.d + r];
+        if (c > 1) {                   // times 1 changes nothing (and c is never 0 for r <= cv)
+            const int z = __clzll((long long)c);
+            K = x87_mul(K, c << z, 64 - z);
+        }
+    }
+    raw[w].m = K.m;
+    raw[w].e = K.e;
+    wconst[w].cov_total = ct;
+    wconst[w].alt_total = at;
+    atomicMax(&info->ct_max, ct);
+}
+
+// K' = K * (1-eps)^reads as {double mantissa, exponent}: one more x87 product, then the
+// conversion to double (round to nearest even at 53 bits).
+__global__ __launch_bounds__(256) void k_prep_win_kp(uint32_t n_win, const WinRaw *__restrict__ raw,
+                                                     const WinRaw *__restrict__ pow_1me, WinConst *__restrict__ wconst)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_win)
+        return;
+    X87 K;
+    K.m = raw[w].m;
+    K.e = raw[w].e;
+    const WinRaw B = pow_1me[wconst[w].cov_total];
+    const X87 Kp = x87_mul(K, B.m, B.e);
+    const uint64_t low = Kp.m & 0x7ffull;
+    uint64_t q = Kp.m >> 11;
+    if (low > 0x400ull || (low == 0x400ull && (q & 1)))
+        q += 1;                        // may reach 2^53: mantissa 1.0, as the host's cast would give
+    wconst[w].mK = (double)q * 0x1p-53;
+    wconst[w].eK = Kp.e;
+}
+
+// One thread per segment: the control word of the --LD kernel (ibdg::Seg::flags), which depends on
+// the run structure; one thread per run: the largest number of segments in a run.
+__global__ __launch_bounds__(256) void k_prep_seg_flags(Seg *__restrict__ segs, const WinConst *__restrict__ wconst,
+                                                        const uint32_t *__restrict__ run_begin, uint32_t n_runs,
+                                                        uint32_t ring, uint32_t seg_cap, PrepInfo *__restrict__ info)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_segs = info->n_segs;
+    if (i < n_runs)
+        atomicMax(&info->max_seg, wconst[run_begin[i + 1]].seg_begin - wconst[run_begin[i]].seg_begin);
+    if (i >= n_segs || n_segs > seg_cap)       // more segments than room: rows out of order, nothing to prepare
+        return;
+    Seg &sg = segs[i];
+    // the run of the segment's window: last r with run_begin[r] <= win
+    uint32_t lo = 0, hi = n_runs;      // run_begin[lo] <= win < run_begin[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (run_begin[mid] <= sg.win)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t s0 = wconst[run_begin[lo]].seg_begin, s1 = wconst[run_begin[lo + 1]].seg_begin;
+    const uint32_t q0 = segs[s0].tile >> 1;
+    uint32_t nc = 0, na = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (sg.cov[k]) nc = k + 1;
+        if (sg.alt[k]) na = k + 1;
+    }
+    uint32_t nslot = 0, nhalf = 0, adv = 0;
+    if (i + 1 < s1) {
+        const uint32_t tn = segs[i + 1].tile, qn = tn >> 1;
+        adv = qn - (sg.tile >> 1);
+        if (adv > 255) {
+            info->adv_overflow = 1;    // rows too far apart for the record format: strict kernel
+            adv = 255;
+        }
+        nslot = (qn - q0) % ring;
+        nhalf = tn & 1;
+    }
+    sg.flags = nslot | (nhalf << 3) | (adv << 4) | ((nc > 3 || na > 2) ? 1u << 12 : 0u) | (sg.last ? 1u << 13 : 0u) |
+               (nc << 16) | (na << 24);
+}
+
+// first / last site of every window (ibdg_get_windows)
+__global__ __launch_bounds__(256) void k_prep_win_bounds(const uint32_t *__restrict__ cov_site, uint32_t n_cov,
+                                                         uint32_t window, uint32_t n_win, uint32_t *__restrict__ first,
+                                                         uint32_t *__restrict__ last)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_win)
+        return;
+    const uint64_t b = (uint64_t)w * window, e64 = b + window;
+    const uint32_t e = e64 < n_cov ? (uint32_t)e64 : n_cov;
+    first[w] = cov_site[b];
+    last[w] = cov_site[e - 1];
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + PREP_BLOCK - 1) / PREP_BLOCK); }
+
+}  // namespace
+
+size_t prep_scan_blocks(size_t n) { return blocks_for(n); }
+
+void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st)
+{
+    if (a.n_sites == 0)
+        return;
+    SiteIn in;
+    in.row_index = a.row_index;
+    in.n_ref = a.n_ref;
+    in.n_alt = a.n_alt;
+    in.n_sites = a.n_sites;
+    in.n_rows = a.n_rows;
+    in.max_cov = a.max_cov;
+    SiteOut out;
+    out.rec_all = a.rec_all;
+    out.rec_cov = a.rec_cov;
+    out.cov_site = a.cov_site;
+    const unsigned nb = blocks_for(a.n_sites);
+    hipLaunchKernelGGL(k_prep_site_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_cov);
+    hipLaunchKernelGGL(k_prep_site_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, out, a.info);
+}
+
+void launch_prep_segments(const PrepSegArgs &a, hipStream_t st)
+{
+    if (a.n_cov == 0)
+        return;
+    SegIn in;
+    in.rec_cov = a.rec_cov;
+    in.n_cov = a.n_cov;
+    in.window = a.window;
+    in.d = a.max_cov + 1;
+    const unsigned nb = blocks_for(a.n_cov);
+    hipLaunchKernelGGL(k_prep_seg_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs);
+    hipLaunchKernelGGL(k_prep_seg_build, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.segs, a.seg_cap,
+                       a.wconst);
+    hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 1 + 63) / 64), dim3(64), 0, st, in, a.n_win, a.nck, a.wconst,
+                       a.raw, a.info);
+}
+
+void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring,
+                           hipStream_t st)
+{
+    const uint32_t n = a.seg_cap > n_runs ? a.seg_cap : n_runs;
+    if (n == 0)
+        return;
+    hipLaunchKernelGGL(k_prep_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, a.segs, a.wconst, run_begin, n_runs,
+                       ring, a.seg_cap, a.info);
+}
+
+void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st)
+{
+    if (n_win == 0)
+        return;
+    hipLaunchKernelGGL(k_prep_win_kp, dim3((n_win + 255) / 256), dim3(256), 0, st, n_win, raw, pow_1me, wconst);
+}
+
+void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t window, uint32_t n_win, uint32_t *first,
+                            uint32_t *last, hipStream_t st)
+{
+    if (n_win == 0)
+        return;
+    hipLaunchKernelGGL(k_prep_win_bounds, dim3((n_win + 255) / 256), dim3(256), 0, st, cov_site, n_cov, window, n_win,
+                       first, last);
+}
+
+}  // namespace ibdg

@@ -27,6 +27,10 @@ SYMBOLS = {
     "ibdg_upload_panel": (C.c_int, [_P, _P, C.c_size_t, C.c_uint]),
     "ibdg_upload_panel_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_uint]),
     "ibdg_upload_sites": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint]),
+    "ibdg_upload_sites_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint]),
+    "ibdg_upload_ms": (C.c_int, [_P, _P]),
+    "ibdg_host_alloc": (_P, [C.c_size_t]),
+    "ibdg_host_free": (None, [_P]),
     "ibdg_num_sites": (C.c_size_t, [_P]),
     "ibdg_num_windows": (C.c_size_t, [_P]),
     "ibdg_get_windows": (C.c_int, [_P, _P, _P, _P]),
@@ -62,12 +66,41 @@ def load_library(path=LIB_PATH):
                           "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
+        if path != LIB_PATH and not hasattr(lib, name):
+            continue                   # an older build of the ABI loaded for an A/B comparison
         fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
     if path == LIB_PATH:
         _lib = lib
     return lib
+
+
+class PinnedArray:
+    """A numpy array over page-locked memory from ibdg_host_alloc (freed by close() or the collector)."""
+
+    def __init__(self, shape, dtype):
+        lib = load_library()
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self.ptr = lib.ibdg_host_alloc(n)
+        if not self.ptr:
+            raise EngineError("ibdg_host_alloc failed")
+        self._lib = lib
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.ibdg_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pack_alleles(alleles):
@@ -98,8 +131,8 @@ def pack_alleles_fast(alleles):
 
 
 class Engine:
-    def __init__(self, device=0, epsilon=0.02, max_cov=20):
-        self.lib = load_library()
+    def __init__(self, device=0, epsilon=0.02, max_cov=20, lib_path=None):
+        self.lib = load_library(lib_path) if lib_path else load_library()
         self.ctx = self.lib.ibdg_create(device, epsilon, max_cov)
         if not self.ctx:
             raise EngineError(self.lib.ibdg_last_error(None).decode())
@@ -140,13 +173,26 @@ class Engine:
         self.n_ids = n_ids
 
     def upload_sites(self, row_index, n_ref, n_alt, window, f_override=None):
-        ri = np.ascontiguousarray(row_index, dtype=np.uint32)
+        """row_index None: site s is panel row s."""
+        ri = None if row_index is None else np.ascontiguousarray(row_index, dtype=np.uint32)
         nr = np.ascontiguousarray(n_ref, dtype=np.uint8)
         na = np.ascontiguousarray(n_alt, dtype=np.uint8)
         fo = None if f_override is None else np.ascontiguousarray(f_override, dtype=np.float64)
-        assert len(ri) == len(nr) == len(na)
-        self._chk(self.lib.ibdg_upload_sites(self.ctx, ri.ctypes.data, nr.ctypes.data, na.ctypes.data,
-                                             None if fo is None else fo.ctypes.data, len(ri), window))
+        assert len(nr) == len(na) and (ri is None or len(ri) == len(nr))
+        self._chk(self.lib.ibdg_upload_sites(self.ctx, None if ri is None else ri.ctypes.data, nr.ctypes.data,
+                                             na.ctypes.data, None if fo is None else fo.ctypes.data, len(nr), window))
+
+    def upload_sites_dev(self, row_index_ptr, n_ref_ptr, n_alt_ptr, n_sites, window, f_override=None):
+        """The same with the three arrays in device memory (pointers; row_index_ptr may be None/0)."""
+        fo = None if f_override is None else np.ascontiguousarray(f_override, dtype=np.float64)
+        self._chk(self.lib.ibdg_upload_sites_dev(self.ctx, row_index_ptr or None, n_ref_ptr, n_alt_ptr,
+                                                 None if fo is None else fo.ctypes.data, n_sites, window))
+
+    def upload_ms(self):
+        """Clocks of the last upload of sites (ms): copies, device preparation, whole call."""
+        out = (C.c_float * 3)()
+        self._chk(self.lib.ibdg_upload_ms(self.ctx, out))
+        return dict(h2d=out[0], device_prep=out[1], call=out[2])
 
     @property
     def n_sites(self):
@@ -178,13 +224,17 @@ class Engine:
         self._chk(self.lib.ibdg_get_site_af(self.ctx, out.ctypes.data))
         return out
 
-    def site_ll(self, t=0):
-        out = np.empty((self.n_sites, 3), dtype=np.float64)
+    def site_ll(self, t=0, out=None):
+        if out is None:
+            out = np.empty((self.n_sites, 3), dtype=np.float64)
+        assert out.dtype == np.float64 and out.size >= self.n_sites * 3 and out.flags.c_contiguous
         self._chk(self.lib.ibdg_get_site_ll(self.ctx, t, out.ctypes.data))
         return out
 
-    def window_ll(self, t=0):
-        out = np.empty((self.n_windows, 3), dtype=np.float64)
+    def window_ll(self, t=0, out=None):
+        if out is None:
+            out = np.empty((self.n_windows, 3), dtype=np.float64)
+        assert out.dtype == np.float64 and out.size >= self.n_windows * 3 and out.flags.c_contiguous
         self._chk(self.lib.ibdg_get_window_ll(self.ctx, t, out.ctypes.data))
         return out
 

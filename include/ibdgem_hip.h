@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 1
+#define IBDG_ABI_VERSION 2
 
 typedef struct ibdg_ctx ibdg_ctx;
 
@@ -91,15 +91,38 @@ int ibdg_upload_panel_dev(ibdg_ctx *ctx, const void *dev_rows, size_t n_rows, un
 /* ---- the rows of one comparison ------------------------------------------ */
 
 /* The rows that passed the reference's filter chain (src/ibdgem.c:584-626)
- * in file order: row_index into the uploaded panel, read counts after -D
- * culling (src/ibdgem.c:620-628; n_ref+n_alt <= max_cov), optional -A
+ * in file order: row_index into the uploaded panel (NULL: site s is panel row
+ * s, n_sites <= panel rows), read counts after -D culling
+ * (src/ibdgem.c:620-628; n_ref+n_alt <= max_cov), optional -A
  * frequency (NaN = use the panel's own; pointer may be NULL), window = -w.
  * Rows with n_ref+n_alt == 0 get per-site values but join no window
  * (src/ibdgem.c:657-663).  Windows are consecutive runs of `window` covered
- * rows; the last may be shorter (src/ibdgem.c:572-578, :736). */
+ * rows; the last may be shorter (src/ibdgem.c:572-578, :736).
+ * The three arrays are copied to the device (6 bytes per row) and everything
+ * else -- the covered-row list, the windows, the per-window constants of the
+ * --LD kernel -- is derived there (ibdgem_amd/csrc/ibdg_prep.hip); arrays from
+ * ibdg_host_alloc are copied at link speed.  Returns when the device is done. */
 int ibdg_upload_sites(ibdg_ctx *ctx, const uint32_t *row_index, const uint8_t *n_ref,
                       const uint8_t *n_alt, const double *f_override, size_t n_sites,
                       unsigned window);
+
+/* Same, with row_index / n_ref / n_alt already in this context's device memory
+ * (uint32 / uint8 / uint8; dev_row_index may be NULL as above).  f_override
+ * stays a HOST array (or NULL): its powers are taken with the host's libm. */
+int ibdg_upload_sites_dev(ibdg_ctx *ctx, const void *dev_row_index, const void *dev_n_ref,
+                          const void *dev_n_alt, const double *f_override, size_t n_sites,
+                          unsigned window);
+
+/* Clocks of the last ibdg_upload_sites[_dev] (ms): out[0] host-to-device copies
+ * of the arrays, out[1] preparation on the device including its two small
+ * read-backs, out[2] the whole call on the host's clock. */
+int ibdg_upload_ms(ibdg_ctx *ctx, float out[3]);
+
+/* Page-locked host memory for arrays handed to ibdg_upload_* / ibdg_get_*:
+ * copies to and from it run at the link's speed instead of going through a
+ * staging buffer.  NULL on failure.  Any host memory works; this is optional. */
+void *ibdg_host_alloc(size_t bytes);
+void ibdg_host_free(void *p);
 
 size_t ibdg_num_sites(const ibdg_ctx *ctx);
 size_t ibdg_num_windows(const ibdg_ctx *ctx);
@@ -107,7 +130,7 @@ size_t ibdg_num_windows(const ibdg_ctx *ctx);
 /* Per window: index (into the uploaded site list) of its first and last
  * covered row, and NUM_SITES (src/ibdgem.c:723-730, :751-756).  Any pointer
  * may be NULL. */
-int ibdg_get_windows(const ibdg_ctx *ctx, uint32_t *first, uint32_t *last, uint32_t *n_covered);
+int ibdg_get_windows(ibdg_ctx *ctx, uint32_t *first, uint32_t *last, uint32_t *n_covered);
 
 /* ---- run ------------------------------------------------------------------- */
 
@@ -117,7 +140,8 @@ int ibdg_get_windows(const ibdg_ctx *ctx, uint32_t *first, uint32_t *last, uint3
  *   bg_count    NULL = every individual is background once
  *               (src/ibdgem.c:517-520), else n_ids bytes: how many times the
  *               individual appears in the -B list (read_rf keeps duplicates,
- *               src/ibd-parse.c:262-308)
+ *               src/ibd-parse.c:262-308); one byte each, so at most 255
+ *               listings of one individual (the host program refuses more)
  *   pu_id       individual whose name equals -N, or -1 (src/ibdgem.c:501-506)
  *   ld_mode     --LD: LIBD0/LIBD1 of each window are the background averages
  *               of src/ibdgem.c:736-753; otherwise the plain products (:755).

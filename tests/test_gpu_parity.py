@@ -546,3 +546,15 @@ def test_dispatch_events_give_the_dominant_kernel_duration():
                 assert 0 < k <= ms["ld"] <= ms["total"] + 1e-3, (k, ms)
             assert_bits(eng.window_ll(0), want, "dispatch events")
         eng.set_option("async", 0)
+
+
+def test_results_are_the_bits_of_round_1():
+    """Site preparation moved from the host to the device in round 2 (ibdg_prep.hip, the x87 products in
+    integer arithmetic) and the --LD kernel was reworked: the window and per-site results must still be
+    the very bits the round-1 library produced (tests/golden/r01_ld_hashes.json, tools/r01_hashes.py)."""
+    import json
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import r01_hashes
+    with open(os.path.join(REPO, "tests", "golden", "r01_ld_hashes.json")) as fh:
+        want = json.load(fh)["sha256"]
+    assert r01_hashes.digests() == want
