@@ -922,9 +922,12 @@ int main(int argc, char **argv)
         if (read_idlist_file(bg_fn, &ids, "Reference sample %s not found in input panel.\n", "read_rf", &bg))
             exit(1);
         bg_count = calloc(n_ids, 1);
-        for (size_t i = 0; i < bg.n; ++i)
-            if (bg_count[bg.idx[i]] < 255)
-                bg_count[bg.idx[i]]++;
+        for (size_t i = 0; i < bg.n; ++i) {
+            /* the engine takes one byte per individual: a list naming somebody 256 times is refused, not truncated */
+            if (bg_count[bg.idx[i]] == 255)
+                DIE("[::] ERROR: Reference sample %s is listed more than 255 times in %s.\n", ids.names[bg.idx[i]], bg_fn);
+            bg_count[bg.idx[i]]++;
+        }
     }
     const long pu_id = find_name(&ids, opt_sq);            /* is the pileup's own name in the panel? (:501-506) */
 

@@ -2,15 +2,18 @@
 
 configs[1]  non-LD, ~100k SNP rows, 1 comparison individual   -> bit-exact vs the oracle
 configs[2]  --LD, ~100k rows, 100-individual panel, window 100 -> per-site bit-exact, LD 1e-10
-configs[3]  --LD, 4M rows, 2504-individual panel, window 100   -> the oracle cannot run this in
-            seconds, so: (a) 64 windows sampled across the chromosome are recomputed by the oracle
-            from the panel rows read back from the device input, (b) the strict and the
+configs[3]  --LD, 4M rows, 2504-individual panel, window 100   -> (a) EVERY window is recomputed by
+            the oracle (a pool of host processes over ranges of windows, tests/oracle_pool.py;
+            ~70 core-seconds) from the panel rows read back from the device input, (b) the strict and the
             exponent-counting kernels agree on every window, (c) two half-chromosome shards cut at a
             window boundary reproduce the whole, (d) a second run is bit-identical, (e) alt counts of
             sampled rows equal numpy popcounts.
 The synthetic data are bench.py's (same generator, same seed)."""
+import contextlib
 import os
+import shutil
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -20,6 +23,7 @@ sys.path.insert(0, REPO)
 
 from ibdgem_amd import engine as E            # noqa: E402
 from ibdgem_amd.sharding import shard_rows    # noqa: E402
+import oracle_pool                            # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TINY = 1e-290
@@ -93,8 +97,33 @@ def chr1():
     torch.cuda.synchronize()
     eng = E.Engine(0, 0.02, 20)
     eng.upload_panel_dev(panel.data_ptr(), L, N)
-    yield dict(eng=eng, panel=panel, nr=nr, na=na, L=L, N=N, target=target, torch=torch)
+    state = dict(eng=eng, panel=panel, nr=nr, na=na, L=L, N=N, target=target, torch=torch)
+    yield state
     eng.close()
+    if state.get("shm"):
+        shutil.rmtree(state["shm"], ignore_errors=True)
+
+
+@contextlib.contextmanager
+def shm_dir(chr1):
+    """A directory in /dev/shm holding the packed panel and the read counts for the oracle pool (the
+    panel is written once per session), cleaned of the per-call result files on exit."""
+    d = chr1.get("shm")
+    if d is None:
+        d = chr1["shm"] = tempfile.mkdtemp(prefix="ibdg_pool_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        words = np.empty((chr1["L"], chr1["panel"].shape[1]), dtype=np.uint64)
+        for a in range(0, chr1["L"], 500_000):              # 2.56 GB, copied in slices
+            words[a:a + 500_000] = chr1["panel"][a:a + 500_000].cpu().numpy().view(np.uint64)
+        np.save(os.path.join(d, "panel.npy"), words)
+        del words
+        np.save(os.path.join(d, "n_ref.npy"), chr1["nr"])
+        np.save(os.path.join(d, "n_alt.npy"), chr1["na"])
+    try:
+        yield d
+    finally:
+        for fn in ("win.npy", "site.npy"):
+            if os.path.exists(os.path.join(d, fn)):
+                os.remove(os.path.join(d, fn))
 
 
 def test_config3_chr1_2504_individuals(chr1, oracle):
@@ -122,18 +151,15 @@ def test_config3_chr1_2504_individuals(chr1, oracle):
     worst = ld_close(win[:, :2], strict[:, :2])
     print(f"exponent counting vs strict over {n_win} windows: max rel {worst:.2e}")
 
-    # (a) oracle on sampled windows, from the rows as the device received them
+    # (a) the oracle on EVERY window, from the rows as the device received them
+    with shm_dir(chr1) as d:
+        np.save(os.path.join(d, "win.npy"), win)
+        np.save(os.path.join(d, "site.npy"), site)
+        checked, worst_orc, bad = oracle_pool.check_all_windows(d, first, L, N, t, 100)
+    assert not bad, bad[:5]
+    assert checked == n_win
+    print(f"oracle on all {checked} windows: max rel {worst_orc:.2e}")
     rng = np.random.default_rng(5)
-    pick = np.unique(np.concatenate([[0, 1, n_win - 2, n_win - 1], rng.integers(0, n_win, 60)]))
-    for w in pick:
-        a, b = int(first[w]), int(last[w]) + 1
-        words = chr1["panel"][a:b].cpu().numpy().view(np.uint64)
-        alle = bench.unpack_rows(words, N)
-        res = oracle.compare(alle, nr[a:b], na[a:b], t, window=100, ld=True)
-        assert len(res["win"]) == 1 and res["nsites"][0] == ncov[w]
-        assert (bits(site[a:b]) == bits(res["site"])).all(), w
-        assert bits(win[w, 2]) == bits(res["win"][0, 2])
-        ld_close(win[w:w + 1, :2], res["win"][:, :2])
 
     # (e) alt counts
     rows = rng.integers(0, L, 200)
@@ -173,12 +199,13 @@ def test_config5_500_comparison_individuals_in_one_launch(chr1, oracle):
         eng.run([int(targets[i])], ld=True, pu_id=int(targets[3]))
         assert (bits(eng.window_ll(0)) == bits(batched[i][0])).all(), f"target slot {i}: windows"
         assert (bits(eng.site_ll(0)) == bits(batched[i][1])).all(), f"target slot {i}: sites"
+    # the oracle on every window of two of the 500 (slot 3 is also the pileup's own sample, -N)
     for i in (3, 499):
-        t = int(targets[i])
-        for w in rng.integers(0, n_win, 6):
-            a, b = int(first[w]), int(last[w]) + 1
-            alle = bench.unpack_rows(chr1["panel"][a:b].cpu().numpy().view(np.uint64), N)
-            res = oracle.compare(alle, nr[a:b], na[a:b], t, window=100, ld=True, pu_id=int(targets[3]))
-            assert (bits(batched[i][1][a:b]) == bits(res["site"])).all()
-            assert bits(batched[i][0][w, 2]) == bits(res["win"][0, 2])
-            ld_close(batched[i][0][w:w + 1, :2], res["win"][:, :2])
+        with shm_dir(chr1) as d:
+            np.save(os.path.join(d, "win.npy"), batched[i][0])
+            np.save(os.path.join(d, "site.npy"), batched[i][1])
+            checked, worst, bad = oracle_pool.check_all_windows(d, first, L, N, int(targets[i]), 100,
+                                                                pu_id=int(targets[3]))
+        assert not bad, bad[:5]
+        assert checked == n_win
+        print(f"target slot {i}: oracle on all {checked} windows, max rel {worst:.2e}")

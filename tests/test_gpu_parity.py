@@ -10,6 +10,9 @@ Bars (BASELINE.json north_star):
     below 1e-290" otherwise (the sum over the background is a tree on the
     GPU and a serial loop in the reference; observed differences are ~1e-15).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -553,8 +556,123 @@ def test_results_are_the_bits_of_round_1():
     integer arithmetic) and the --LD kernel was reworked: the window and per-site results must still be
     the very bits the round-1 library produced (tests/golden/r01_ld_hashes.json, tools/r01_hashes.py)."""
     import json
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import r01_hashes
     with open(os.path.join(REPO, "tests", "golden", "r01_ld_hashes.json")) as fh:
         want = json.load(fh)["sha256"]
     assert r01_hashes.digests() == want
+
+
+# --------------------------------------------------------------------------- site preparation on the device
+def test_one_engine_two_panels(oracle):
+    """A context that uploads a second panel with another number of individuals (same lane count) and
+    runs the same comparison individuals must not reuse the background weights of the first."""
+    alle_a, nr, na = synth(71, 400, 100)
+    alle_b, _, _ = synth(72, 400, 120)
+    with E.Engine() as eng:
+        for alle, N in ((alle_a, 100), (alle_b, 120), (alle_a, 100)):
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            with pytest.raises(E.EngineError, match="no sites"):
+                eng.run([3, 50], ld=True)                 # the sites of the previous panel are gone
+            eng.upload_sites(np.arange(400), nr, na, 100)
+            bg = np.ones(N, dtype=np.uint8)
+            bg[7] = 3
+            for bgc, refids in ((None, None), (bg, list(range(N)) + [7, 7])):
+                eng.run([3, 50], ld=True, bg_count=bgc)
+                for i, t in enumerate((3, 50)):
+                    res = oracle.compare(alle, nr, na, t, window=100, ld=True, refids=refids)
+                    assert_bits(eng.site_ll(i), res["site"], f"N={N} site")
+                    assert_ld_close(eng.window_ll(i)[:, :2], res["win"][:, :2], f"N={N} t={t} LD")
+
+
+def windows_numpy(nr, na, W):
+    cov = np.flatnonzero((nr.astype(int) + na) > 0)
+    n_win = (len(cov) + W - 1) // W
+    first = cov[::W][:n_win]
+    last = np.array([cov[min(len(cov), (w + 1) * W) - 1] for w in range(n_win)], dtype=np.int64)
+    ncov = np.array([min(len(cov), (w + 1) * W) - w * W for w in range(n_win)], dtype=np.int64)
+    return first, last, ncov
+
+
+@pytest.mark.parametrize("L,W,cov_mean", [(20000, 100, 2.0), (9000, 3, 0.3), (4096, 4096, 1.0), (4097, 17, 5.0),
+                                          (70000, 1000, 2.0)])
+def test_device_resident_inputs_identity_rows_and_pinned_arrays(oracle, L, W, cov_mean):
+    """ibdg_upload_sites with pageable arrays, with page-locked arrays (ibdg_host_alloc), with row_index
+    NULL, and ibdg_upload_sites_dev with torch tensors all give the same windows and results."""
+    import torch
+    N = 64
+    alle, nr, na = synth(500 + L, L, N, cov_mean)
+    want_first, want_last, want_ncov = windows_numpy(nr, na, W)
+    got = []
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        pins = [E.PinnedArray(L, np.uint32), E.PinnedArray(L, np.uint8), E.PinnedArray(L, np.uint8)]
+        pins[0].array[:] = np.arange(L)
+        pins[1].array[:] = nr
+        pins[2].array[:] = na
+        dr = torch.arange(L, dtype=torch.int32, device="cuda")
+        dnr, dna = torch.from_numpy(nr).cuda(), torch.from_numpy(na).cuda()
+        torch.cuda.synchronize()
+        uploads = [lambda: eng.upload_sites(np.arange(L), nr, na, W),
+                   lambda: eng.upload_sites(None, nr, na, W),
+                   lambda: eng.upload_sites(pins[0].array, pins[1].array, pins[2].array, W),
+                   lambda: eng.upload_sites_dev(dr.data_ptr(), dnr.data_ptr(), dna.data_ptr(), L, W),
+                   lambda: eng.upload_sites_dev(None, dnr.data_ptr(), dna.data_ptr(), L, W)]
+        for up in uploads:
+            up()
+            ms = eng.upload_ms()
+            assert ms["call"] > 0 and ms["device_prep"] > 0
+            first, last, ncov = eng.windows()
+            assert (first == want_first).all() and (last == want_last).all() and (ncov == want_ncov).all()
+            eng.run([9], ld=True)
+            assert eng.last_ld_variant() == 2
+            out = E.PinnedArray((L, 3), np.float64)
+            got.append((eng.window_ll(0).copy(), eng.site_ll(0, out=out.array).copy()))
+            out.close()
+        for p in pins:
+            p.close()
+    for w, s in got[1:]:
+        assert_bits(w, got[0][0], "windows of the upload variants")
+        assert_bits(s, got[0][1], "sites of the upload variants")
+    res = oracle.compare(alle, nr, na, 9, window=W, ld=True)
+    assert_bits(got[0][1], res["site"], "site")
+    assert_bits(got[0][0][:, 2], res["win"][:, 2], "LIBD2")
+    assert_ld_close(got[0][0][:, :2], res["win"][:, :2], "LD")
+
+
+def test_rows_in_any_order_and_the_first_offending_site(oracle):
+    """Rows visited in a random order (several scan blocks, duplicates included) take the strict kernel and
+    still equal the oracle; errors name the first offending site in list order, its row before its counts."""
+    N, Lp, L = 70, 3000, 10000
+    alle, _, _ = synth(81, Lp, N)
+    rng = np.random.default_rng(82)
+    rows = rng.integers(0, Lp, size=L).astype(np.uint32)
+    cov = np.minimum(rng.poisson(1.5, size=L), 20)
+    na = rng.binomial(cov, 0.3).astype(np.uint8)
+    nr = (cov - na).astype(np.uint8)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(rows, nr, na, 100)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 1
+        res = oracle.compare(alle[rows], nr, na, 1, window=100, ld=True)
+        assert_bits(eng.site_ll(0), res["site"], "site")
+        assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "LD")
+        first, last, ncov = eng.windows()
+        assert (first == res["first"]).all() and (last == res["last"]).all() and (ncov == res["nsites"]).all()
+        bad_rows, bad_nr = rows.copy(), nr.copy()
+        bad_nr[5000] = 21
+        bad_rows[7000] = Lp
+        with pytest.raises(E.EngineError, match=r"site 5000 has n_ref\+n_alt=2[1-9]"):
+            eng.upload_sites(bad_rows, bad_nr, na, 100)
+        bad_rows[5000] = Lp + 3
+        with pytest.raises(E.EngineError, match=rf"row_index\[5000\]={Lp + 3} outside the panel"):
+            eng.upload_sites(bad_rows, bad_nr, na, 100)
+        bad_rows[4999] = 2 ** 32 - 1
+        with pytest.raises(E.EngineError, match=r"row_index\[4999\]=4294967295"):
+            eng.upload_sites(bad_rows, bad_nr, na, 100)
+        with pytest.raises(E.EngineError, match="no sites"):
+            eng.run([1], ld=True)                     # a failed upload leaves no sites behind
+        with pytest.raises(E.EngineError, match="outside the panel"):
+            eng.upload_sites(None, np.ones(Lp + 1, np.uint8), np.ones(Lp + 1, np.uint8), 100)

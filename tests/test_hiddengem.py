@@ -16,7 +16,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 GOLD = os.path.join(HERE, "golden")
-EXE = os.path.join(REPO, "ibdgem_amd", "host", "hiddengem")
+# HIDDENGEM_EXE: another build of the same program (tests/test_host_asan.py points it at the sanitizer build)
+EXE = os.environ.get("HIDDENGEM_EXE") or os.path.join(REPO, "ibdgem_amd", "host", "hiddengem")
 
 
 def _exe():

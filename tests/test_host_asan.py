@@ -1,0 +1,31 @@
+"""The host C programs under AddressSanitizer + UndefinedBehaviorSanitizer (sanitizers on
+the host build; the GPU pool offers none for device code).
+
+`make -C ibdgem_amd/host asan` builds ibdgem_asan / hiddengem_asan; the CPU-tier host tests (option
+handling, the integer plan of every golden case, genotype ingest for every thread count, hiddengem's
+golden tables) are then rerun against those binaries in a child pytest.  Any sanitizer report aborts
+the program, which fails the test that ran it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(REPO, "ibdgem_amd", "host")
+
+
+@pytest.mark.skipif(os.environ.get("IBDGEM_EXE") is not None, reason="already inside the sanitizer rerun")
+def test_host_tests_pass_under_asan_and_ubsan():
+    subprocess.run(["make", "-C", os.path.join(REPO, "ibdgem_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", HOST, "asan"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ,
+               IBDGEM_EXE=os.path.join(HOST, "ibdgem_asan"), HIDDENGEM_EXE=os.path.join(HOST, "hiddengem_asan"),
+               # the HIP runtime the engine library pulls in keeps allocations until exit: leak checking off
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
+                        "tests/test_host_cli.py", "tests/test_host_ingest.py", "tests/test_hiddengem.py"],
+                       cwd=REPO, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

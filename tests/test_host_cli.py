@@ -15,7 +15,8 @@ import pytest
 import golden_io as G
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
+# IBDGEM_EXE: another build of the same program (tests/test_host_asan.py points it at the sanitizer build)
+EXE = os.environ.get("IBDGEM_EXE") or os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
 
 
 def _exe():
@@ -134,6 +135,20 @@ def test_option_errors_match_the_reference():
     assert r.returncode == 1 and "ERROR parsing Pileup data" in r.stderr
     r = run()
     assert r.returncode == 0 and "Usage:" in r.stderr
+
+
+def test_background_list_naming_someone_256_times_is_refused(tmp_path):
+    """The engine's background multiplicities are one byte each (include/ibdgem_hip.h): 255 listings of
+    one individual pass, 256 are an error -- never a silent truncation."""
+    base = ["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "test1.pileup", "--LD", "--plan"]
+    for n, ok in ((255, True), (256, False)):
+        lst = tmp_path / f"bg{n}.txt"
+        lst.write_text("sample2\n" + "sample3\n" * n)
+        r = subprocess.run([_exe(), *base, "-B", str(lst)], cwd=FIX_IN, capture_output=True, text=True)
+        if ok:
+            assert r.returncode == 0, r.stderr
+        else:
+            assert r.returncode == 1 and "sample3 is listed more than 255 times" in r.stderr
 
 
 def test_read_thinning_stream_is_glibc_rand():
