@@ -19,6 +19,14 @@ per rank (strong scaling; no data-path collective -- windows are independent,
 src/ibdgem.c:558-570; torch.distributed is used only for the barrier and the
 max-over-ranks reduction of the timing).
 
+Beside `value` (inputs resident in HBM, results left there) the line carries the other clocks of
+SURVEY.md s8(d), each labelled: "upload_sites" (what one more comparison costs before its first run:
+copying its row list and read counts and preparing windows / segments on the device), "engine_clock"
+(site arrays resident -> per-window results in host memory: preparation, alt-allele counts, all
+kernels, the copy back), "results_to_host" (per-site results), "warm_e2e" / "cold_e2e" (the host
+program ibdgem_amd/host/ibdgem from files to files), and "cpu_baseline" (the unmodified reference
+binary on a slice of the same data).
+
 One JSON line is printed by rank 0.
 """
 import argparse
@@ -152,7 +160,7 @@ def cpu_baseline(words_host, n_ref, n_alt, n_ids, target, window, gpu_win):
 
         for mode, extra in (("ld", ["--LD"]), ("nonld", [])):
             best = None
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.perf_counter()
                 subprocess.run(base + extra, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                preexec_fn=pin)
@@ -164,12 +172,16 @@ def cpu_baseline(words_host, n_ref, n_alt, n_ids, target, window, gpu_win):
                         if not l.startswith("#")]
         # the same sources at -O2 (labelled; the north-star ratio uses the build as shipped)
         exe_o2 = os.path.join(REPO, "oracle", "_ref", "ibdgem_O2")
-        o2 = None
+        o2 = o2_ld_stage = None
         if os.path.exists(exe_o2):
-            t0 = time.perf_counter()
-            subprocess.run([exe_o2] + base[1:] + ["--LD"], cwd=d, check=True, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, preexec_fn=pin)
-            o2 = n_cov / (time.perf_counter() - t0)
+            t_o2 = {}
+            for mode, extra in (("ld", ["--LD"]), ("nonld", [])):
+                t0 = time.perf_counter()
+                subprocess.run([exe_o2] + base[1:] + extra, cwd=d, check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, preexec_fn=pin)
+                t_o2[mode] = time.perf_counter() - t0
+            o2 = n_cov / t_o2["ld"]
+            o2_ld_stage = n_cov / max(t_o2["ld"] - t_o2["nonld"], 1e-9)
         parity = None
         if gpu_win is not None:
             ok = len(rows) <= len(gpu_win)
@@ -179,11 +191,240 @@ def cpu_baseline(words_host, n_ref, n_alt, n_ids, target, window, gpu_win):
     ld_stage = max(times["ld"] - times["nonld"], 1e-9)
     return dict(value=n_cov / times["ld"], unit="sites/s", cores=1, kind="reference",
                 sample=(f"first {L} rows ({n_cov} windowed) of the same workload as reference text inputs, "
-                        f"unmodified reference built -O0 as shipped, 1 process pinned to 1 core, best of 2, end-to-end --LD run "
-                        f"{times['ld']:.2f}s; non-LD {times['nonld']:.2f}s"),
+                        f"unmodified reference built -O0 as shipped, 1 process pinned to core {cpu0}, best of 3, "
+                        f"end-to-end --LD run {times['ld']:.2f}s; non-LD {times['nonld']:.2f}s"),
                 ld_stage_only_sites_per_s=n_cov / ld_stage,
                 O2_rebuild_sites_per_s=o2,
+                O2_rebuild_ld_stage_only_sites_per_s=o2_ld_stage,
                 summary_matches_gpu_7digits=parity)
+
+
+
+# ----------------------------------------------------------------------------- other clocks
+def best_of(n, fn):
+    best = None
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targets, n_cov):
+    """What one more comparison costs around its kernels, at the full size of this rank's rows.
+
+    upload_sites: ibdg_upload_sites with the caller's arrays in pageable memory (numpy), in page-locked
+    memory (ibdg_host_alloc) and already on the device (ibdg_upload_sites_dev); 6 bytes per row go to the
+    device (2 when row_index is NULL = the panel's own rows), everything else is derived there.
+    engine_clock: site arrays resident in HBM -> per-window results in host memory =
+    preparation + alt-allele counts (k_alt_count, inside the run) + per-site, --LD and window kernels +
+    the copy of the window table to page-locked host memory; also with the alt counts left to the panel
+    upload ("amortised": they depend on the panel only), and from pageable host arrays."""
+    n = len(n_ref)
+    idx = np.arange(n, dtype=np.uint32)
+    pins = [ibdgem_amd.PinnedArray(n, np.uint32), ibdgem_amd.PinnedArray(n, np.uint8), ibdgem_amd.PinnedArray(n, np.uint8)]
+    pins[0].array[:] = idx
+    pins[1].array[:] = n_ref
+    pins[2].array[:] = n_alt
+    d_idx = torch.from_numpy(idx.view(np.int32)).cuda()
+    d_nr, d_na = torch.from_numpy(n_ref).cuda(), torch.from_numpy(n_alt).cuda()
+    torch.cuda.synchronize()
+    ups = {
+        "pageable_ms": lambda: eng.upload_sites(idx, n_ref, n_alt, window),
+        "pageable_rows_implicit_ms": lambda: eng.upload_sites(None, n_ref, n_alt, window),
+        "pinned_ms": lambda: eng.upload_sites(pins[0].array, pins[1].array, pins[2].array, window),
+        "device_resident_ms": lambda: eng.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), n, window),
+    }
+    up = {}
+    for name, fn in ups.items():
+        fn()
+        up[name] = best_of(5, fn)
+        c = eng.upload_ms()
+        up[name.replace("_ms", "_parts")] = {"h2d_ms": c["h2d"], "device_prep_ms": c["device_prep"]}
+    up["bytes_to_device_per_row"] = 6
+    up["note"] = ("host wall clock of one ibdg_upload_sites[_dev] call, best of 5, all rows of the workload; parts are the "
+                  "engine's own event clocks of the last call")
+    n_win = eng.n_windows
+    win_pin = ibdgem_amd.PinnedArray((n_win, 3), np.float64)
+
+    def clock(recount, dev):
+        eng.set_option("count_in_run", 1 if recount else 0)
+
+        def once():
+            if dev:
+                eng.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), n, window)
+            else:
+                eng.upload_sites(idx, n_ref, n_alt, window)
+            eng.run(targets, ld=True)
+            eng.window_ll(0, out=win_pin.array)
+        once()
+        ms = best_of(5, once)
+        eng.set_option("count_in_run", 0)
+        return ms
+    full = clock(True, True)
+    ec = {
+        "definition": "site arrays (row index, n_ref, n_alt) resident in HBM -> per-window LIBD0/1/2 in host memory: "
+                      "ibdg_upload_sites_dev + ibdg_run with the alt-allele counts recomputed inside (K0) + "
+                      "ibdg_get_window_ll into page-locked memory; host wall clock, best of 5",
+        "ms": full, "sites_per_s": n_cov / (full * 1e-3),
+        "alt_counts_amortised_ms": None, "alt_counts_amortised_sites_per_s": None,
+        "from_pageable_host_arrays_ms": None,
+    }
+    am = clock(False, True)
+    ec["alt_counts_amortised_ms"] = am
+    ec["alt_counts_amortised_sites_per_s"] = n_cov / (am * 1e-3)
+    ec["from_pageable_host_arrays_ms"] = clock(True, False)
+    # per-site results (96 MB at 4M rows): pageable vs page-locked destination
+    eng.run(targets, ld=True)
+    site_pin = ibdgem_amd.PinnedArray((n, 3), np.float64)
+    page = np.empty((n, 3))
+    eng.site_ll(0, out=page)
+    t_page = best_of(3, lambda: eng.site_ll(0, out=page))
+    eng.site_ll(0, out=site_pin.array)
+    t_pin = best_of(3, lambda: eng.site_ll(0, out=site_pin.array))
+    d2h = {"per_site_results_ms": t_pin, "per_site_results_GBps": page.nbytes / (t_pin * 1e-3) / 1e9,
+           "per_site_results_pageable_ms": t_page, "per_site_results_pageable_GBps": page.nbytes / (t_page * 1e-3) / 1e9,
+           "note": "ibdg_get_site_ll of one comparison individual into page-locked (ibdg_host_alloc) / pageable memory"}
+    for a in pins + [win_pin, site_pin]:
+        a.close()
+    del d_idx, d_nr, d_na
+    return up, ec, d2h
+
+
+def valu_roofline(launch_ms, n_win, n_chunks):
+    """The second roofline of the dominant kernel: VALU issue.
+    Instructions per launch come from the committed PMC pass of this very workload (profiles/*_ld_pmc.json,
+    tools/pmc_ld.sh), cycles per instruction from the issue-rate micro-benchmark (profiles/*_issue_rates*.txt);
+    bound = issue cycles / (1024 SIMDs x shader clock).  None when no PMC file matches."""
+    pdir = os.path.join(REPO, "profiles")
+    best = None
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.endswith("_ld_pmc.json"):
+            with open(os.path.join(pdir, fn)) as fh:
+                best = (fn, json.load(fh))
+    if best is None:
+        return None
+    fn, p = best
+    c = p.get("config", {})
+    if (c.get("n_win"), c.get("n_chunks")) != (n_win, n_chunks):
+        return None
+    k = p["per_launch"]
+    cyc = p["cycles_per_wave_instruction"]
+    bcnt = k["valu_half_rate_estimate"]
+    full = k["SQ_INSTS_VALU"] - bcnt
+    cycles = bcnt * cyc["half_rate"] + full * cyc["full_rate"]
+    bound_ms = cycles / (p["simds"] * p["shader_clock_hz"]) * 1e3
+    return {"bound": "valu-issue", "profile": fn, "valu_instructions_per_launch": k["SQ_INSTS_VALU"],
+            "of_which_half_rate": bcnt, "cycles_per_instruction": cyc, "issue_cycles_per_launch": cycles,
+            "simds": p["simds"], "shader_clock_hz": p["shader_clock_hz"], "bound_ms": bound_ms,
+            "achieved_ms": launch_ms, "frac": bound_ms / launch_ms,
+            "note": "frac = time the VALU instructions alone need at their measured issue rates / measured kernel time"}
+
+
+def write_pileup_and_legend(d, n_ref, n_alt, n_ids, rows):
+    """Reference text inputs for `rows` rows (legend, indv, pileup; the .hap comes from the caller)."""
+    with open(os.path.join(d, "p.legend"), "w") as fh:
+        fh.write("ID pos allele0 allele1\n")
+        for a in range(0, rows, 500_000):
+            fh.write("".join([f"rs{i} {100 + 10 * i} A C\n" for i in range(a, min(rows, a + 500_000))]))
+    with open(os.path.join(d, "p.indv"), "w") as fh:
+        fh.write("".join(f"ind{n}\n" for n in range(n_ids)))
+    tails = {}
+    for r in range(21):
+        for a in range(21 - r):
+            c = r + a
+            tails[r * 32 + a] = ("N\t0\t*\t*\t*\n" if c == 0 else
+                                 f"N\t{c}\t{'A' * r}{'C' * a}\t{'I' * c}\t{'I' * c}\n")
+    key = (n_ref[:rows].astype(np.int32) * 32 + n_alt[:rows]).tolist()
+    with open(os.path.join(d, "p.pileup"), "w") as fh:
+        for a in range(0, rows, 500_000):
+            fh.write("".join([f"1\t{100 + 10 * i}\t{tails[key[i]]}" for i in range(a, min(rows, a + 500_000))]))
+
+
+def timed_run(cmd, cwd, repeat=2):
+    best = None
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows, gpu_win):
+    """warm_e2e: the host program from the packed-panel cache + legend + pileup text of ALL rows to its
+    output files (summary only, and with the per-site table).  cold_e2e: from .hap text, on the first
+    cold_rows rows (the whole chromosome would be 40 GB of text), with the fixed cost of a run (process
+    start, device initialisation) measured on 1000 rows so the linear extrapolation is explicit.
+    Reference: src/ibdgem.c:522-773 end to end (it re-reads and re-parses the text per individual)."""
+    import struct
+    exe = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
+    if not os.path.exists(exe):
+        return {"error": "ibdgem_amd/host/ibdgem not built"}, None
+    rows = words_all.shape[0]
+    threads = str(max(1, min(16, len(os.sched_getaffinity(0)))))
+    base_dir = "/dev/shm" if os.path.isdir("/dev/shm") else os.environ.get("TMPDIR", "/tmp")
+    warm = cold = None
+    with tempfile.TemporaryDirectory(dir=base_dir) as d:
+        # ---- warm: every row.  The 40 GB of .hap text behind the cache are not written: the cache header
+        # names the size and mtime of a placeholder p.hap, which is all the host program checks.
+        write_pileup_and_legend(d, n_ref, n_alt, n_ids, rows)
+        with open(os.path.join(d, "p.hap"), "w") as fh:
+            fh.write("placeholder: the packed-panel cache p.cache stands for the .hap text\n")
+        st = os.stat(os.path.join(d, "p.hap"))
+        with open(os.path.join(d, "p.cache"), "wb") as fh:
+            fh.write(struct.pack("<8sIIQQQqq", b"IBDGPNL1", n_ids, 0, rows, words_all.shape[1], st.st_size,
+                                 st.st_mtime_ns // 1_000_000_000, st.st_mtime_ns % 1_000_000_000))
+            fh.write(np.ones(rows, dtype=np.uint8).tobytes())
+            for a in range(0, rows, 500_000):
+                fh.write(np.ascontiguousarray(words_all[a:a + 500_000]).tobytes())
+        base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", f"ind{target}", "--LD",
+                "-w", str(window), "--threads", threads, "--panel-cache", "p.cache"]
+        os.makedirs(os.path.join(d, "o1"))
+        os.makedirs(os.path.join(d, "o2"))
+        t_sum = timed_run(base + ["-O", "o1", "--summary-only"], d)
+        t_tab = timed_run(base + ["-O", "o2"], d)
+        got = [l.split("\t")[3:6] for l in open(os.path.join(d, "o1", f"UNKWN.ind{target}.summary.txt")) if not l.startswith("#")]
+        same = gpu_win is not None and len(got) == len(gpu_win) and all(
+            ["%e" % v for v in gpu_win[w]] == got[w] for w in range(len(got)))
+        warm = {"rows": rows, "summary_only_s": t_sum, "with_per_site_table_s": t_tab,
+                "rows_per_s_summary_only": rows / t_sum, "rows_per_s_with_per_site_table": rows / t_tab,
+                "per_site_table_bytes": os.path.getsize(os.path.join(d, "o2", f"UNKWN.ind{target}.tab.txt")),
+                "summary_equals_engine_windows_7digits": bool(same), "host_threads": int(threads),
+                "note": "ibdgem_amd/host/ibdgem --LD, packed-panel cache (2.56 GB) + legend + pileup text -> output files, "
+                        "process start and device initialisation included, files in page cache, best of 2"}
+        for fn in ("p.cache",):
+            os.remove(os.path.join(d, fn))
+        # ---- cold: text .hap of the first cold_rows rows
+        r = min(cold_rows, rows)
+        alle = None
+        with open(os.path.join(d, "p.hap"), "wb") as fh:
+            for a in range(0, r, 50_000):
+                alle = unpack_rows(np.ascontiguousarray(words_all[a:min(r, a + 50_000)]), n_ids)
+                hap = np.full((alle.shape[0], 4 * n_ids), ord(" "), dtype=np.uint8)
+                hap[:, 0::2] = alle + ord("0")
+                hap[:, -1] = ord("\n")
+                fh.write(hap.tobytes())
+        del alle, hap
+        write_pileup_and_legend(d, n_ref, n_alt, n_ids, r)
+        cbase = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", f"ind{target}", "--LD",
+                 "-w", str(window), "--threads", threads]
+        os.makedirs(os.path.join(d, "o3"))
+        t_cold = timed_run(cbase + ["-O", "o3"], d)
+        # fixed cost: the same program on the first 1000 rows
+        os.makedirs(os.path.join(d, "tiny"))
+        with open(os.path.join(d, "p.hap"), "rb") as fi, open(os.path.join(d, "tiny", "p.hap"), "wb") as fo:
+            fo.write(fi.read(1000 * 4 * n_ids))
+        write_pileup_and_legend(os.path.join(d, "tiny"), n_ref, n_alt, n_ids, 1000)
+        t_fixed = timed_run(cbase + ["-O", "."], os.path.join(d, "tiny"))
+        cold = {"rows": r, "s": t_cold, "rows_per_s": r / t_cold, "fixed_cost_s": t_fixed,
+                "hap_text_bytes": r * 4 * n_ids,
+                "extrapolated_to_all_rows_s": t_fixed + (t_cold - t_fixed) * rows / r,
+                "note": f"ibdgem_amd/host/ibdgem --LD, .hap/.legend/.pileup text -> both output files on the first {r} rows "
+                        f"(the whole chromosome is {rows * 4 * n_ids / 1e9:.0f} GB of text); fixed_cost_s = the same run on "
+                        "1000 rows (process start + device initialisation); extrapolation linear in the rows beyond that"}
+    return warm, cold
 
 
 def traffic_bytes(args, world):
@@ -214,8 +455,10 @@ def main():
     ap.add_argument("--window", type=int, default=100)
     ap.add_argument("--target", type=int, default=7)
     ap.add_argument("--seed", type=int, default=20241008)
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-program clocks (warm_e2e, cold_e2e)")
+    ap.add_argument("--cold-rows", type=int, default=400_000, help="rows of .hap text for the cold end-to-end clock")
     ap.add_argument("--variant", type=int, default=None, help="ld_variant option of the engine")
     ap.add_argument("--cpw", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
@@ -283,10 +526,17 @@ def main():
     eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
     sample_rows = min(args.cpu_sample_rows, panel.shape[0])
     sample_words = panel[:sample_rows].cpu().numpy().view(np.uint64) if rank == 0 else None
+    words_all = None
+    if rank == 0 and world == 1 and not args.no_e2e:       # the whole packed panel on the host (2.56 GB) for warm_e2e
+        words_all = np.empty((panel.shape[0], panel.shape[1]), dtype=np.uint64)
+        for a in range(0, panel.shape[0], 500_000):
+            words_all[a:a + 500_000] = panel[a:a + 500_000].cpu().numpy().view(np.uint64)
     del panel
     torch.cuda.empty_cache()
     n_rows = row1 - row0
+    t_up = time.perf_counter()
     eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
+    first_upload_ms = (time.perf_counter() - t_up) * 1e3
     n_cov = int(((n_ref.astype(np.int32) + n_alt) > 0).sum())
     targets = [args.target]
 
@@ -338,17 +588,11 @@ def main():
         pass                                 # strict kernel: no such figure
     eng.set_option("async", 0)
     eng.set_option("dispatch_events", 0)
-    # the survey's "engine clock": one run plus its results copied to host memory (not `value`)
+    # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
+    up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov)
+    up["first_call_ms"] = first_upload_ms
     eng.run(targets, ld=True)
-    t2 = time.perf_counter()
-    eng.run(targets, ld=True)
-    w_host = eng.window_ll(0)
-    t3 = time.perf_counter()
-    s_host = eng.site_ll(0)
-    t4 = time.perf_counter()
-    d2h = {"run_plus_window_results_ms": (t3 - t2) * 1e3, "per_site_results_ms": (t4 - t3) * 1e3,
-           "per_site_results_GBps": s_host.nbytes / (t4 - t3) / 1e9}
-    del w_host, s_host
+    win_full = eng.window_ll(0) if rank == 0 else None
     ld_variant = eng.last_ld_variant()
 
     tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64,
@@ -361,6 +605,15 @@ def main():
         dt_max, cov_total, rows_total = float(mx[0]), float(sm[1]), float(sm[2])
     else:
         dt_max, cov_total, rows_total = dt, float(n_cov), float(n_rows)
+
+    mine = {"rank": rank, "rows": int(n_rows), "windowed_sites": int(n_cov), "windows": int(eng.n_windows),
+            "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
+            "upload_sites_ms": up["pageable_ms"], "engine_clock_ms": engine_clock["ms"],
+            "host_queue_ms_per_step": dt_host / args.steps * 1e3}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
@@ -388,11 +641,17 @@ def main():
                                            f"{len(ms_ld)} timed steps",
                          "dominant_kernel_only_ms": float(np.mean(ms_kernel)) if ms_kernel else None,
                          "dominant_kernel_only_note": "k_ld_popcount alone, start/stop events of its own dispatch "
-                                                      "packet, 32 extra steps after the timed region"},
+                                                      "packet, 32 extra steps after the timed region",
+                         "valu": valu_roofline(float(np.mean(ms_kernel)) if ms_kernel else ld_ms, int(eng.n_windows),
+                                               (args.ids + 63) // 64) if world == 1 else None},
             "kernel_ms": kern,
             "host_queue_ms_per_step": dt_host / args.steps * 1e3,
             "alt_count_ms": alt_ms,
-            "results_to_host": d2h if world == 1 else None,
+            "upload_sites_ms": up["pageable_ms"],
+            "upload_sites": up,
+            "engine_clock": engine_clock,
+            "results_to_host": d2h,
+            "per_rank": per_rank,
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
@@ -402,7 +661,25 @@ def main():
             eng.run(targets, ld=True)
             out["cpu_baseline"] = cpu_baseline(sample_words, n_ref[:s], n_alt[:s], args.ids, args.target,
                                                args.window, eng.window_ll(0))
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            cb = out["cpu_baseline"]
+            # like for like: the --LD launches against the reference's LD stage alone (its LD run minus its non-LD
+            # run on the same text); and the whole comparison (upload of its rows + kernels + window results to the
+            # host = engine_clock) against the reference's whole run.  The step-vs-whole-run figure compares
+            # different scopes and is kept under its own name.
+            if cb.get("ld_stage_only_sites_per_s"):
+                out["ld_kernels_vs_reference_ld_stage"] = (n_cov / (ld_ms * 1e-3)) / cb["ld_stage_only_sites_per_s"]
+            out["engine_clock_vs_reference_end_to_end"] = engine_clock["sites_per_s"] / cb["value"]
+            out["step_vs_reference_end_to_end"] = value / cb["value"]
+        if words_all is not None:
+            try:
+                warm, cold = end_to_end_clocks(words_all, n_ref, n_alt, args.ids, args.target, args.window, args.cold_rows,
+                                               win_full)
+            except Exception as e:                     # the bench line survives a failing host-program leg
+                warm, cold = {"error": repr(e)}, None
+            out["warm_e2e"] = warm
+            out["cold_e2e"] = cold
+            if isinstance(warm, dict) and "summary_only_s" in warm and "cpu_baseline" in out:
+                out["warm_e2e_vs_reference_end_to_end"] = (n_cov / warm["summary_only_s"]) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     eng.close()
     if world > 1:

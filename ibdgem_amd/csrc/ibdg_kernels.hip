@@ -21,23 +21,75 @@ namespace ibdg {
 // K0: alt-allele count of every panel row = popcount of the packed row.
 // Replaces find_f_impute / find_f_vcf (src/ibd-parse.c:91-110): the count over
 // ALL 2*n_ids alleles of the row; the division happens where f is used.
-// One wave per row per iteration, 16 B per lane.
+//
+// The panel is read as one flat stream of 16-byte units, 64 consecutive units (1 KiB) per wave
+// load, whatever the row length: with `pairs` units per row, R = 64/gcd(pairs,64) rows make a whole
+// number of loads (2504 individuals: 40 units per row, 8 rows = 5 loads), so no lane ever idles
+// (a wave per row left 24 of 64 lanes without work on 640-byte rows: 3.96 TB/s).  Every lane
+// drops the popcount of its unit into the wave's LDS strip; then gcd lanes per row add the row's
+// units up (strided reads, xor-shuffle among the gcd neighbours).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_alt_count(const uint64_t *__restrict__ panel,
-                                                   uint32_t stride, size_t n_rows,
-                                                   uint32_t *__restrict__ alt_count)
+__device__ __forceinline__ unsigned popc16(const uint4 v)
+{
+    return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+}
+
+// LOADS > 0: the number of 64-unit loads per group, known at compile time (all of them in flight at
+// once); LOADS == 0: any number (one at a time, hidden by the other waves of the CU).
+template <int LOADS>
+__global__ __launch_bounds__(64) void k_alt_count(const uint4 *__restrict__ panel16, uint32_t pairs, uint32_t g,
+                                                  uint32_t loads, size_t n_rows, size_t n_groups,
+                                                  uint32_t *__restrict__ alt_count)
+{
+    extern __shared__ uint32_t cnt[];                 // loads * 64 unit counts
+    const unsigned lane = threadIdx.x;
+    const uint32_t R = 64 / g;                        // rows per group
+    const size_t unit_end = n_rows * pairs;
+    const unsigned r = lane / g, part = lane % g;
+    for (size_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const size_t unit0 = grp * (size_t)loads * 64;
+        if (LOADS > 0 && unit0 + (size_t)LOADS * 64 <= unit_end) {     // a whole group: plain loads, nothing masked
+            uint4 v[LOADS > 0 ? LOADS : 1];
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i)
+                v[i] = panel16[unit0 + (size_t)i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i)
+                cnt[i * 64 + lane] = popc16(v[i]);
+        } else {
+            for (uint32_t i = 0; i < loads; ++i) {
+                const size_t u = unit0 + (size_t)i * 64 + lane;
+                const uint4 v = panel16[u < unit_end ? u : unit_end - 1];      // clamped, never masked
+                cnt[i * 64 + lane] = u < unit_end ? popc16(v) : 0u;
+            }
+        }
+        __syncthreads();                              // one wave per block: orders its LDS writes and reads
+        unsigned c = 0;
+        for (uint32_t k = part; k < pairs; k += g)
+            c += cnt[r * pairs + k];
+        for (uint32_t m = 1; m < g; m <<= 1)
+            c += __shfl_xor(c, m);
+        const size_t row = grp * R + r;
+        if (part == 0 && row < n_rows)
+            alt_count[row] = c;
+        __syncthreads();
+    }
+}
+
+// Rows too long for the LDS strip (pairs * 64 / gcd counts): a wave per row, 16 B per lane and turn.
+__global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restrict__ panel,
+                                                        uint32_t stride, size_t n_rows,
+                                                        uint32_t *__restrict__ alt_count)
 {
     const unsigned lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t pairs = stride >> 1;          // stride is even: 16-byte units per row
     for (size_t r = wave; r < n_rows; r += n_waves) {
-        const ulonglong2 *row = reinterpret_cast<const ulonglong2 *>(panel + r * stride);
+        const uint4 *row = reinterpret_cast<const uint4 *>(panel + r * stride);
         unsigned c = 0;
-        for (uint32_t i = lane; i < pairs; i += 64) {
-            ulonglong2 v = row[i];
-            c += __popcll(v.x) + __popcll(v.y);
-        }
+        for (uint32_t i = lane; i < pairs; i += 64)
+            c += popc16(row[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             c += __shfl_xor(c, off);
@@ -331,10 +383,35 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
 {
     if (n_rows == 0)
         return;
+    const uint32_t pairs = stride >> 1;
+    uint32_t g = 64;                                  // gcd(pairs, 64): the lowest set bit of pairs, at most 64
+    while (g > 1 && pairs % g)
+        g >>= 1;
+    const uint32_t loads = pairs / g;
+    const size_t lds = (size_t)loads * 64 * 4;
+    if (lds <= 16 * 1024) {
+        const size_t R = 64 / g, n_groups = (n_rows + R - 1) / R;
+        const size_t blocks = n_groups < 256 * 32 * 4 ? n_groups : 256 * 32 * 4;      // a few rounds of 32 waves per CU
+        auto kern = k_alt_count<0>;
+        switch (loads) {
+        case 1: kern = k_alt_count<1>; break;
+        case 2: kern = k_alt_count<2>; break;
+        case 3: kern = k_alt_count<3>; break;
+        case 4: kern = k_alt_count<4>; break;
+        case 5: kern = k_alt_count<5>; break;
+        case 6: kern = k_alt_count<6>; break;
+        case 7: kern = k_alt_count<7>; break;
+        case 8: kern = k_alt_count<8>; break;
+        default: break;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), (uint32_t)lds, st,
+                           reinterpret_cast<const uint4 *>(panel), pairs, g, loads, n_rows, n_groups, alt_count);
+        return;
+    }
     size_t blocks = (n_rows + 3) / 4;
     if (blocks > 256 * 32)
         blocks = 256 * 32;
-    hipLaunchKernelGGL(k_alt_count, dim3((unsigned)blocks), dim3(256), 0, st, panel, stride, n_rows,
+    hipLaunchKernelGGL(k_alt_count_long, dim3((unsigned)blocks), dim3(256), 0, st, panel, stride, n_rows,
                        alt_count);
 }
 

@@ -790,6 +790,14 @@ static void window_cuts(const uint8_t *nr, const uint8_t *na, size_t n, unsigned
     cuts[parts] = n;
 }
 
+/* page-locked memory from the engine when asked for and available, plain memory otherwise (never freed:
+ * these arrays live as long as the program) */
+static void *io_alloc(size_t bytes, int pinned)
+{
+    void *p = pinned ? ibdg_host_alloc(bytes) : NULL;
+    return p ? p : malloc(bytes);
+}
+
 #define TARGET_BATCH 16      /* comparison individuals per engine call when their site lists coincide */
 #define DIE(...)                          \
     do {                                  \
@@ -1013,10 +1021,15 @@ int main(int argc, char **argv)
     }
 
     /* ---- per comparison individual (:522-773) ------------------------------------------ */
-    uint32_t *s_row = malloc((n_cand ? n_cand : 1) * 4), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
-    uint8_t *s_nr = malloc(n_cand ? n_cand : 1), *s_na = malloc(n_cand ? n_cand : 1);
+    /* the arrays that cross the engine's boundary live in page-locked memory when a device is in use
+     * (ibdg_host_alloc: copies at link speed, 45+ GB/s instead of ~17 through a staging buffer) */
+    const int pin = !opt_plan;
+    uint32_t *s_row = io_alloc((n_cand ? n_cand : 1) * 4, pin), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
+    uint8_t *s_nr = io_alloc(n_cand ? n_cand : 1, pin), *s_na = io_alloc(n_cand ? n_cand : 1, pin);
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
-    double *site_af = malloc((n_cand ? n_cand : 1) * 8), *site_ll = malloc((n_cand ? n_cand : 1) * 24);
+    double *site_af = io_alloc((n_cand ? n_cand : 1) * 8, pin), *site_ll = io_alloc((n_cand ? n_cand : 1) * 24, pin);
+    if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
+        DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
      * reads anew for each (src/ibdgem.c:584, :627-628) */
     const int batchable = !opt_plan && !has_v && cull_p == 1.0;

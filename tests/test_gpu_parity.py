@@ -676,3 +676,21 @@ def test_rows_in_any_order_and_the_first_offending_site(oracle):
             eng.run([1], ld=True)                     # a failed upload leaves no sites behind
         with pytest.raises(E.EngineError, match="outside the panel"):
             eng.upload_sites(None, np.ones(Lp + 1, np.uint8), np.ones(Lp + 1, np.uint8), 100)
+
+
+@pytest.mark.parametrize("N,L", [(3, 131), (64, 70), (65, 300), (700, 257), (2504, 1003), (4000, 67), (5000, 130)])
+def test_alt_counts_for_every_row_layout(N, L):
+    """k_alt_count reads the panel as a flat stream of 16-byte units (rows per group = 64/gcd(units per
+    row, 64); 4000 individuals: 65 units per row, the wave-per-row kernel) -- counts equal numpy's for
+    every row, also when the rows do not fill the last group, both at upload and inside a run."""
+    rng = np.random.default_rng(N)
+    alle = (rng.random((L, 2 * N)) < rng.random((L, 1))).astype(np.uint8)
+    want = alle.sum(axis=1, dtype=np.uint32)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        assert (eng.alt_counts(0, L) == want).all()
+        eng.set_option("count_in_run", 1)
+        eng.upload_sites(None, np.ones(L, np.uint8), np.zeros(L, np.uint8), 10)
+        eng.run([0], ld=False)
+        assert (eng.alt_counts(0, L) == want).all()
+        assert_bits(eng.site_af(), want / float(2 * N), "AF")
