@@ -294,9 +294,12 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
 
 def valu_roofline(launch_ms, n_win, n_chunks):
     """The second roofline of the dominant kernel: VALU issue.
-    Instructions per launch come from the committed PMC pass of this very workload (profiles/*_ld_pmc.json,
-    tools/pmc_ld.sh), cycles per instruction from the issue-rate micro-benchmark (profiles/*_issue_rates*.txt);
-    bound = issue cycles / (1024 SIMDs x shader clock).  None when no PMC file matches."""
+    Instructions per launch come from the committed PMC passes of this very workload (profiles/*_ld_pmc.json,
+    tools/pmc_ld.sh), cycles per instruction from the micro-benchmark of the kernel's own instruction mix
+    (profiles/*_dep_distance.txt); issue cycles per SIMD = instructions x cycles / 1024 SIMDs.  Reported
+    against the kernel's own cycle count (GRBM_GUI_ACTIVE / 8 XCDs, same passes) and, as a time, at the
+    nominal 2.4 GHz -- under this dense integer load the chip sustains about 2.0 GHz (kernel cycles /
+    kernel time).  None when no PMC file matches the workload."""
     pdir = os.path.join(REPO, "profiles")
     best = None
     for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -309,17 +312,19 @@ def valu_roofline(launch_ms, n_win, n_chunks):
     c = p.get("config", {})
     if (c.get("n_win"), c.get("n_chunks")) != (n_win, n_chunks):
         return None
-    k = p["per_launch"]
-    cyc = p["cycles_per_wave_instruction"]
-    bcnt = k["valu_half_rate_estimate"]
-    full = k["SQ_INSTS_VALU"] - bcnt
-    cycles = bcnt * cyc["half_rate"] + full * cyc["full_rate"]
-    bound_ms = cycles / (p["simds"] * p["shader_clock_hz"]) * 1e3
+    k, d = p["per_launch"], p["derived"]
+    cyc = p["cycles_per_valu_instruction"]["value"]
+    issue = k["SQ_INSTS_VALU"] * cyc / p["simds"]
+    bound_ms = issue / p["nominal_clock_hz"] * 1e3
     return {"bound": "valu-issue", "profile": fn, "valu_instructions_per_launch": k["SQ_INSTS_VALU"],
-            "of_which_half_rate": bcnt, "cycles_per_instruction": cyc, "issue_cycles_per_launch": cycles,
-            "simds": p["simds"], "shader_clock_hz": p["shader_clock_hz"], "bound_ms": bound_ms,
-            "achieved_ms": launch_ms, "frac": bound_ms / launch_ms,
-            "note": "frac = time the VALU instructions alone need at their measured issue rates / measured kernel time"}
+            "valu_instructions_per_window_and_chunk": d["valu_per_window_chunk"],
+            "cycles_per_instruction": cyc, "simds": p["simds"], "issue_cycles_per_simd": issue,
+            "kernel_cycles_profiled": d["kernel_cycles"], "frac_of_kernel_cycles": issue / d["kernel_cycles"],
+            "bound_ms_at_2.4GHz": bound_ms, "achieved_ms": launch_ms, "frac_at_2.4GHz": bound_ms / launch_ms,
+            "sustained_clock_GHz": d["kernel_cycles"] / (launch_ms * 1e-3) / 1e9,
+            "note": "frac_of_kernel_cycles: share of the kernel's cycles in which the SIMDs must be issuing its VALU "
+                    "instructions (~1 = at the VALU-issue roofline); frac_at_2.4GHz: the same bound as a time at the "
+                    "nominal clock over the measured kernel time (the rest is the clock the chip sustains)"}
 
 
 def write_pileup_and_legend(d, n_ref, n_alt, n_ids, rows):

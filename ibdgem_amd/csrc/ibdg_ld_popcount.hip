@@ -49,7 +49,11 @@
 // of one with VGPR operands only (tools/ubench/issue_rates.hip: v_and_b32 4.1 vs 2.4 cycles),
 // and a wave-uniform mask is just as good in a VGPR.
 #define IBDG_REC_WORDS 8
-// LDS image of a window's constants (8 words): eK AT <t0,cov> <t1,cov> | AT-<t0,alt> AT-<t1,alt> - -
+// LDS image of a window's constants (8 words), all but eK already table BYTE OFFSETS (16 bytes per
+// entry), so that the window end forms its ten table addresses without a shift of their own:
+//   eK  16*AT  16*<t0,cov>  16*<t1,cov> | 16*(AT-<t0,alt>)  16*(AT-<t1,alt>)  0  -
+// (k_win_target); while a workgroup stages them it adds the LDS address of the table each one indexes
+// (rho^n: words 1, 4, 5; sigma^n: words 2, 3, 6), see stage_wc_base.
 #define IBDG_WC_WORDS 8
 
 namespace ibdg {
@@ -97,10 +101,10 @@ __device__ __forceinline__ uint2 tile_words(const uint4 *__restrict__ base, uint
 }
 
 // ---------------------------------------------------------------------------
-// Per target, one thread per segment and per window: the LDS-ready images the --LD kernel stages with plain
-// contiguous copies -- every segment's 20-word record (layout above k_ld_popcount) with the
-// target's haplotype words of its tile filled in, and the window's 12 constants including
-// <t0,cov>, <t1,cov>, <t0,alt>, <t1,alt> summed over the window's rows.
+// Per target, one thread per segment and eight per window: the LDS-ready images the --LD kernel stages
+// with plain contiguous copies -- every segment's 8-word record (IBDG_REC_WORDS, layout above) with the
+// target's haplotype words of its tile filled in, and the window's 8 constants (IBDG_WC_WORDS) built
+// from <t0,cov>, <t1,cov>, <t0,alt>, <t1,alt> summed over the window's rows.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restrict__ rec_ready,
                                                     uint32_t *__restrict__ wc_ready)
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
             const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);    // mK(2) eK ct at seg_begin
             uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WC_WORDS);
             const uint32_t AT = wcs[4];
-            o[0] = make_uint4(wcs[2], AT, a0cov, a1cov);
-            o[1] = make_uint4(AT - a0alt, AT - a1alt, 0, 0);
+            o[0] = make_uint4(wcs[2], 16 * AT, 16 * a0cov, 16 * a1cov);
+            o[1] = make_uint4(16 * (AT - a0alt), 16 * (AT - a1alt), 0, 0);
         }
     }
 }
@@ -173,10 +177,21 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
 
 // Two wave-wide sums at once through a 1 KiB LDS scratch of the wave: every lane writes its two
 // addends into two arrays of 64 doubles; lane 32j+p then reads elements 2p, 2p+1 of sum j (one
-// 16-byte read at scratch + 16*lane), adds them, and the 32 lanes of half j finish with five DPP
-// steps.  Lane 31 ends up with the total of the first sum, lane 63 with the second.  Fixed order,
-// no barrier (the scratch is the wave's own and a wave's LDS operations execute in order);
-// 19 instructions for the two sums of a window instead of 36 for two full-wave DPP reductions.
+// 16-byte read at scratch + 16*lane), adds them, and the 32 lanes of half j finish with five
+// exchange-and-add steps.  Every lane of the first half ends up with the total of the first sum,
+// every lane of the second half with the second.  Fixed order, no barrier (the scratch is the wave's
+// own and a wave's LDS operations execute in order); 6 VALU instructions for the two sums of a window.
+// v + (v of lane ^ X within the 32-lane half) through the LDS crossbar (ds_swizzle, bit mode): no VALU
+// move, no LDS memory -- the exchange is issued on the LDS port beside other waves' arithmetic.
+template <int X>
+__device__ __forceinline__ double swz_add(double v)
+{
+    constexpr int pat = (X << 10) | 0x1f;        // and 0x1f, or 0, xor X
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+    return v + __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, uint32_t scr_r)
 {
     uint4 r;
@@ -188,22 +203,71 @@ __device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, 
                  : "v"(scr_w), "v"(a), "v"(b), "v"(scr_r)
                  : "memory");
     double v = __hiloint2double((int)r.y, (int)r.x) + __hiloint2double((int)r.w, (int)r.z);
-    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a 16-lane row holds the row total
-    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3: lanes 16-31 / 48-63 hold the half totals
+    // a butterfly over the 32 lanes of each half: after every step the lanes of a group hold the same
+    // subtotal, so the tree is the one of the DPP sequence this replaced (quad_perm, quad_perm,
+    // row_half_mirror, row_mirror, row_bcast:15) and the totals are the same bits
+    v = swz_add<1>(v);
+    v = swz_add<2>(v);
+    v = swz_add<4>(v);
+    v = swz_add<8>(v);
+    v = swz_add<16>(v);
     return v;
 }
 
+// (a << SH) + b and a * M + c as the single instructions they are (v_lshl_add_u32, v_mad_i32_i24): the
+// window end is a chain of these, and hipcc otherwise splits them into shifts and three-operand adds
+// (56 integer instructions per window where 38 do).  a < 2^23 for the multiply (exponents are sums of
+// at most a few thousand reads; the host does not offer this kernel beyond that).
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
+    return d;
+}
+
+template <int M>
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t c)
+{
+    static_assert(M >= -16 && M <= 64, "inline constants only; other multipliers go through mad24r");
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(M), "v"(c));
+    return d;
+}
+
+// the same with the multiplier in a register (-32 is not an inline constant)
+__device__ __forceinline__ uint32_t mad24r(uint32_t a, uint32_t m, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(c));
+    return d;
+}
+
+// sum_k v[k] << k by Horner's rule: KP-1 instructions
 template <int KP>
 __device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
 {
-    uint32_t s = v[0];
+    uint32_t s = v[KP - 1];
 #pragma unroll
-    for (int k = 1; k < KP; ++k)
-        s += v[k] << k;
+    for (int k = KP - 2; k >= 0; --k)
+        s = lshl_add<1>(s, v[k]);
     return s;
+}
+
+// Staging of the window constants: the table base each word indexes is added on the way into LDS
+// (i = index of the uint4 within the run's constants, two per window).
+__device__ __forceinline__ uint4 stage_wc_base(uint4 v, uint32_t i, uint32_t tab1, uint32_t tab2)
+{
+    if (i & 1) {
+        v.x += tab1;
+        v.y += tab1;
+        v.z = tab2;
+    } else {
+        v.y += tab1;
+        v.z += tab2;
+        v.w += tab2;
+    }
+    return v;
 }
 
 // ---------------------------------------------------------------------------
@@ -428,10 +492,14 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
         for (uint32_t i = threadIdx.x; i < nseg * (IBDG_REC_WORDS / 4); i += blockDim.x)
             rdst[i] = rsrc[i];
+        // with the tables in LDS the constants become LDS addresses (table base + 16 * exponent), otherwise
+        // they stay byte offsets into the global tables
+        const uint32_t stab1 = TAB_LDS ? (uint32_t)(uintptr_t)(lds_void *)tab_lds : 0u;
+        const uint32_t stab2 = TAB_LDS ? stab1 + a.tab_len * 16 : 0u;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
         for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
-            wdst[i] = wsrc[i];
+            wdst[i] = stage_wc_base(wsrc[i], i, stab1, stab2);
         if (TAB_LDS)
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
                 tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
@@ -440,8 +508,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 
     if (!has_chunk)
         return;
-    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
-    const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
     // the wave's 1 KiB scratch for wave_sum2, behind the rings
     const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
@@ -464,6 +530,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     // NEXT segment are precomputed by the host into each record's flag word (ring slot relative to
     // the run's first pair), so the loop carries no tile/pair arithmetic:
     //   flags = next slot (3) | next half (1) | pairs to advance (8) | rare planes (1) | last (1) | .. | ncov (8) | nalt (8)
+    uint32_t m32 = (uint32_t)-32;                    // multiplier of the 2 G(x,t) term in a table address, kept in a VGPR
+    asm volatile("" : "+v"(m32));
     uint32_t x_off = (tile0 & 1) * 8;                // ring byte offset of the current segment's words (slot 0)
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
@@ -478,32 +546,30 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
             lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
             const int eK = (int)k0.x;
-            const uint32_t AT = k0.y;
-            const uint32_t a0cov = k0.z, a1cov = k0.w, b0 = k1.x, b1 = k1.y;   // b = AT - <t,alt>
+            // table addresses of 16*AT, 16*<t0,cov>, 16*<t1,cov>, 16*(AT-<t0,alt>), 16*(AT-<t1,alt>), 0
+            const uint32_t kAT = k0.y, kc0 = k0.z, kc1 = k0.w, kb0 = k1.x, kb1 = k1.y, ktab2 = k1.z;
             const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
             const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
             const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
             const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
-            uint32_t E2[5], E3[5];
-            E3[0] = C0 + C1 - 2 * CH;      E2[0] = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
-            E3[1] = a0cov + C0 - 2 * G00;  E2[1] = b0 - a0 + G00;                // pDg[A0+h0] (:716)
-            E3[2] = a0cov + C1 - 2 * G01;  E2[2] = b0 - a1 + G01;                // pDg[A0+h1] (:717)
-            E3[3] = a1cov + C0 - 2 * G10;  E2[3] = b1 - a0 + G10;                // pDg[A1+h0] (:718)
-            E3[4] = a1cov + C1 - 2 * G11;  E2[4] = b1 - a1 + G11;                // pDg[A1+h1] (:719)
+            // ad[2i] / ad[2i+1]: where rho^E2 / sigma^E3 of product i sit (table base + 16 * exponent), with
+            //   pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH          E2 = AT - a0 - a1 + CH
+            //   pDg[At+hx] (:716-719):     E3 = <t,cov> + Cx - 2 G(x,t)  E2 = AT - <t,alt> - ax + G(x,t)
+            uint32_t ad[10];
+            ad[0] = lshl_add<4>(CH - (a0 + a1), kAT);
+            ad[1] = lshl_add<4>(mad24<-2>(CH, C0 + C1), ktab2);
+            ad[2] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[3] = mad24r(G00, m32, lshl_add<4>(C0, kc0));   // A0, h0
+            ad[4] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[5] = mad24r(G01, m32, lshl_add<4>(C1, kc0));   // A0, h1
+            ad[6] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[7] = mad24r(G10, m32, lshl_add<4>(C0, kc1));   // A1, h0
+            ad[8] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[9] = mad24r(G11, m32, lshl_add<4>(C1, kc1));   // A1, h1
             uint4 pw[10];
             if (TAB_LDS) {
-                uint32_t ad[10];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    ad[2 * i] = tab1 + E2[i] * 16;
-                    ad[2 * i + 1] = tab2 + E3[i] * 16;
-                }
                 lds_read_pow10(pw, ad);
             } else {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    pw[2 * i] = pow_1me[E2[i]];
-                    pw[2 * i + 1] = pow_eps[E3[i]];
+                    pw[2 * i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_1me) + ad[2 * i]);
+                    pw[2 * i + 1] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_eps) + ad[2 * i + 1]);
                 }
             }
             const double P2 = ld_value(eK, pw[0], pw[1]);
@@ -513,7 +579,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             const double Q11 = ld_value(eK, pw[8], pw[9]);
             double s0 = wgt * P2;                                   // :743
             double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
-            const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // lane 31: sum of s0, lane 63: of s1
+            const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // first half: sum of s0, second half: of s1
             if ((lane & 31) == 31)
                 a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
         }
@@ -539,7 +605,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 //
 // LDS images (written by k_win_target_mt):
 //   segment, 8 + 2 TB words:        flags cov0 cov1 cov2 | alt0 alt1 - - | TB x {t0 t1}   (IBDG_RECM_WORDS)
-//   window, 8 + 4 TB words:         mK(2) eK CT | AT - - - | TB x {a0cov a1cov a0alt a1alt}
+//   window, 8 + 4 TB words:         mK(2) eK CT | 16*AT 0 - - | TB x {16*<t0,cov> 16*<t1,cov> 16*(AT-<t0,alt>) 16*(AT-<t1,alt>)}
+//   (table byte offsets like IBDG_WC_WORDS; the staging adds the table bases, stage_wcm_base)
 // ---------------------------------------------------------------------------
 #ifndef IBDG_MT
 #define IBDG_MT 4
@@ -602,13 +669,29 @@ __global__ __launch_bounds__(256) void k_win_target_mt(PopArgs a, uint32_t *__re
         if ((i & 7) == 0) {
             const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);
             uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)g * a.n_win + w) * IBDG_WCM_WORDS);
+            const uint32_t AT = wcs[4];
             o[0] = make_uint4(wcs[0], wcs[1], wcs[2], wcs[3]);
-            o[1] = make_uint4(wcs[4], 0, 0, 0);
+            o[1] = make_uint4(16 * AT, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TB; ++j)
-                o[2 + j] = make_uint4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+                o[2 + j] = make_uint4(16 * acc[j][0], 16 * acc[j][1], 16 * (AT - acc[j][2]), 16 * (AT - acc[j][3]));
         }
     }
+}
+
+// Staging of the multi-individual window constants (j = index of the uint4 within its window's record)
+__device__ __forceinline__ uint4 stage_wcm_base(uint4 v, uint32_t j, uint32_t tab1, uint32_t tab2)
+{
+    if (j == 1) {
+        v.x += tab1;
+        v.y = tab2;
+    } else if (j >= 2) {
+        v.x += tab2;
+        v.y += tab2;
+        v.z += tab1;
+        v.w += tab1;
+    }
+    return v;
 }
 
 __device__ __forceinline__ void lds_fetch_mt(uint4 &h0, uint4 &h1, uint4 &h2, uint4 &h3, uint2 &x, uint32_t rec_addr,
@@ -763,10 +846,12 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
         for (uint32_t i = threadIdx.x; i < nseg * (IBDG_RECM_WORDS / 4); i += blockDim.x)
             rdst[i] = rsrc[i];
+        const uint32_t stab1 = TAB_LDS ? (uint32_t)(uintptr_t)(lds_void *)tab_lds : 0u;
+        const uint32_t stab2 = TAB_LDS ? stab1 + a.tab_len * 16 : 0u;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)g * a.n_win + w0) * (IBDG_WCM_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
         for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WCM_WORDS / 4); i += blockDim.x)
-            wdst[i] = wsrc[i];
+            wdst[i] = stage_wcm_base(wsrc[i], i % (IBDG_WCM_WORDS / 4), stab1, stab2);
         if (TAB_LDS)
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
                 tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
@@ -774,8 +859,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     __syncthreads();
     if (!has_chunk)
         return;
-    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
-    const uint32_t tab2 = tab1 + a.tab_len * 16;
     const uint32_t ring_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16;
     // the wave's 1 KiB scratch for wave_sum2, behind the rings
     const uint32_t scr = (uint32_t)(uintptr_t)(lds_void *)(ring0 + (size_t)a.waves_per_group * NS * 1024 + wave * 1024);
@@ -793,6 +876,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    uint32_t m32 = (uint32_t)-32;
+    asm volatile("" : "+v"(m32));
     uint32_t x_off = (tile0 & 1) * 8;
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
@@ -817,46 +902,42 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
                      : "v"(wc_addr)
                      : "memory");
         const int eK = (int)k0.z;
-        const uint32_t AT = k1.x;
+        const uint32_t kAT = k1.x, ktab2 = k1.y;
         const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
         const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
         double P2;
         {
-            const uint32_t E3 = C0 + C1 - 2 * CH, E2 = AT - a0 - a1 + CH;            // pDg[x0+x1] (ibdgem.c:715)
+            // pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH, E2 = AT - a0 - a1 + CH
+            const uint32_t ad2 = lshl_add<4>(CH - (a0 + a1), kAT), ad3 = lshl_add<4>(mad24<-2>(CH, C0 + C1), ktab2);
             uint4 p1, p2;
             if (TAB_LDS) {
-                lds_read2(p1, p2, tab1 + E2 * 16, tab2 + E3 * 16);
+                lds_read2(p1, p2, ad2, ad3);
             } else {
-                p1 = pow_1me[E2];
-                p2 = pow_eps[E3];
+                p1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_1me) + ad2);
+                p2 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_eps) + ad3);
             }
             P2 = ld_value(eK, p1, p2);
         }
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
             const uint4 kt = kt4[j];
-            const uint32_t a0cov = kt.x, a1cov = kt.y, a0alt = kt.z, a1alt = kt.w;
+            const uint32_t kc0 = kt.x, kc1 = kt.y, kb0 = kt.z, kb1 = kt.w;
             const uint32_t G00 = planes_sum<FC>(gq[j][0]), G01 = planes_sum<FC>(gq[j][1]);
             const uint32_t G10 = planes_sum<FC>(gq[j][2]), G11 = planes_sum<FC>(gq[j][3]);
-            uint32_t E2[4], E3[4];
-            E3[0] = a0cov + C0 - 2 * G00;  E2[0] = AT - a0alt - a0 + G00;        // pDg[A0+h0] (:716)
-            E3[1] = a0cov + C1 - 2 * G01;  E2[1] = AT - a0alt - a1 + G01;        // pDg[A0+h1] (:717)
-            E3[2] = a1cov + C0 - 2 * G10;  E2[2] = AT - a1alt - a0 + G10;        // pDg[A1+h0] (:718)
-            E3[3] = a1cov + C1 - 2 * G11;  E2[3] = AT - a1alt - a1 + G11;        // pDg[A1+h1] (:719)
+            // pDg[At+hx] (:716-719): E3 = <t,cov> + Cx - 2 G(x,t), E2 = AT - <t,alt> - ax + G(x,t)
+            uint32_t ad[8];
+            ad[0] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[1] = mad24r(G00, m32, lshl_add<4>(C0, kc0));
+            ad[2] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[3] = mad24r(G01, m32, lshl_add<4>(C1, kc0));
+            ad[4] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[5] = mad24r(G10, m32, lshl_add<4>(C0, kc1));
+            ad[6] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[7] = mad24r(G11, m32, lshl_add<4>(C1, kc1));
             uint4 pw[8];
             if (TAB_LDS) {
-                uint32_t ad[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ad[2 * i] = tab1 + E2[i] * 16;
-                    ad[2 * i + 1] = tab2 + E3[i] * 16;
-                }
                 lds_read_pow8(pw, ad);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    pw[2 * i] = pow_1me[E2[i]];
-                    pw[2 * i + 1] = pow_eps[E3[i]];
+                    pw[2 * i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_1me) + ad[2 * i]);
+                    pw[2 * i + 1] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_eps) + ad[2 * i + 1]);
                 }
             }
             const double Q00 = ld_value(eK, pw[0], pw[1]);
