@@ -568,15 +568,21 @@ def main():
     ms_all = [eng.run_ms(b) for b in range(min(args.steps, 32))]
     ms_ld = [m["ld"] for m in ms_all]
 
-    # cost of recounting the alt alleles inside the step (reported, not part of `value`)
+    # the step with the alt alleles recounted inside it (K0 in the timed region; reported beside `value`): queued
+    # back to back like the timed steps
     eng.set_option("count_in_run", 1)
-    eng.run(targets, ld=True)
-    t1 = time.perf_counter()
-    for _ in range(3):
+    eng.set_option("async", 1)
+    for _ in range(10):
         eng.run(targets, ld=True)
     eng.sync()
-    dt_recount = (time.perf_counter() - t1) / 3
-    alt_ms = eng.last_run_ms()["alt_count"]
+    n_rc = max(20, min(args.steps, 100))
+    t1 = time.perf_counter()
+    for _ in range(n_rc):
+        eng.run(targets, ld=True)
+    eng.sync()
+    dt_recount = (time.perf_counter() - t1) / n_rc
+    eng.set_option("async", 0)
+    alt_ms = float(np.mean([eng.run_ms(b)["alt_count"] for b in range(min(n_rc, 32))]))
     eng.set_option("count_in_run", 0)
     # the dominant kernel alone: 32 more queued steps timed through the kernel's own dispatch packet
     # (hipExtLaunchKernel start/stop events; slower per step than one event record, hence not in the

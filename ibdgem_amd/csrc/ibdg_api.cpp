@@ -615,8 +615,16 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess)
-        return bail("hipStreamCreate", e);
+    {
+        // stream2 carries the short memory-bound kernels (alt counts, per-site values, window products) beside the
+        // --LD kernel, whose workgroups fill every wave slot of the chip: at the highest priority its workgroups
+        // take the slots that free up first instead of queueing behind ~17 000 --LD workgroups
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
+            lo = hi = 0;
+        if ((e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+    }
     for (auto &E : c->evs) {
         for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);

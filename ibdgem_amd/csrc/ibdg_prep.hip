@@ -225,44 +225,95 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint3
         block_cnt[blockIdx.x] = tot;
 }
 
-// The thread of a segment's first row walks the segment (at most 32 rows) and writes its masks.
+// Segment masks, row-parallel: every covered row is a lane; the lanes of a segment (consecutive rows, at
+// most 32) OR their bits together with a segmented scan over the wave (six shuffle steps per weight
+// plane, only planes some lane of the wave has), and the last lane of each piece adds it to the
+// segment's words in memory with atomicOr -- a segment cut by a wave boundary is simply two pieces.
+// segs[] is zeroed beforehand.  The first row of a segment writes tile and window, its last row the
+// end-of-window mark.
 __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const uint32_t *__restrict__ block_off,
                                                                  Seg *__restrict__ segs, uint32_t seg_cap,
                                                                  WinConst *__restrict__ wconst)
 {
+    constexpr int NW = PREP_THREADS / 64;
+    __shared__ uint32_t pre[PREP_ITEMS * NW];
     const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
-    block_scatter(
-        base, in.n_cov, block_off[blockIdx.x], [&](size_t j) { return seg_start(in, j); },
-        [&](size_t j, uint32_t i) {
-            const uint32_t w = (uint32_t)(j / in.window);
-            const uint64_t wend64 = (uint64_t)(w + 1) * in.window;
-            const uint32_t wend = wend64 < in.n_cov ? (uint32_t)wend64 : in.n_cov;
-            const uint32_t tile = in.rec_cov[j].x >> 5;
-            uint32_t cov[8] = {0, 0, 0, 0, 0, 0, 0, 0}, alt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            uint32_t jj = (uint32_t)j;
-            for (; jj < wend; ++jj) {
-                const uint2 rc = in.rec_cov[jj];
-                if ((rc.x >> 5) != tile)
-                    break;
-                const uint32_t idx = rc.y / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
-                const uint32_t bit = 1u << (rc.x & 31);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if ((cv >> k) & 1) cov[k] |= bit;
-                    if ((a >> k) & 1) alt[k] |= bit;
-                }
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 1: segment starts per (item, wave) -> exclusive prefix (the same ranks k_prep_seg_count counted)
+#pragma unroll 4
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const uint64_t b = __ballot(j < in.n_cov && seg_start(in, j));
+        if (lane == 0)
+            pre[i * NW + wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t tot;
+        const uint32_t v = pre[lane];
+        pre[lane] = wave_excl_scan(v, &tot);
+    }
+    __syncthreads();
+    const uint32_t boff = block_off[blockIdx.x];
+#pragma unroll 1
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const bool live = j < in.n_cov;
+        if (!__any(live))
+            break;
+        const uint64_t starts = __ballot(live && seg_start(in, j));
+        // segment of this row: starts up to and including this lane, minus one (0xffffffff before the first
+        // segment of everything cannot happen: row 0 starts a window)
+        const uint32_t incl = (uint32_t)__popcll(starts & ((2ull << lane) - 1));
+        const uint32_t seg = boff + pre[i * NW + wave] + incl - 1;
+        uint32_t row = 0, cv = 0, al = 0;
+        if (live) {
+            const uint2 rc = in.rec_cov[j];
+            const uint32_t idx = rc.y / 24u, r = idx / in.d;
+            row = rc.x;
+            al = idx - r * in.d;
+            cv = r + al;
+        }
+        const uint32_t bit = live ? 1u << (row & 31) : 0u;
+        // first lane of this lane's piece: the nearest start at or below it, else lane 0
+        const uint64_t below = starts & ((2ull << lane) - 1);
+        const unsigned first = below ? 63u - (unsigned)__clzll((long long)below) : 0u;
+        // last lane of a piece: the next lane starts a segment, or the wave / the rows end
+        const bool piece_end = live && (lane == 63 || ((starts >> (lane + 1)) & 1) || j + 1 >= in.n_cov);
+        const bool is_start = (starts >> lane) & 1;
+        if (live && seg < seg_cap) {
+            if (is_start) {
+                segs[seg].tile = row >> 5;
+                segs[seg].win = (uint32_t)(j / in.window);
+                if (j % in.window == 0)
+                    wconst[j / in.window].seg_begin = seg;
             }
-            if (j % in.window == 0)
-                wconst[w].seg_begin = i;
-            if (i >= seg_cap)
-                return;                    // rows out of file order: the host drops these segments
-            uint4 *o = reinterpret_cast<uint4 *>(segs + i);
-            o[0] = make_uint4(tile, w, jj == wend ? 1u : 0u, 0u);         // tile, win, last, flags (k_prep_seg_flags)
-            o[1] = make_uint4(cov[0], cov[1], cov[2], cov[3]);
-            o[2] = make_uint4(cov[4], cov[5], cov[6], cov[7]);
-            o[3] = make_uint4(alt[0], alt[1], alt[2], alt[3]);
-            o[4] = make_uint4(alt[4], alt[5], alt[6], alt[7]);
-        });
+            // the segment's final row: the next row starts another one (known here only through the next row)
+            const bool seg_end = j + 1 >= in.n_cov || seg_start(in, j + 1);
+            if (seg_end)
+                segs[seg].last = (j + 1 >= in.n_cov || (j + 1) % in.window == 0) ? 1u : 0u;
+        } else if (live && is_start && j % in.window == 0) {
+            wconst[j / in.window].seg_begin = seg;
+        }
+        const uint32_t planes = cv | (al << 8);
+        uint32_t any_planes = planes;                  // planes some lane of the wave has
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1)
+            any_planes |= __shfl_xor(any_planes, m);
+        for (int k = 0; k < 16; ++k) {
+            if (!((any_planes >> k) & 1))
+                continue;                              // wave-uniform
+            uint32_t v = ((planes >> k) & 1) ? bit : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {         // segmented inclusive OR-scan
+                const uint32_t u = __shfl_up(v, d);
+                if (lane >= first + (unsigned)d)
+                    v |= u;
+            }
+            if (piece_end && v && seg < seg_cap)
+                atomicOr(k < 8 ? &segs[seg].cov[k] : &segs[seg].alt[k - 8], v);
+        }
+    }
 }
 
 // x = m / 2^64 * 2^e with m in [2^63, 2^64): a normalised x87 extended number
@@ -454,6 +505,7 @@ void launch_prep_segments(const PrepSegArgs &a, hipStream_t st)
     const unsigned nb = blocks_for(a.n_cov);
     hipLaunchKernelGGL(k_prep_seg_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs);
+    (void)hipMemsetAsync(a.segs, 0, (size_t)a.seg_cap * sizeof(Seg), st);          // the masks are built with atomicOr
     hipLaunchKernelGGL(k_prep_seg_build, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.segs, a.seg_cap,
                        a.wconst);
     hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 1 + 63) / 64), dim3(64), 0, st, in, a.n_win, a.nck, a.wconst,

@@ -12,4 +12,9 @@ print("upload_panel_dev (transpose + alt counts)", round(t1 - t0, 4), "s")
 idx = np.arange(rows, dtype=np.uint32)
 for _ in range(2):
     t0 = time.perf_counter(); eng.upload_sites(idx, n_ref, n_alt, 100); t1 = time.perf_counter()
-    print("upload_sites 4M rows", round(t1 - t0, 4), "s")
+    print("upload_sites 4M rows", round(t1 - t0, 4), "s", eng.upload_ms())
+d_nr, d_na = torch.from_numpy(n_ref).cuda(), torch.from_numpy(n_alt).cuda()
+torch.cuda.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); eng.upload_sites_dev(None, d_nr.data_ptr(), d_na.data_ptr(), rows, 100); t1 = time.perf_counter()
+    print("upload_sites_dev 4M rows (device arrays, implicit rows)", round(t1 - t0, 5), "s", eng.upload_ms())
