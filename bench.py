@@ -357,6 +357,18 @@ def timed_run(cmd, cwd, repeat=2):
     return best
 
 
+def run_phases(cmd, cwd):
+    """One more run with IBDGEM_TIMING=1: the host program's own wall clock per phase (summed per name)."""
+    r = subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, IBDGEM_TIMING="1"))
+    out = {}
+    for line in r.stderr.splitlines():
+        if line.startswith("## time "):
+            name, sec = line[8:].rsplit(" ", 1)
+            out[name] = out.get(name, 0.0) + float(sec)
+    return out
+
+
 def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows, gpu_win):
     """warm_e2e: the host program from the packed-panel cache + legend + pileup text of ALL rows to its
     output files (summary only, and with the per-site table).  cold_e2e: from .hap text, on the first
@@ -394,6 +406,8 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
         same = gpu_win is not None and len(got) == len(gpu_win) and all(
             ["%e" % v for v in gpu_win[w]] == got[w] for w in range(len(got)))
         warm = {"rows": rows, "summary_only_s": t_sum, "with_per_site_table_s": t_tab,
+                "phases_summary_only_s": run_phases(base + ["-O", "o1", "--summary-only"], d),
+                "phases_with_per_site_table_s": run_phases(base + ["-O", "o2"], d),
                 "rows_per_s_summary_only": rows / t_sum, "rows_per_s_with_per_site_table": rows / t_tab,
                 "per_site_table_bytes": os.path.getsize(os.path.join(d, "o2", f"UNKWN.ind{target}.tab.txt")),
                 "summary_equals_engine_windows_7digits": bool(same), "host_threads": int(threads),
@@ -424,6 +438,7 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
         write_pileup_and_legend(os.path.join(d, "tiny"), n_ref, n_alt, n_ids, 1000)
         t_fixed = timed_run(cbase + ["-O", "."], os.path.join(d, "tiny"))
         cold = {"rows": r, "s": t_cold, "rows_per_s": r / t_cold, "fixed_cost_s": t_fixed,
+                "phases_s": run_phases(cbase + ["-O", "o3"], d),
                 "hap_text_bytes": r * 4 * n_ids,
                 "extrapolated_to_all_rows_s": t_fixed + (t_cold - t_fixed) * rows / r,
                 "note": f"ibdgem_amd/host/ibdgem --LD, .hap/.legend/.pileup text -> both output files on the first {r} rows "

@@ -790,6 +790,30 @@ static void window_cuts(const uint8_t *nr, const uint8_t *na, size_t n, unsigned
     cuts[parts] = n;
 }
 
+/* IBDGEM_TIMING=1 in the environment: wall-clock seconds per phase on stderr ("## time <phase> <s>") */
+static int timing_on = -1;
+static double timing_last;
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void phase(const char *name)
+{
+    if (timing_on < 0) {
+        const char *e = getenv("IBDGEM_TIMING");
+        timing_on = e && *e && *e != '0';
+        timing_last = now_s();
+        return;
+    }
+    if (!timing_on)
+        return;
+    const double t = now_s();
+    fprintf(stderr, "## time %s %.4f\n", name, t - timing_last);
+    timing_last = t;
+}
+
 /* page-locked memory from the engine when asked for and available, plain memory otherwise (never freed:
  * these arrays live as long as the program) */
 static void *io_alloc(size_t bytes, int pinned)
@@ -808,6 +832,7 @@ static void *io_alloc(size_t bytes, int pinned)
 int main(int argc, char **argv)
 {
     const clock_t t_start = clock();
+    phase("start");
     const char *hap_fn = NULL, *legend_fn = NULL, *indv_fn = NULL, *pu_fn = NULL, *vcf_fn = NULL;
     const char *sample_fn = NULL, *sample_csv = NULL, *bg_fn = NULL, *af_fn = NULL, *pos_fn = NULL;
     const char *uchr = NULL, *out_dir = NULL, *devices_arg = "0";
@@ -938,9 +963,11 @@ int main(int argc, char **argv)
         }
     }
     const long pu_id = find_name(&ids, opt_sq);            /* is the pileup's own name in the panel? (:501-506) */
+    phase("options, pileup, names");
 
     if (in_impute && read_genotypes(hap_fn, legend_fn, n_ids))
         exit(1);
+    phase("genotypes (hap or cache, legend)");
 
     /* input coverage distribution and cull ratio: find_cull_p (:83-106) */
     unsigned long in_dist[128] = {0}, in_total = 0;
@@ -981,6 +1008,7 @@ int main(int argc, char **argv)
             DIE("[::] ERROR: --devices needs at least one device index.\n");
         if (ibdg_get_alt_counts(engs[0], 0, n_rows, alt_count))
             DIE("%s\n", ibdg_last_error(engs[0]));
+        phase("device start, panel upload, alt counts");
     } else {
         for (size_t r = 0; r < n_rows; ++r) {           /* --plan: same integers, on the host */
             unsigned c = 0;
@@ -1019,6 +1047,7 @@ int main(int argc, char **argv)
         c->f = f; c->f_is_override = ovr;
         row_fate[r] = 1;
     }
+    phase("row filter chain");
 
     /* ---- per comparison individual (:522-773) ------------------------------------------ */
     /* the arrays that cross the engine's boundary live in page-locked memory when a device is in use
@@ -1030,6 +1059,7 @@ int main(int argc, char **argv)
     double *site_af = io_alloc((n_cand ? n_cand : 1) * 8, pin), *site_ll = io_alloc((n_cand ? n_cand : 1) * 24, pin);
     if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
+    phase("page-locked result arrays");
     /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
      * reads anew for each (src/ibdgem.c:584, :627-628) */
     const int batchable = !opt_plan && !has_v && cull_p == 1.0;
@@ -1060,6 +1090,7 @@ int main(int argc, char **argv)
             n++;
         }
         const unsigned long processed = n;
+        phase("per individual: site list");
 
         /* windows: runs of opt_window covered rows (:572, :657-663, :723-730) */
         size_t n_win = 0;
@@ -1136,6 +1167,7 @@ int main(int argc, char **argv)
             }
         }
 
+        phase("per individual: engine (upload, run, results)");
         FILE *tab, *sum;
         if (opt_plan) {
             tab = stdout;
@@ -1206,9 +1238,11 @@ int main(int argc, char **argv)
             fclose(sum);
         }
         free(w_first); free(w_last); free(w_ncov); free(win_ll);
+        phase("per individual: output files");
     }
     for (int d = 0; d < n_eng; ++d)
         ibdg_destroy(engs[d]);
+    phase("engine shutdown");
     pileup_free(pu);
     fprintf(stderr, "Run time: %f minutes.\n", ((double)(clock() - t_start) / CLOCKS_PER_SEC) / 60);
     return EXIT_SUCCESS;
