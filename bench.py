@@ -391,9 +391,11 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
             fh.write("placeholder: the packed-panel cache p.cache stands for the .hap text\n")
         st = os.stat(os.path.join(d, "p.hap"))
         with open(os.path.join(d, "p.cache"), "wb") as fh:
-            fh.write(struct.pack("<8sIIQQQqq", b"IBDGPNL1", n_ids, 0, rows, words_all.shape[1], st.st_size,
-                                 st.st_mtime_ns // 1_000_000_000, st.st_mtime_ns % 1_000_000_000))
+            hdr = struct.pack("<8sIIQQQqq", b"IBDGPNL2", n_ids, 0, rows, words_all.shape[1], st.st_size,
+                              st.st_mtime_ns // 1_000_000_000, st.st_mtime_ns % 1_000_000_000)
+            fh.write(hdr)
             fh.write(np.ones(rows, dtype=np.uint8).tobytes())
+            fh.write(b"\0" * (-(len(hdr) + rows) % 4096))          # the rows start on a 4096-byte boundary (ingest.c)
             for a in range(0, rows, 500_000):
                 fh.write(np.ascontiguousarray(words_all[a:a + 500_000]).tobytes())
         base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", f"ind{target}", "--LD",

@@ -358,39 +358,158 @@ typedef struct {
     const char *fn;
     size_t n;
     int rc;
+    int threads;
 } legend_job;
 
+/* one legend line into a row and a string arena (src/ibdgem.c:589) */
+typedef struct {
+    row_t *rows;
+    size_t n, cap;
+    char *arena;
+    size_t arena_len, arena_cap;
+} legend_part;
+
+static uint32_t part_arena_add(legend_part *t, const char *s)
+{
+    const size_t l = strlen(s) + 1;
+    if (t->arena_len + l > t->arena_cap) {
+        t->arena_cap = t->arena_cap ? t->arena_cap * 2 : (1 << 20);
+        while (t->arena_len + l > t->arena_cap)
+            t->arena_cap *= 2;
+        t->arena = realloc(t->arena, t->arena_cap);
+    }
+    memcpy(t->arena + t->arena_len, s, l);
+    t->arena_len += l;
+    return (uint32_t)(t->arena_len - l);
+}
+
+static void part_add_legend_line(legend_part *t, const char *l)
+{
+    if (t->n == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : (1 << 16);
+        t->rows = realloc(t->rows, t->cap * sizeof *t->rows);
+    }
+    row_t *r = &t->rows[t->n++];
+    memset(r, 0, sizeof *r);
+    char id[129], ref[129], alt[129];
+    if (sscanf(l, "%128s %lu %128s %128s", id, &r->pos, ref, alt) == 4) {
+        r->legend_ok = 1;
+        r->id_off = part_arena_add(t, id);
+        r->ref_off = part_arena_add(t, ref);
+        r->alt_off = part_arena_add(t, alt);
+    }
+}
+
+typedef struct {
+    const char *base;
+    size_t a, b;
+    legend_part part;
+} legend_range;
+
+static void *legend_worker(void *arg)
+{
+    legend_range *j = arg;
+    char *buf = NULL;
+    size_t cap = 0;
+    for (size_t p = j->a; p < j->b;) {
+        const char *nl = memchr(j->base + p, '\n', j->b - p);
+        const size_t len = nl ? (size_t)(nl - (j->base + p)) + 1 : j->b - p;
+        if (len + 1 > cap) {
+            cap = (len + 1) * 2;
+            buf = realloc(buf, cap);
+        }
+        memcpy(buf, j->base + p, len);
+        buf[len] = 0;
+        part_add_legend_line(&j->part, buf);
+        p += len;
+    }
+    free(buf);
+    return NULL;
+}
+
+/* A large plain legend is cut into byte ranges at line starts, one thread each; rows and strings are
+ * joined in file order (arena offsets shifted).  Small or gzip files go line by line. */
 static void *read_legend(void *arg)
 {
     legend_job *j = arg;
+    size_t size = 0;
+    const char *base = j->threads > 1 ? ls_map(j->fn, &size) : NULL;
+    if (base && size >= ls_mt_min_bytes()) {
+        const char *nl = memchr(base, '\n', size);              /* legend header (src/ibdgem.c:555) */
+        const size_t from = nl ? (size_t)(nl - base) + 1 : size;
+        int T = j->threads > 64 ? 64 : j->threads;
+        size_t cut[65];
+        legend_range rg[64];
+        pthread_t th[64];
+        ls_split_lines(base, size, from, T, cut);
+        for (int t = 0; t < T; ++t) {
+            memset(&rg[t], 0, sizeof rg[t]);
+            rg[t].base = base;
+            rg[t].a = cut[t];
+            rg[t].b = cut[t + 1];
+            if (pthread_create(&th[t], NULL, legend_worker, &rg[t]) != 0) {
+                legend_worker(&rg[t]);
+                th[t] = pthread_self();
+            }
+        }
+        size_t total = 0, atotal = 0;
+        for (int t = 0; t < T; ++t) {
+            if (!pthread_equal(th[t], pthread_self()))
+                pthread_join(th[t], NULL);
+            total += rg[t].part.n;
+            atotal += rg[t].part.arena_len;
+        }
+        rows = realloc(rows, (total ? total : 1) * sizeof *rows);
+        if (arena_len + atotal > arena_cap) {
+            arena_cap = arena_len + atotal;
+            arena = realloc(arena, arena_cap ? arena_cap : 1);
+        }
+        size_t n = 0;
+        for (int t = 0; t < T; ++t) {
+            const uint32_t shift = (uint32_t)arena_len;
+            if (rg[t].part.arena_len)
+                memcpy(arena + arena_len, rg[t].part.arena, rg[t].part.arena_len);
+            arena_len += rg[t].part.arena_len;
+            for (size_t i = 0; i < rg[t].part.n; ++i) {
+                row_t r = rg[t].part.rows[i];
+                if (r.legend_ok) {
+                    r.id_off += shift;
+                    r.ref_off += shift;
+                    r.alt_off += shift;
+                }
+                rows[n++] = r;
+            }
+            free(rg[t].part.rows);
+            free(rg[t].part.arena);
+        }
+        ls_unmap(base, size);
+        j->n = n;
+        return NULL;
+    }
+    ls_unmap(base, size);
     line_src *leg = ls_open(j->fn);
     if (!leg) {
         j->rc = 1;
         return NULL;
     }
-    size_t cap = 0, n = 0;
+    legend_part t;
+    memset(&t, 0, sizeof t);
+    t.arena = arena;
+    t.arena_len = arena_len;
+    t.arena_cap = arena_cap;
     ls_next(leg, NULL);                                   /* legend header (src/ibdgem.c:555) */
     for (;;) {
         char *l = ls_next(leg, NULL);
         if (!l)
             break;
-        if (n == cap) {
-            cap = cap ? cap * 2 : (1 << 16);
-            rows = realloc(rows, cap * sizeof *rows);
-        }
-        row_t *r = &rows[n];
-        memset(r, 0, sizeof *r);
-        char id[129], ref[129], alt[129];
-        if (sscanf(l, "%128s %lu %128s %128s", id, &r->pos, ref, alt) == 4) {
-            r->legend_ok = 1;
-            r->id_off = arena_add(id);
-            r->ref_off = arena_add(ref);
-            r->alt_off = arena_add(alt);
-        }
-        n++;
+        part_add_legend_line(&t, l);
     }
     ls_close(leg);
-    j->n = n;
+    rows = t.rows;
+    arena = t.arena;
+    arena_len = t.arena_len;
+    arena_cap = t.arena_cap;
+    j->n = t.n;
     return NULL;
 }
 
@@ -406,7 +525,9 @@ static int default_threads(void)
 static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_ids)
 {
     row_words = ibdg_row_words(n_ids);
-    legend_job lj = {legend_fn, 0, 0};
+    /* the .hap team and the legend team share the threads: the legend is ~1/400 of the text, but its rows
+     * cost a sscanf each; with the packed-panel cache the legend is all there is to parse */
+    legend_job lj = {legend_fn, 0, 0, opt_threads > 0 ? opt_threads : default_threads()};
     pthread_t lt;
     const int threaded = pthread_create(&lt, NULL, read_legend, &lj) == 0;
     if (!threaded)
@@ -822,11 +943,89 @@ static void *io_alloc(size_t bytes, int pinned)
     return p ? p : malloc(bytes);
 }
 
+/* the row filter chain up to the read counts (src/ibdgem.c:589-626) for the rows [a, b) */
+typedef struct {
+    size_t a, b;
+    const pileup_t *pu;
+    const uint32_t *alt_count;
+    unsigned n_ids;
+    int in_vcf, has_p, has_A;
+    cand_t *cand;               /* this range's candidates, from its own start */
+    size_t n;
+    uint8_t *row_fate;
+} filter_job;
+
+static void *filter_rows(void *arg)
+{
+    filter_job *j = arg;
+    for (size_t r = j->a; r < j->b; ++r) {
+        const row_t *R = &rows[r];
+        j->row_fate[r] = 2;
+        if (!R->hap_ok) { j->row_fate[r] = 0; continue; }
+        if (!R->legend_ok) continue;
+        const char *ref = arena + R->ref_off, *alt = arena + R->alt_off;
+        if (!is_snp(ref, alt)) continue;
+        if (j->in_vcf && R->qual < opt_min_qual) continue;                /* -q (src/ibdgem.c:297) */
+        const pu_line *pl = pileup_find(j->pu, R->pos);
+        if (!pl) continue;
+        if (j->has_p && !pos_listed(R->pos)) continue;
+        double f = (double)j->alt_count[r] / (int)(j->n_ids * 2);
+        int ovr = 0;
+        if (j->has_A) {
+            const af_rec *a = find_af(R->pos);
+            if (a) { f = a->f; ovr = 1; }
+        }
+        if (f > opt_max_af || f < opt_min_af) continue;
+        const unsigned nr = pileup_count(pl, ref[0]), na = pileup_count(pl, alt[0]);
+        if (nr + na > opt_max_cov) continue;
+        cand_t *c = &j->cand[j->n++];
+        c->row = (uint32_t)r; c->pu = (uint32_t)(pl - j->pu->lines); c->n_ref = (uint8_t)nr; c->n_alt = (uint8_t)na;
+        c->f = f; c->f_is_override = ovr;
+        j->row_fate[r] = 1;
+    }
+    return NULL;
+}
+
+/* engine contexts created on a thread of their own while the main thread parses the inputs */
+typedef struct {
+    int dev[64], n;
+    double eps;
+    unsigned max_cov;
+    ibdg_ctx *eng[64];
+    char *err[64];
+} dev_job_t;
+
+static pthread_t g_dev_thread;
+static int g_dev_started;
+
+/* exit() while another thread is inside the GPU runtime's start-up is asking for trouble: wait for it first */
+static void quit(int code)
+{
+    if (g_dev_started) {
+        g_dev_started = 0;
+        pthread_join(g_dev_thread, NULL);
+    }
+    exit(code);
+}
+
+static void *dev_start(void *arg)
+{
+    dev_job_t *j = arg;
+    for (int d = 0; d < j->n; ++d) {
+        j->eng[d] = ibdg_create(j->dev[d], j->eps, j->max_cov);
+        if (!j->eng[d]) {
+            j->err[d] = strdup(ibdg_last_error(NULL));
+            break;                     /* the message of the first failure is the one reported */
+        }
+    }
+    return NULL;
+}
+
 #define TARGET_BATCH 16      /* comparison individuals per engine call when their site lists coincide */
 #define DIE(...)                          \
     do {                                  \
         fprintf(stderr, __VA_ARGS__);     \
-        exit(1);                          \
+        quit(1);                          \
     } while (0)
 
 int main(int argc, char **argv)
@@ -909,14 +1108,27 @@ int main(int argc, char **argv)
 
     if (!pu_fn)
         DIE("[::] ERROR parsing Pileup data; make sure input is valid.\n");
-    pileup_t *pu = pileup_read(pu_fn, uchr);
+    /* start the device(s) now: ibdg_create takes ~0.2 s of runtime start-up that needs none of the inputs */
+    static dev_job_t dev_job;
+    if (!opt_plan) {
+        dev_job.eps = opt_eps;
+        dev_job.max_cov = opt_max_cov;
+        char *dl = strdup(devices_arg);
+        for (char *tok = strtok(dl, ","); tok && dev_job.n < 64; tok = strtok(NULL, ","))
+            dev_job.dev[dev_job.n++] = atoi(tok);
+        free(dl);
+        if (pthread_create(&g_dev_thread, NULL, dev_start, &dev_job) != 0)
+            DIE("[::] ERROR: cannot start a worker thread.\n");
+        g_dev_started = 1;
+    }
+    pileup_t *pu = pileup_read_mt(pu_fn, uchr, opt_threads > 0 ? opt_threads : default_threads());
     if (!pu)
         DIE("[::] ERROR parsing Pileup data; make sure input is valid.\n");
     if (has_A && read_af_file(af_fn, uchr))
-        exit(1);
+        quit(1);
     if (has_p) {
         if (read_pos_file(pos_fn, uchr))
-            exit(1);
+            quit(1);
         qsort(pos_tab, pos_n, sizeof *pos_tab, cmp_ul);
     }
     if (!in_vcf && !in_impute)
@@ -929,10 +1141,10 @@ int main(int argc, char **argv)
     names_t ids;
     if (in_vcf) {
         if (read_genotypes_vcf(vcf_fn, &ids))
-            exit(1);
+            quit(1);
     } else {
         if (read_names(indv_fn, &ids))
-            exit(1);
+            quit(1);
         if (ids.n == 0)
             DIE("[::] ERROR: No samples found in .indv file.\n");
     }
@@ -940,10 +1152,10 @@ int main(int argc, char **argv)
     idlist_t targets = {NULL, 0}, bg = {NULL, 0};
     if (has_S) {                                            /* -S wins over -s (:1135-1155) */
         if (read_idlist_file(sample_fn, &ids, "Sample %s not found in reference panel.\n", "read_sf", &targets))
-            exit(1);
+            quit(1);
     } else if (has_s) {
         if (read_idlist_csv(sample_csv, &ids, &targets))
-            exit(1);
+            quit(1);
     } else {
         targets.n = n_ids;
         targets.idx = malloc(n_ids * sizeof *targets.idx);
@@ -953,7 +1165,7 @@ int main(int argc, char **argv)
     uint8_t *bg_count = NULL;
     if (has_B) {
         if (read_idlist_file(bg_fn, &ids, "Reference sample %s not found in input panel.\n", "read_rf", &bg))
-            exit(1);
+            quit(1);
         bg_count = calloc(n_ids, 1);
         for (size_t i = 0; i < bg.n; ++i) {
             /* the engine takes one byte per individual: a list naming somebody 256 times is refused, not truncated */
@@ -966,7 +1178,7 @@ int main(int argc, char **argv)
     phase("options, pileup, names");
 
     if (in_impute && read_genotypes(hap_fn, legend_fn, n_ids))
-        exit(1);
+        quit(1);
     phase("genotypes (hap or cache, legend)");
 
     /* input coverage distribution and cull ratio: find_cull_p (:83-106) */
@@ -990,11 +1202,14 @@ int main(int argc, char **argv)
     int n_eng = 0;
     uint32_t *alt_count = malloc((n_rows ? n_rows : 1) * sizeof *alt_count);
     if (!opt_plan) {
-        char *dl = strdup(devices_arg);
-        for (char *tok = strtok(dl, ","); tok && n_eng < 64; tok = strtok(NULL, ",")) {
-            ibdg_ctx *e = ibdg_create(atoi(tok), opt_eps, opt_max_cov);
+        /* the contexts were being created (device start-up, ~0.2 s) while the inputs were parsed */
+        pthread_join(g_dev_thread, NULL);
+        g_dev_started = 0;
+        phase("device start (the part not hidden behind parsing)");
+        for (int d = 0; d < dev_job.n; ++d) {
+            ibdg_ctx *e = dev_job.eng[d];
             if (!e)
-                DIE("%s\n", ibdg_last_error(NULL));
+                DIE("%s\n", dev_job.err[d] ? dev_job.err[d] : "[::] ERROR in ibdg_create");
             if (ibdg_upload_panel(e, packed, n_rows, n_ids))      /* every GPU holds the whole panel */
                 DIE("%s\n", ibdg_last_error(e));
             if (opt_ref_order) {                                  /* background list in the -B file's order (:741) */
@@ -1003,7 +1218,6 @@ int main(int argc, char **argv)
             }
             engs[n_eng++] = e;
         }
-        free(dl);
         if (n_eng == 0)
             DIE("[::] ERROR: --devices needs at least one device index.\n");
         if (ibdg_get_alt_counts(engs[0], 0, n_rows, alt_count))
@@ -1018,34 +1232,36 @@ int main(int argc, char **argv)
         }
     }
 
-    /* ---- target-independent part of the row filter chain (:589-626) ------------------- */
+    /* ---- target-independent part of the row filter chain (:589-626) -------------------
+     * Rows are independent here: a team of threads takes contiguous row ranges, each fills its own part
+     * of cand[] from the range's first row on, and the parts are closed up in order afterwards. */
     cand_t *cand = malloc((n_rows ? n_rows : 1) * sizeof *cand);
     uint8_t *row_fate = calloc(n_rows ? n_rows : 1, 1);   /* 0 skip-before-v, 1 candidate, 2 skipped after the -v test */
     size_t n_cand = 0;
-    for (size_t r = 0; r < n_rows; ++r) {
-        const row_t *R = &rows[r];
-        row_fate[r] = 2;
-        if (!R->hap_ok) { row_fate[r] = 0; continue; }
-        if (!R->legend_ok) continue;
-        const char *ref = arena + R->ref_off, *alt = arena + R->alt_off;
-        if (!is_snp(ref, alt)) continue;
-        if (in_vcf && R->qual < opt_min_qual) continue;                /* -q (src/ibdgem.c:297) */
-        const pu_line *pl = pileup_find(pu, R->pos);
-        if (!pl) continue;
-        if (has_p && !pos_listed(R->pos)) continue;
-        double f = (double)alt_count[r] / (int)(n_ids * 2);
-        int ovr = 0;
-        if (has_A) {
-            const af_rec *a = find_af(R->pos);
-            if (a) { f = a->f; ovr = 1; }
+    {
+        int T = opt_threads > 0 ? opt_threads : default_threads();
+        if (T > 64) T = 64;
+        if (n_rows * 64 < ls_mt_min_bytes()) T = 1;           /* small inputs (and the tests, unless they ask) on one thread */
+        filter_job fj[64];
+        pthread_t th[64];
+        for (int t = 0; t < T; ++t) {
+            filter_job *j = &fj[t];
+            j->a = n_rows * (size_t)t / (size_t)T;
+            j->b = n_rows * (size_t)(t + 1) / (size_t)T;
+            j->pu = pu; j->alt_count = alt_count; j->n_ids = n_ids; j->in_vcf = in_vcf; j->has_p = has_p; j->has_A = has_A;
+            j->cand = cand + j->a; j->row_fate = row_fate; j->n = 0;
+            if (T == 1 || pthread_create(&th[t], NULL, filter_rows, j) != 0) {
+                filter_rows(j);
+                th[t] = pthread_self();
+            }
         }
-        if (f > opt_max_af || f < opt_min_af) continue;
-        const unsigned nr = pileup_count(pl, ref[0]), na = pileup_count(pl, alt[0]);
-        if (nr + na > opt_max_cov) continue;
-        cand_t *c = &cand[n_cand++];
-        c->row = (uint32_t)r; c->pu = (uint32_t)(pl - pu->lines); c->n_ref = (uint8_t)nr; c->n_alt = (uint8_t)na;
-        c->f = f; c->f_is_override = ovr;
-        row_fate[r] = 1;
+        for (int t = 0; t < T; ++t) {
+            if (!pthread_equal(th[t], pthread_self()))
+                pthread_join(th[t], NULL);
+            if (fj[t].cand != cand + n_cand)
+                memmove(cand + n_cand, fj[t].cand, fj[t].n * sizeof *cand);
+            n_cand += fj[t].n;
+        }
     }
     phase("row filter chain");
 
@@ -1178,12 +1394,12 @@ int main(int argc, char **argv)
             char *tab_fn, *sum_fn;
             if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
                 asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
-                exit(1);
+                quit(1);
             tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
             sum = fopen(sum_fn, "w");
             if (!tab || !sum) {
                 fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
-                return 1;
+                quit(1);
             }
             free(tab_fn);
             free(sum_fn);
@@ -1211,7 +1427,7 @@ int main(int argc, char **argv)
             proto.plan = opt_plan;
             if (write_rows_parallel(tab, proto, n, opt_threads > 0 ? opt_threads : default_threads())) {
                 fprintf(stderr, "[::] ERROR writing the per-site rows of %s.\n", tname);
-                return 1;
+                quit(1);
             }
         }
         for (size_t w = 0; w < n_win; ++w) {

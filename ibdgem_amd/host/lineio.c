@@ -4,6 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 struct line_src {
     FILE *f;
@@ -83,4 +87,52 @@ void ls_close(line_src *ls)
         fclose(ls->f);
     free(ls->buf);
     free(ls);
+}
+
+const char *ls_map(const char *fn, size_t *size)
+{
+    if (!fn || name_is_gz(fn))
+        return NULL;
+    const int fd = open(fn, O_RDONLY);
+    if (fd < 0)
+        return NULL;
+    struct stat st;
+    const char *base = NULL;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            base = m;
+            *size = (size_t)st.st_size;
+        }
+    }
+    close(fd);
+    return base;
+}
+
+void ls_unmap(const char *base, size_t size)
+{
+    if (base)
+        munmap((void *)base, size);
+}
+
+void ls_split_lines(const char *base, size_t size, size_t from, int parts, size_t *cut)
+{
+    cut[0] = from;
+    for (int p = 1; p < parts; ++p) {
+        size_t c = from + (size - from) / (size_t)parts * (size_t)p;
+        if (c < cut[p - 1])
+            c = cut[p - 1];
+        if (c > from && c < size && base[c - 1] != '\n') {          /* move to the start of the next line */
+            const char *q = memchr(base + c, '\n', size - c);
+            c = q ? (size_t)(q - base) + 1 : size;
+        }
+        cut[p] = c;
+    }
+    cut[parts] = size;
+}
+
+size_t ls_mt_min_bytes(void)
+{
+    const char *e = getenv("IBDGEM_MT_MIN_BYTES");
+    return e && *e ? (size_t)strtoull(e, NULL, 10) : (size_t)1 << 20;
 }

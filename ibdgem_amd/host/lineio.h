@@ -15,4 +15,15 @@ line_src *ls_open(const char *fn);          /* NULL (and a message on stderr) on
 char *ls_next(line_src *ls, size_t *len);
 int ls_rewind(line_src *ls);
 void ls_close(line_src *ls);
+
+/* Plain (not .gz) files for readers that split the text among threads: the whole file mapped
+ * read-only, or NULL (gzip name, empty file, any failure -- the caller then reads line by line). */
+const char *ls_map(const char *fn, size_t *size);
+void ls_unmap(const char *base, size_t size);
+/* cut[0..parts]: byte offsets from `from` to `size` that all sit at the start of a line (cut[0] = from,
+ * cut[parts] = size), about equal in bytes. */
+void ls_split_lines(const char *base, size_t size, size_t from, int parts, size_t *cut);
+/* files smaller than this are read line by line (1 MiB; IBDGEM_MT_MIN_BYTES in the environment overrides it,
+ * which is how the tests send their small files through the threaded readers) */
+size_t ls_mt_min_bytes(void);
 #endif

@@ -2,6 +2,7 @@
 #include "lineio.h"
 
 #include <ctype.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,6 +33,11 @@ static const char *next_field(const char *p, const char **end)
 }
 
 int pileup_parse_line(const char *line, pu_line *out, char *chr_buf)
+{
+    return pileup_parse_line_to(line, out, chr_buf, stderr);
+}
+
+int pileup_parse_line_to(const char *line, pu_line *out, char *chr_buf, FILE *err)
 {
     const char *e;
     /* chr, pos, ref, cov  -- sscanf("%s\t%u\t%c\t%u\t") of src/pileup.c:216-220 */
@@ -106,7 +112,7 @@ int pileup_parse_line(const char *line, pu_line *out, char *chr_buf)
         case '$': ++i; continue;
         case '^': i += 2; continue;                /* start marker + mapping-quality character */
         default:
-            fprintf(stderr, "Cannot parse %c in reads field\n", c);
+            fprintf(err, "Cannot parse %c in reads field\n", c);
             return 1;
         }
         if (got >= 128)
@@ -118,11 +124,11 @@ int pileup_parse_line(const char *line, pu_line *out, char *chr_buf)
         ++i;
     }
     if (got != cov) {
-        fprintf(stderr, "Incorrect number of bases read in: %s\n", line);
+        fprintf(err, "Incorrect number of bases read in: %s\n", line);
         return 1;
     }
     if ((size_t)(e_q - f_q) != got && (size_t)(e_m - f_m) != got) {
-        fprintf(stderr, "Incorrect number of base or map quals in: %s\n", line);
+        fprintf(err, "Incorrect number of base or map quals in: %s\n", line);
         return 1;
     }
     for (int k = 0; k < 4; ++k)
@@ -130,45 +136,48 @@ int pileup_parse_line(const char *line, pu_line *out, char *chr_buf)
     return 0;
 }
 
-pileup_t *pileup_read(const char *fn, const char *chr)
+/* one line into a growing table: what the loop of init_Pu_chr does with it (src/pileup.c:487-559) */
+typedef struct {
+    pu_line *lines;
+    size_t n, cap;
+    char **chr_names;
+    size_t n_chr;
+} pu_part;
+
+static void part_add_line(pu_part *t, const char *line, const char *chr, FILE *err)
 {
-    line_src *ls = ls_open(fn);
-    if (!ls)
-        return NULL;
-    pileup_t *pu = calloc(1, sizeof *pu);
-    size_t cap = 0;
     char cb[256];
-    char *line;
-    while ((line = ls_next(ls, NULL))) {
-        if (pu->n_lines == cap) {
-            cap = cap ? cap * 2 : (1 << 16);
-            pu->lines = realloc(pu->lines, cap * sizeof *pu->lines);
-        }
-        pu_line *l = &pu->lines[pu->n_lines];
-        const int st = pileup_parse_line(line, l, cb);
-        if (st == 2) {
-            fprintf(stderr, "Problem parsing %s\n", line);
-            continue;
-        }
-        if (st)
-            continue;
-        if (chr && strcmp(cb, chr) != 0)
-            continue;
-        size_t ci = pu->n_chr;
-        if (pu->n_chr && strcmp(pu->chr_names[pu->n_chr - 1], cb) == 0)
-            ci = pu->n_chr - 1;
-        else
-            for (ci = 0; ci < pu->n_chr; ++ci)
-                if (strcmp(pu->chr_names[ci], cb) == 0)
-                    break;
-        if (ci == pu->n_chr) {
-            pu->chr_names = realloc(pu->chr_names, (pu->n_chr + 1) * sizeof *pu->chr_names);
-            pu->chr_names[pu->n_chr++] = strdup(cb);
-        }
-        l->chr = (uint32_t)ci;
-        pu->n_lines++;
+    if (t->n == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : (1 << 16);
+        t->lines = realloc(t->lines, t->cap * sizeof *t->lines);
     }
-    ls_close(ls);
+    pu_line *l = &t->lines[t->n];
+    const int st = pileup_parse_line_to(line, l, cb, err);
+    if (st == 2) {
+        fprintf(err, "Problem parsing %s\n", line);
+        return;
+    }
+    if (st)
+        return;
+    if (chr && strcmp(cb, chr) != 0)
+        return;
+    size_t ci = t->n_chr;
+    if (t->n_chr && strcmp(t->chr_names[t->n_chr - 1], cb) == 0)
+        ci = t->n_chr - 1;
+    else
+        for (ci = 0; ci < t->n_chr; ++ci)
+            if (strcmp(t->chr_names[ci], cb) == 0)
+                break;
+    if (ci == t->n_chr) {
+        t->chr_names = realloc(t->chr_names, (t->n_chr + 1) * sizeof *t->chr_names);
+        t->chr_names[t->n_chr++] = strdup(cb);
+    }
+    l->chr = (uint32_t)ci;
+    t->n++;
+}
+
+static pileup_t *pileup_finish(pileup_t *pu, const char *fn)
+{
     if (pu->n_lines == 0) {
         fprintf(stderr, "[::] ERROR in init_Pu_chr(): Cannot parse mpileup lines from %s.\n", fn);
         pileup_free(pu);
@@ -181,6 +190,126 @@ pileup_t *pileup_read(const char *fn, const char *chr)
             return NULL;
         }
     return pu;
+}
+
+pileup_t *pileup_read(const char *fn, const char *chr)
+{
+    line_src *ls = ls_open(fn);
+    if (!ls)
+        return NULL;
+    pu_part t;
+    memset(&t, 0, sizeof t);
+    char *line;
+    while ((line = ls_next(ls, NULL)))
+        part_add_line(&t, line, chr, stderr);
+    ls_close(ls);
+    pileup_t *pu = calloc(1, sizeof *pu);
+    pu->lines = t.lines;
+    pu->n_lines = t.n;
+    pu->chr_names = t.chr_names;
+    pu->n_chr = t.n_chr;
+    return pileup_finish(pu, fn);
+}
+
+typedef struct {
+    const char *base;
+    size_t a, b;
+    const char *chr;
+    pu_part part;
+    char *msg;              /* what this range would have written to stderr */
+    size_t msg_len;
+} pu_job;
+
+static void *pu_worker(void *arg)
+{
+    pu_job *j = arg;
+    FILE *err = open_memstream(&j->msg, &j->msg_len);
+    char *buf = NULL;
+    size_t cap = 0;
+    for (size_t p = j->a; p < j->b;) {
+        const char *nl = memchr(j->base + p, '\n', j->b - p);
+        const size_t len = nl ? (size_t)(nl - (j->base + p)) + 1 : j->b - p;    /* with its '\n', like ls_next */
+        if (len + 1 > cap) {
+            cap = (len + 1) * 2;
+            buf = realloc(buf, cap);
+        }
+        memcpy(buf, j->base + p, len);
+        buf[len] = 0;
+        part_add_line(&j->part, buf, j->chr, err ? err : stderr);
+        p += len;
+    }
+    free(buf);
+    if (err)
+        fclose(err);
+    return NULL;
+}
+
+pileup_t *pileup_read_mt(const char *fn, const char *chr, int threads)
+{
+    size_t size = 0;
+    const char *base = threads > 1 ? ls_map(fn, &size) : NULL;
+    if (!base || size < ls_mt_min_bytes()) {                            /* gzip, small or unmappable: line by line */
+        ls_unmap(base, size);
+        return pileup_read(fn, chr);
+    }
+    if (threads > 64)
+        threads = 64;
+    size_t cut[65];
+    pu_job jobs[64];
+    pthread_t th[64];
+    ls_split_lines(base, size, 0, threads, cut);
+    for (int t = 0; t < threads; ++t) {
+        memset(&jobs[t], 0, sizeof jobs[t]);
+        jobs[t].base = base;
+        jobs[t].a = cut[t];
+        jobs[t].b = cut[t + 1];
+        jobs[t].chr = chr;
+        if (pthread_create(&th[t], NULL, pu_worker, &jobs[t]) != 0) {
+            pu_worker(&jobs[t]);
+            th[t] = pthread_self();
+        }
+    }
+    pileup_t *pu = calloc(1, sizeof *pu);
+    size_t total = 0;
+    for (int t = 0; t < threads; ++t) {
+        if (!pthread_equal(th[t], pthread_self()))
+            pthread_join(th[t], NULL);
+        total += jobs[t].part.n;
+    }
+    pu->lines = malloc((total ? total : 1) * sizeof *pu->lines);
+    for (int t = 0; t < threads; ++t) {
+        pu_job *j = &jobs[t];
+        if (j->msg_len)
+            fwrite(j->msg, 1, j->msg_len, stderr);
+        free(j->msg);
+        /* chromosome names in order of first appearance over the whole file; lines renumbered to them */
+        uint32_t map[256];
+        uint32_t *mp = j->part.n_chr <= 256 ? map : malloc(j->part.n_chr * sizeof *mp);
+        for (size_t c = 0; c < j->part.n_chr; ++c) {
+            size_t g = 0;
+            for (; g < pu->n_chr; ++g)
+                if (strcmp(pu->chr_names[g], j->part.chr_names[c]) == 0)
+                    break;
+            if (g == pu->n_chr) {
+                pu->chr_names = realloc(pu->chr_names, (pu->n_chr + 1) * sizeof *pu->chr_names);
+                pu->chr_names[pu->n_chr++] = j->part.chr_names[c];
+            } else {
+                free(j->part.chr_names[c]);
+            }
+            mp[c] = (uint32_t)g;
+        }
+        for (size_t i = 0; i < j->part.n; ++i) {
+            pu->lines[pu->n_lines] = j->part.lines[i];
+            pu->lines[pu->n_lines].chr = mp[j->part.lines[i].chr];
+            pu->n_lines++;
+        }
+        if (mp != map)
+            free(mp);
+        free(j->part.chr_names);
+        free(j->part.lines);
+    }
+    ls_unmap(base, size);
+    return pileup_finish(pu, fn);
 }
 
 const pu_line *pileup_find(const pileup_t *pu, unsigned long pos)

@@ -29,6 +29,9 @@ typedef struct {
 /* Whole file -> table; only lines whose chromosome equals `chr` when chr != NULL.
  * NULL on error (message on stderr), including unsorted input. */
 pileup_t *pileup_read(const char *fn, const char *chr);
+/* the same with the lines of a plain file parsed by `threads` threads (byte ranges cut at line starts,
+ * tables and messages joined in file order: same table, same stderr text as pileup_read) */
+pileup_t *pileup_read_mt(const char *fn, const char *chr, int threads);
 /* line with exactly this position, or NULL (binary search, like fetch_Pul) */
 const pu_line *pileup_find(const pileup_t *pu, unsigned long pos);
 /* count_base_from_pul: bytes equal to `base`; 0 for anything but A,C,G,T */
@@ -39,4 +42,7 @@ void pileup_free(pileup_t *pu);
  * 1 = drop it silently or with the reference's message, 2 = unparsable start
  * (src/pileup.c:206-415). */
 int pileup_parse_line(const char *line, pu_line *out, char *chr_buf);
+/* the same with the reference's messages written to `err` instead of stderr */
+#include <stdio.h>
+int pileup_parse_line_to(const char *line, pu_line *out, char *chr_buf, FILE *err);
 #endif

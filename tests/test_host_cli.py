@@ -343,3 +343,58 @@ def test_cli_reference_order_mode(case, tmp_path):
     for fn in sorted(os.listdir(ref)):
         got, want = _read(str(tmp_path / fn[:-3])), _read(os.path.join(ref, fn))
         assert (got[1:] if fn.endswith(".tab.txt.gz") else got) == want, fn
+
+
+@pytest.mark.parametrize("tag,case", [("synA", c) for c in G.cases("synA")["cases"]][:6] + [("synB", c) for c in G.cases("synB")["cases"]][:3])
+def test_threaded_text_readers_give_the_same_plan_and_messages(tag, case):
+    """Pileup and legend files above 1 MiB are parsed by a team of threads (byte ranges cut at line starts,
+    tables and stderr text joined in file order).  IBDGEM_MT_MIN_BYTES=1 sends the small golden inputs
+    through that path: stdout and stderr must equal the line-by-line run's, for any team size."""
+    meta = G.cases(tag)
+    args = meta["base_args"] + meta["cases"][case] + ["--plan"]
+    cwd = os.path.join(G.GOLD, tag, "input")
+    want = subprocess.run([_exe()] + args + ["--threads", "1"], cwd=cwd, capture_output=True, text=True)
+    assert want.returncode == 0
+    strip = lambda e: "\n".join(l for l in e.splitlines() if not l.startswith("Run time:"))
+    for th in ("2", "3", "7"):
+        got = subprocess.run([_exe()] + args + ["--threads", th], cwd=cwd, capture_output=True, text=True,
+                             env=dict(os.environ, IBDGEM_MT_MIN_BYTES="1"))
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == want.stdout
+        assert strip(got.stderr) == strip(want.stderr)
+
+
+def test_threaded_pileup_reader_on_messy_lines(tmp_path):
+    """Unparsable starts, bad read fields, over-deep lines, a last line without newline and several
+    chromosomes: the threaded reader reports and keeps what the line-by-line reader does."""
+    import random
+    rnd = random.Random(5)
+    lines, pos = [], 100
+    for i in range(4000):
+        pos += rnd.randint(1, 9)
+        kind = rnd.random()
+        chrom = "chr1" if i < 2500 else "chr2" if i < 3300 else "chr1"
+        if kind < 0.02:
+            lines.append("garbage")
+        elif kind < 0.04:
+            lines.append(f"{chrom}\t{pos}\tA\t3\tAC?\tIII\tIII")
+        elif kind < 0.06:
+            lines.append(f"{chrom}\t{pos}\tA\t2\tACG\tII\tII")
+        elif kind < 0.08:
+            lines.append(f"{chrom}\t{pos}\tA\t200\t{'A' * 200}\t{'I' * 200}\t{'I' * 200}")
+        else:
+            c = rnd.randint(0, 6)
+            bases = "".join(rnd.choice("ACGTacgt.,") for _ in range(c)) or "*"
+            lines.append(f"{chrom}\t{pos}\tN\t{c}\t{bases}\t{'I' * max(c, 1)}\t{'I' * max(c, 1)}")
+    pu = tmp_path / "m.pileup"
+    pu.write_text("\n".join(lines))                       # no newline at the end
+    base = ["-H", os.path.join(FIX_IN, "test.hap"), "-L", os.path.join(FIX_IN, "test.legend"), "-I",
+            os.path.join(FIX_IN, "test.indv"), "-P", str(pu), "--plan"]
+    want = subprocess.run([_exe()] + base + ["--threads", "1"], capture_output=True, text=True)
+    strip = lambda e: "\n".join(l for l in e.splitlines() if not l.startswith("Run time:"))
+    for th in ("2", "5", "16"):
+        got = subprocess.run([_exe()] + base + ["--threads", th], capture_output=True, text=True,
+                             env=dict(os.environ, IBDGEM_MT_MIN_BYTES="1"))
+        assert got.returncode == want.returncode
+        assert got.stdout == want.stdout and strip(got.stderr) == strip(want.stderr)
+    assert "Problem parsing garbage" in want.stderr and "Cannot parse ? in reads field" in want.stderr

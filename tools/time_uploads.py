@@ -9,6 +9,11 @@ panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
 eng = ibdgem_amd.Engine(0, 0.02, 20)
 t0 = time.perf_counter(); eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], 2504); t1 = time.perf_counter()
 print("upload_panel_dev (transpose + alt counts)", round(t1 - t0, 4), "s")
+host = panel.cpu().numpy().view(np.uint64)
+for _ in range(2):
+    t0 = time.perf_counter(); eng.upload_panel(host, 2504); t1 = time.perf_counter()
+    print(f"upload_panel from pageable host memory ({host.nbytes / 1e9:.2f} GB)", round(t1 - t0, 4), "s", f"{host.nbytes / (t1 - t0) / 1e9:.1f} GB/s")
+del host
 idx = np.arange(rows, dtype=np.uint32)
 for _ in range(2):
     t0 = time.perf_counter(); eng.upload_sites(idx, n_ref, n_alt, 100); t1 = time.perf_counter()
