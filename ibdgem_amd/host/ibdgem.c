@@ -400,17 +400,39 @@ static void part_add_legend_line(legend_part *t, const char *l)
     }
 }
 
+/* A large plain legend is cut into byte ranges at line starts, one thread each.  Pass 1 counts the
+ * lines of every range, so pass 2 can write its rows straight into their final places; the strings go
+ * to an arena per thread, and once all sizes are known every thread copies its arena into the common
+ * one and shifts the offsets of its own rows.  Small or gzip files go line by line. */
 typedef struct {
     const char *base;
     size_t a, b;
-    legend_part part;
+    size_t lines;               /* pass 1 */
+    size_t first;               /* pass 2: index of the range's first row */
+    legend_part part;           /* .rows unused here: rows are written in place */
+    size_t arena_base;          /* pass 3 */
 } legend_range;
 
-static void *legend_worker(void *arg)
+static void *legend_count(void *arg)
+{
+    legend_range *j = arg;
+    size_t n = 0;
+    for (const char *p = j->base + j->a, *e = j->base + j->b; p < e;) {
+        const char *nl = memchr(p, '\n', (size_t)(e - p));
+        ++n;
+        if (!nl)
+            break;
+        p = nl + 1;
+    }
+    j->lines = n;
+    return NULL;
+}
+
+static void *legend_parse(void *arg)
 {
     legend_range *j = arg;
     char *buf = NULL;
-    size_t cap = 0;
+    size_t cap = 0, n = j->first;
     for (size_t p = j->a; p < j->b;) {
         const char *nl = memchr(j->base + p, '\n', j->b - p);
         const size_t len = nl ? (size_t)(nl - (j->base + p)) + 1 : j->b - p;
@@ -420,15 +442,50 @@ static void *legend_worker(void *arg)
         }
         memcpy(buf, j->base + p, len);
         buf[len] = 0;
-        part_add_legend_line(&j->part, buf);
+        row_t *r = &rows[n++];
+        memset(r, 0, sizeof *r);
+        char id[129], ref[129], alt[129];
+        if (sscanf(buf, "%128s %lu %128s %128s", id, &r->pos, ref, alt) == 4) {
+            r->legend_ok = 1;
+            r->id_off = part_arena_add(&j->part, id);
+            r->ref_off = part_arena_add(&j->part, ref);
+            r->alt_off = part_arena_add(&j->part, alt);
+        }
         p += len;
     }
     free(buf);
     return NULL;
 }
 
-/* A large plain legend is cut into byte ranges at line starts, one thread each; rows and strings are
- * joined in file order (arena offsets shifted).  Small or gzip files go line by line. */
+static void *legend_place(void *arg)
+{
+    legend_range *j = arg;
+    if (j->part.arena_len)
+        memcpy(arena + j->arena_base, j->part.arena, j->part.arena_len);
+    free(j->part.arena);
+    const uint32_t shift = (uint32_t)j->arena_base;
+    for (size_t i = j->first; i < j->first + j->lines; ++i)
+        if (rows[i].legend_ok) {
+            rows[i].id_off += shift;
+            rows[i].ref_off += shift;
+            rows[i].alt_off += shift;
+        }
+    return NULL;
+}
+
+static void team_run(void *(*fn)(void *), legend_range *rg, int T)
+{
+    pthread_t th[64];
+    for (int t = 0; t < T; ++t)
+        if (pthread_create(&th[t], NULL, fn, &rg[t]) != 0) {
+            fn(&rg[t]);
+            th[t] = pthread_self();
+        }
+    for (int t = 0; t < T; ++t)
+        if (!pthread_equal(th[t], pthread_self()))
+            pthread_join(th[t], NULL);
+}
+
 static void *read_legend(void *arg)
 {
     legend_job *j = arg;
@@ -437,53 +494,37 @@ static void *read_legend(void *arg)
     if (base && size >= ls_mt_min_bytes()) {
         const char *nl = memchr(base, '\n', size);              /* legend header (src/ibdgem.c:555) */
         const size_t from = nl ? (size_t)(nl - base) + 1 : size;
-        int T = j->threads > 64 ? 64 : j->threads;
+        const int T = j->threads > 64 ? 64 : j->threads;
         size_t cut[65];
         legend_range rg[64];
-        pthread_t th[64];
         ls_split_lines(base, size, from, T, cut);
         for (int t = 0; t < T; ++t) {
             memset(&rg[t], 0, sizeof rg[t]);
             rg[t].base = base;
             rg[t].a = cut[t];
             rg[t].b = cut[t + 1];
-            if (pthread_create(&th[t], NULL, legend_worker, &rg[t]) != 0) {
-                legend_worker(&rg[t]);
-                th[t] = pthread_self();
-            }
         }
-        size_t total = 0, atotal = 0;
+        team_run(legend_count, rg, T);
+        size_t total = 0;
         for (int t = 0; t < T; ++t) {
-            if (!pthread_equal(th[t], pthread_self()))
-                pthread_join(th[t], NULL);
-            total += rg[t].part.n;
-            atotal += rg[t].part.arena_len;
+            rg[t].first = total;
+            total += rg[t].lines;
         }
         rows = realloc(rows, (total ? total : 1) * sizeof *rows);
-        if (arena_len + atotal > arena_cap) {
-            arena_cap = arena_len + atotal;
-            arena = realloc(arena, arena_cap ? arena_cap : 1);
-        }
-        size_t n = 0;
+        team_run(legend_parse, rg, T);
+        size_t atotal = arena_len;
         for (int t = 0; t < T; ++t) {
-            const uint32_t shift = (uint32_t)arena_len;
-            if (rg[t].part.arena_len)
-                memcpy(arena + arena_len, rg[t].part.arena, rg[t].part.arena_len);
-            arena_len += rg[t].part.arena_len;
-            for (size_t i = 0; i < rg[t].part.n; ++i) {
-                row_t r = rg[t].part.rows[i];
-                if (r.legend_ok) {
-                    r.id_off += shift;
-                    r.ref_off += shift;
-                    r.alt_off += shift;
-                }
-                rows[n++] = r;
-            }
-            free(rg[t].part.rows);
-            free(rg[t].part.arena);
+            rg[t].arena_base = atotal;
+            atotal += rg[t].part.arena_len;
         }
+        if (atotal > arena_cap) {
+            arena_cap = atotal;
+            arena = realloc(arena, arena_cap);
+        }
+        arena_len = atotal;
+        team_run(legend_place, rg, T);
         ls_unmap(base, size);
-        j->n = n;
+        j->n = total;
         return NULL;
     }
     ls_unmap(base, size);
