@@ -480,6 +480,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-program clocks (warm_e2e, cold_e2e)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up and timed steps only (no recount / engine-clock / upload / host legs): the command to put under "
+                         "rocprofv3 --kernel-trace --stats, so that the per-kernel averages are those of the timed steps")
     ap.add_argument("--cold-rows", type=int, default=400_000, help="rows of .hap text for the cold end-to-end clock")
     ap.add_argument("--variant", type=int, default=None, help="ld_variant option of the engine")
     ap.add_argument("--cpw", type=int, default=None)
@@ -585,6 +588,17 @@ def main():
     ms_all = [eng.run_ms(b) for b in range(min(args.steps, 32))]
     ms_ld = [m["ld"] for m in ms_all]
 
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "SNP-sites/sec in --LD mode, chr1, 2504-indiv panel", "value": n_cov / (dt / args.steps),
+                              "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
+                              "note": "--timed-only: this rank's clock, no other legs"}))
+        eng.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # the step with the alt alleles recounted inside it (K0 in the timed region; reported beside `value`): queued
     # back to back like the timed steps
     eng.set_option("count_in_run", 1)
