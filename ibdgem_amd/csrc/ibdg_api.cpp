@@ -585,6 +585,40 @@ int ibdg_pdg_table(double epsilon, unsigned max_cov, double *out)
     return 0;
 }
 
+// src/ibd-math.c:84-101 in k_site's operation order
+double ibdg_pdg_ibd0(double f, double p00, double p01, double p11)
+{
+    if (p00 == 1 || p01 == 1 || p11 == 1)
+        return 1.0;
+    const double omf = 1 - f;
+    const double t1 = libm_pow(omf, 2.0) * p00;
+    const double t2 = ((2 * omf) * f) * p01;
+    const double t3 = libm_pow(f, 2.0) * p11;
+    double v = (t1 + t2) + t3;
+    if (v == 0.0)
+        v = DBL_MIN;
+    return v;
+}
+
+// src/ibd-math.c:104-142
+double ibdg_pdg_ibd1(unsigned a0, unsigned a1, double f, double p00, double p01, double p11)
+{
+    if (a0 > 1 || a1 > 1)
+        return 1.0;                         // no branch of the reference's switch is taken
+    const double omf = 1 - f;
+    const unsigned g = a0 + a1;
+    double v;
+    if (g == 0)
+        v = (f * p01) + (omf * p00);
+    else if (g == 1)
+        v = ((0.5 * p01) + ((0.5 * omf) * p00)) + ((0.5 * f) * p11);
+    else
+        v = (omf * p01) + (f * p11);
+    if (v == 0.0)
+        v = DBL_MIN;
+    return v;
+}
+
 ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
 {
     g_create_error.clear();

@@ -21,6 +21,8 @@ SYMBOLS = {
     "ibdg_destroy": (None, [_P]),
     "ibdg_last_error": (C.c_char_p, [_P]),
     "ibdg_pdg_table": (C.c_int, [C.c_double, C.c_uint, _P]),
+    "ibdg_pdg_ibd0": (C.c_double, [C.c_double] * 4),
+    "ibdg_pdg_ibd1": (C.c_double, [C.c_uint, C.c_uint] + [C.c_double] * 4),
     "ibdg_row_words": (C.c_size_t, [C.c_uint]),
     "ibdg_pack_alleles": (None, [_P, C.c_uint, _P]),
     "ibdg_pack_hap_text": (C.c_int, [C.c_char_p, C.c_uint, _P]),

@@ -61,6 +61,15 @@ const char *ibdg_last_error(const ibdg_ctx *ctx);
  * (src/ibd-math.c:46-81).  out holds (max_cov+1)^2*3 doubles. */
 int ibdg_pdg_table(double epsilon, unsigned max_cov, double *out);
 
+/* Host-side twins of find_pDgf and find_pDgIBD1 (src/ibd-math.h:40-63, src/ibd-math.c:84-142) for one
+ * row: P(D|IBD0) and P(D|IBD1) from the allele frequency f, the three P(D|G) of the row (a row of
+ * ibdg_pdg_table) and, for IBD1, the comparison individual's two alleles (0/1; anything else leaves the
+ * value at 1.0 like the reference).  Same operations in the same order as the device kernel (libm pow,
+ * no fused multiply-add, zero -> DBL_MIN), so they return the bits ibdg_get_site_ll returns.  For spot
+ * checks and bindings that want single values; the engine itself never computes on the host. */
+double ibdg_pdg_ibd0(double f, double p00, double p01, double p11);
+double ibdg_pdg_ibd1(unsigned a0, unsigned a1, double f, double p00, double p01, double p11);
+
 /* ---- phased panel (the .hap rows / VCF GT columns) ---------------------- */
 
 /* A packed row is ibdg_row_words(n_ids) 64-bit words: for individual n,

@@ -114,3 +114,25 @@ def test_create_fails_loudly_without_a_device():
 def test_missing_library_is_an_error(tmp_path):
     with pytest.raises(E.EngineError, match="no CPU fallback"):
         E.load_library(str(tmp_path / "nope.so"))
+
+
+def test_ibd0_ibd1_twins_match_the_oracle_and_the_reference_grid_bitwise(oracle):
+    """ibdg_pdg_ibd0 / ibdg_pdg_ibd1 = find_pDgf / find_pDgIBD1 (src/ibd-math.c:84-142): the oracle's
+    values (itself pinned to the reference's own calls over the grid, tests/test_oracle_golden.py) bit
+    for bit over read counts x genotypes x frequencies, the untouched 1.0 for alleles other than 0/1, the
+    r+a=0 short cut and the DBL_MIN clamp."""
+    lib = E.load_library()
+    C = oracle.lib
+    fs = [0.0, 1e-3, 0.0137, 0.25, 1 / 3, 0.5, 0.731, 0.999, 1.0, 3 / 5008, 2504 / 5008]
+    for eps, M in ((0.02, 20), (1e-3, 8), (0.3, 5)):
+        for r in range(0, M + 1, max(1, M // 6)):
+            for a in range(0, M + 1 - r, max(1, M // 6)):
+                p = oracle.pdg(eps, M, r, a)
+                for f in fs:
+                    assert lib.ibdg_pdg_ibd0(f, *p).hex() == C.orc_pDgf(f, *p).hex(), (eps, r, a, f)
+                    for a0, a1 in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (0, 7)):
+                        assert lib.ibdg_pdg_ibd1(a0, a1, f, *p).hex() == C.orc_pDgIBD1(a0, a1, f, *p).hex()
+    assert lib.ibdg_pdg_ibd0(0.3, 1.0, 1.0, 1.0) == 1.0
+    assert lib.ibdg_pdg_ibd0(0.3, 0.0, 0.0, 0.0) == 2.2250738585072014e-308
+    assert lib.ibdg_pdg_ibd1(1, 1, 1.0, 0.0, 0.0, 0.0) == 2.2250738585072014e-308
+    assert lib.ibdg_pdg_ibd1(3, 0, 0.3, 0.1, 0.2, 0.3) == 1.0

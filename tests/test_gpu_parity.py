@@ -694,3 +694,27 @@ def test_alt_counts_for_every_row_layout(N, L):
         eng.run([0], ld=False)
         assert (eng.alt_counts(0, L) == want).all()
         assert_bits(eng.site_af(), want / float(2 * N), "AF")
+
+
+def test_host_twins_return_the_device_bits():
+    """ibdg_pdg_ibd0 / ibdg_pdg_ibd1 on the host (with ibdg_pdg_table and the alt counts) give, row by row,
+    the doubles k_site wrote on the device."""
+    N, L = 77, 400
+    alle, nr, na = synth(91, L, N)
+    lib = E.load_library()
+    tab = np.empty((21, 21, 3), dtype=np.float64)
+    assert lib.ibdg_pdg_table(0.02, 20, tab.ctypes.data) == 0
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(None, nr, na, 100)
+        eng.run([13], ld=False)
+        site, af = eng.site_ll(0), eng.site_af()
+        counts = eng.alt_counts(0, L)
+    for s in range(L):
+        f = float(counts[s]) / float(2 * N)
+        assert f.hex() == float(af[s]).hex()
+        p = [float(x) for x in tab[nr[s], na[s]]]
+        a0, a1 = int(alle[s, 26]), int(alle[s, 27])
+        assert lib.ibdg_pdg_ibd0(f, *p).hex() == float(site[s, 0]).hex(), s
+        assert lib.ibdg_pdg_ibd1(a0, a1, f, *p).hex() == float(site[s, 1]).hex(), s
+        assert p[a0 + a1] == site[s, 2]
