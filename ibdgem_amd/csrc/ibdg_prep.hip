@@ -23,7 +23,9 @@ namespace ibdg {
 namespace {
 
 constexpr int PREP_THREADS = 256;
-constexpr int PREP_ITEMS = 16;                       // rows of 256 consecutive elements per block
+constexpr int PREP_ITEMS = 4;                        // rows of 256 consecutive elements per block: few, so that many
+                                                     // waves are in flight -- these kernels wait on memory, and a
+                                                     // wave's rows are processed one after the other
 constexpr int PREP_BLOCK = PREP_THREADS * PREP_ITEMS;
 
 // exclusive prefix over the 64 lanes of a wave; *total = the wave's sum (all lanes)
@@ -50,7 +52,7 @@ __device__ __forceinline__ uint32_t block_count(size_t base, size_t n, F flag_of
 {
     __shared__ uint32_t wave_cnt[PREP_THREADS / 64];
     uint32_t cnt = 0;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < PREP_ITEMS; ++i) {
         const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
         const bool f = e < n && flag_of(e);
@@ -84,12 +86,13 @@ __device__ __forceinline__ void block_scatter(size_t base, size_t n, uint32_t bl
             pre[i * NW + wave] = (uint32_t)__popcll(ballots[i]);
     }
     __syncthreads();
-    if (wave == 0) {                                   // PREP_ITEMS * NW == 64 entries: one wave scans them
-        static_assert(PREP_ITEMS * NW == 64, "one wave scans the per-(row, wave) totals");
+    if (wave == 0) {                                   // at most 64 entries: one wave scans them
+        static_assert(PREP_ITEMS * NW <= 64, "one wave scans the per-(row, wave) totals");
         uint32_t tot;
-        const uint32_t v = pre[lane];
+        const uint32_t v = lane < PREP_ITEMS * NW ? pre[lane] : 0u;
         const uint32_t x = wave_excl_scan(v, &tot);
-        pre[lane] = x;
+        if (lane < PREP_ITEMS * NW)
+            pre[lane] = x;
     }
     __syncthreads();
 #pragma unroll
@@ -225,18 +228,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint3
         block_cnt[blockIdx.x] = tot;
 }
 
-// Segment masks, row-parallel: every covered row is a lane; the lanes of a segment (consecutive rows, at
-// most 32) OR their bits together with a segmented scan over the wave (six shuffle steps per weight
-// plane, only planes some lane of the wave has), and the last lane of each piece adds it to the
-// segment's words in memory with atomicOr -- a segment cut by a wave boundary is simply two pieces.
-// segs[] is zeroed beforehand.  The first row of a segment writes tile and window, its last row the
-// end-of-window mark.
+// Segment masks, row-parallel: every covered row is a lane.  The lanes of a wave (64 consecutive covered
+// rows) OR their bits into a wave-private LDS table of [piece][weight plane] words -- a piece = the rows of
+// one segment that fall into this wave's 64, so at most 64 pieces -- with ds_or (LDS atomics; a segment's
+// ~20 rows hit the same word, which the LDS serialises in a few tens of cycles), then one lane per piece
+// adds the piece's non-zero words to the segment in memory with atomicOr: a segment cut by a wave boundary
+// is simply two pieces.  segs[] is zeroed beforehand.  The first row of a segment writes tile and window,
+// its last row the end-of-window mark.
 __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const uint32_t *__restrict__ block_off,
                                                                  Seg *__restrict__ segs, uint32_t seg_cap,
                                                                  WinConst *__restrict__ wconst)
 {
     constexpr int NW = PREP_THREADS / 64;
     __shared__ uint32_t pre[PREP_ITEMS * NW];
+    __shared__ __attribute__((aligned(16))) uint32_t tbl[NW][64][16];
     const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pass 1: segment starts per (item, wave) -> exclusive prefix (the same ranks k_prep_seg_count counted)
@@ -250,11 +255,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
     __syncthreads();
     if (wave == 0) {
         uint32_t tot;
-        const uint32_t v = pre[lane];
-        pre[lane] = wave_excl_scan(v, &tot);
+        const uint32_t v = lane < PREP_ITEMS * NW ? pre[lane] : 0u;
+        const uint32_t x = wave_excl_scan(v, &tot);
+        if (lane < PREP_ITEMS * NW)
+            pre[lane] = x;
     }
     __syncthreads();
     const uint32_t boff = block_off[blockIdx.x];
+    uint4 *my_row = reinterpret_cast<uint4 *>(&tbl[wave][lane][0]);
 #pragma unroll 1
     for (int i = 0; i < PREP_ITEMS; ++i) {
         const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
@@ -262,10 +270,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
         if (!__any(live))
             break;
         const uint64_t starts = __ballot(live && seg_start(in, j));
-        // segment of this row: starts up to and including this lane, minus one (0xffffffff before the first
-        // segment of everything cannot happen: row 0 starts a window)
-        const uint32_t incl = (uint32_t)__popcll(starts & ((2ull << lane) - 1));
-        const uint32_t seg = boff + pre[i * NW + wave] + incl - 1;
+        // piece of this row within the wave: pieces are numbered from 0; when lane 0 does not start a
+        // segment, piece 0 is the tail of a segment that began in an earlier wave
+        const uint32_t lead = (uint32_t)(~starts & 1);                       // 1: there is such a tail
+        const uint32_t piece = (uint32_t)__popcll(starts & ((2ull << lane) - 1)) - 1 + lead;
+        const uint32_t n_pieces = (uint32_t)__popcll(starts) + lead;
+        // global segment of piece q: the segments that start in this wave follow those counted before it
+        const uint32_t seg0 = boff + pre[i * NW + wave] - lead;               // segment of piece 0
+        const uint32_t seg = seg0 + piece;
         uint32_t row = 0, cv = 0, al = 0;
         if (live) {
             const uint2 rc = in.rec_cov[j];
@@ -274,45 +286,45 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
             al = idx - r * in.d;
             cv = r + al;
         }
-        const uint32_t bit = live ? 1u << (row & 31) : 0u;
-        // first lane of this lane's piece: the nearest start at or below it, else lane 0
-        const uint64_t below = starts & ((2ull << lane) - 1);
-        const unsigned first = below ? 63u - (unsigned)__clzll((long long)below) : 0u;
-        // last lane of a piece: the next lane starts a segment, or the wave / the rows end
-        const bool piece_end = live && (lane == 63 || ((starts >> (lane + 1)) & 1) || j + 1 >= in.n_cov);
         const bool is_start = (starts >> lane) & 1;
         if (live && seg < seg_cap) {
             if (is_start) {
                 segs[seg].tile = row >> 5;
                 segs[seg].win = (uint32_t)(j / in.window);
-                if (j % in.window == 0)
-                    wconst[j / in.window].seg_begin = seg;
             }
-            // the segment's final row: the next row starts another one (known here only through the next row)
-            const bool seg_end = j + 1 >= in.n_cov || seg_start(in, j + 1);
-            if (seg_end)
+            // the segment's final row: the next row starts another one
+            if (j + 1 >= in.n_cov || seg_start(in, j + 1))
                 segs[seg].last = (j + 1 >= in.n_cov || (j + 1) % in.window == 0) ? 1u : 0u;
-        } else if (live && is_start && j % in.window == 0) {
+        }
+        if (live && is_start && j % in.window == 0)
             wconst[j / in.window].seg_begin = seg;
-        }
-        const uint32_t planes = cv | (al << 8);
-        uint32_t any_planes = planes;                  // planes some lane of the wave has
+        // the wave's table: clear, OR, read back (a wave's LDS operations execute in order)
+        my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            const uint32_t bit = 1u << (row & 31);
+            uint32_t *t = &tbl[wave][piece][0];
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1)
-            any_planes |= __shfl_xor(any_planes, m);
-        for (int k = 0; k < 16; ++k) {
-            if (!((any_planes >> k) & 1))
-                continue;                              // wave-uniform
-            uint32_t v = ((planes >> k) & 1) ? bit : 0u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {         // segmented inclusive OR-scan
-                const uint32_t u = __shfl_up(v, d);
-                if (lane >= first + (unsigned)d)
-                    v |= u;
+            for (int k = 0; k < 8; ++k) {
+                if ((cv >> k) & 1) atomicOr(&t[k], bit);
+                if ((al >> k) & 1) atomicOr(&t[8 + k], bit);
             }
-            if (piece_end && v && seg < seg_cap)
-                atomicOr(k < 8 ? &segs[seg].cov[k] : &segs[seg].alt[k - 8], v);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_pieces && seg0 + lane < seg_cap) {
+            Seg *sg = &segs[seg0 + lane];
+            const uint4 *src = reinterpret_cast<const uint4 *>(&tbl[wave][lane][0]);
+            const uint4 c0 = src[0], c1 = src[1], a0 = src[2], a1 = src[3];
+            const uint32_t w[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (w[k])
+                    atomicOr(k < 8 ? &sg->cov[k] : &sg->alt[k - 8], w[k]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -369,15 +381,27 @@ __global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win,
     K.m = 1ull << 63;                  // 1.0 = 0.5 * 2^1
     K.e = 1;
     uint32_t ct = 0, at = 0;
-    for (uint32_t j = (uint32_t)b; j < e; ++j) {
-        const uint32_t idx = in.rec_cov[j].y / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
-        ct += cv;
-        at += a;
-        const uint64_t c = nck[(size_t)cv * in.d + r];
-        if (c > 1) {                   // times 1 changes nothing (and c is never 0 for r <= cv)
-            const int z = __clzll((long long)c);
-            K = x87_mul(K, c << z, 64 - z);
+    // eight rows per turn: their loads (and the coefficient look-ups behind them) are independent of the
+    // product chain and go out together -- a thread's rows are 64 consecutive bytes
+    for (uint32_t j = (uint32_t)b; j < e; j += 8) {
+        uint32_t y[8];
+        uint64_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            y[u] = j + u < e ? in.rec_cov[j + u].y : 0u;      // offset 0 = no reads: coefficient 1, counts 0
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t idx = y[u] / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
+            ct += cv;
+            at += a;
+            c[u] = nck[(size_t)cv * in.d + r];
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c[u] > 1) {            // times 1 changes nothing (and c is never 0 for r <= cv)
+                const int z = __clzll((long long)c[u]);
+                K = x87_mul(K, c[u] << z, 64 - z);
+            }
     }
     raw[w].m = K.m;
     raw[w].e = K.e;
