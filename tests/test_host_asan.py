@@ -29,3 +29,23 @@ def test_host_tests_pass_under_asan_and_ubsan():
                        cwd=REPO, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_threaded_host_paths_are_race_free_under_tsan():
+    """ThreadSanitizer build of the host program: golden cases through the threaded pileup / legend readers,
+    the threaded row filter chain and the threaded .hap reader (IBDGEM_MT_MIN_BYTES=1 sends small files that
+    way), several team sizes: no report, same stdout as the plain build."""
+    import golden_io as G
+    subprocess.run(["make", "-C", os.path.join(REPO, "ibdgem_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", HOST, "ibdgem_tsan", "ibdgem"], check=True, stdout=subprocess.DEVNULL)
+    meta = G.cases("synA")
+    cwd = os.path.join(G.GOLD, "synA", "input")
+    env = dict(os.environ, IBDGEM_MT_MIN_BYTES="1", TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    for case in list(meta["cases"])[:6]:
+        for th in ("3", "8"):
+            args = meta["base_args"] + meta["cases"][case] + ["--plan", "--threads", th]
+            want = subprocess.run([os.path.join(HOST, "ibdgem")] + args, cwd=cwd, capture_output=True, text=True)
+            got = subprocess.run([os.path.join(HOST, "ibdgem_tsan")] + args, cwd=cwd, capture_output=True, text=True, env=env)
+            assert "ThreadSanitizer" not in got.stderr, got.stderr[-2000:]
+            assert got.returncode == want.returncode == 0
+            assert got.stdout == want.stdout
