@@ -58,6 +58,7 @@ static struct option longopts[] = {
     {"summary-only", no_argument, &opt_summary_only, 1},
     {"reference-order", no_argument, &opt_ref_order, 1},
     {"rand-stream", required_argument, 0, 1000},
+    {"fmt-check", required_argument, 0, 1005},
     {"devices", required_argument, 0, 1001},
     {"threads", required_argument, 0, 1002},
     {"panel-cache", required_argument, 0, 1003},
@@ -776,11 +777,175 @@ static void print_ll(FILE *fp, double v, char sep)
  * comparison individual.  Here the rows are cut into contiguous ranges, every thread formats its
  * range into a buffer of its own with the same conversions (%lf, %e, %u, %lu through snprintf, so
  * the text is what printf would have written), and the buffers are written in order. */
+/* ---- the reference's conversions without going through printf --------------------------------
+ * 4M rows x (three %e + one %lf + six integers) per comparison individual is where a table-writing run
+ * spends its host time.  These produce the very characters printf produces -- printf rounds the exact
+ * binary value to nearest, ties to even -- and hand the rare case they cannot decide to sprintf:
+ *   %lf of 0 <= f < 2^40: f * 10^6 exactly in 128-bit integer arithmetic (a double is m * 2^e);
+ *   %e: a * 10^(6-E) in long double (64-bit mantissa; relative error < 2^-60 after the table product);
+ *       when the result lies within 1e-6 of a rounding boundary or of a power of ten, sprintf decides.
+ * `ibdgem --fmt-check N` compares them with sprintf on N random doubles (tests/test_host_cli.py). */
+static long double pow10_tab[700];           /* 10^(i-350) */
+static void fmt_init(void)
+{
+    static int done;
+    if (done)
+        return;
+    pow10_tab[350] = 1.0L;
+    for (int i = 1; i <= 349; ++i) {
+        pow10_tab[350 + i] = pow10_tab[350 + i - 1] * 10.0L;      /* exact up to 10^27, 1 rounding per step after */
+        pow10_tab[350 - i] = 1.0L / pow10_tab[350 + i];
+    }
+    done = 1;
+}
+
+static char *put_str(char *d, const char *s)
+{
+    const size_t n = strlen(s);
+    memcpy(d, s, n);
+    return d + n;
+}
+
+static char *put_u64(char *d, unsigned long v)
+{
+    char t[24];
+    int n = 0;
+    do {
+        t[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n)
+        *d++ = t[--n];
+    return d;
+}
+
+/* "%lf" (six decimals) */
+static char *put_lf6(char *d, double f)
+{
+    if (!(f >= 0.0) || f >= 1099511627776.0 || (f == 0.0 && signbit(f)))
+        return d + sprintf(d, "%lf", f);
+    int e;
+    const double m = frexp(f, &e);                         /* f = m * 2^e, 0.5 <= m < 1 */
+    const uint64_t mi = (uint64_t)ldexp(m, 53);            /* f = mi * 2^(e-53) exactly */
+    unsigned __int128 p = (unsigned __int128)mi * 1000000u;   /* < 2^73 */
+    const int sh = 53 - e;                                 /* f * 10^6 = p / 2^sh; e <= 40 -> sh >= 13 */
+    unsigned __int128 q;
+    if (f == 0.0) {
+        q = 0;
+    } else if (sh >= 127) {
+        q = 0;                                             /* below 2^-54 * 10^6: rounds to 0 (no tie: p < 2^73) */
+    } else {
+        q = p >> sh;
+        const unsigned __int128 rem = p - (q << sh), half = (unsigned __int128)1 << (sh - 1);
+        if (rem > half || (rem == half && (q & 1)))
+            q += 1;
+    }
+    const unsigned long whole = (unsigned long)(q / 1000000u);
+    unsigned long frac = (unsigned long)(q % 1000000u);
+    d = put_u64(d, whole);
+    *d++ = '.';
+    for (int k = 5; k >= 0; --k) {
+        d[k] = (char)('0' + frac % 10);
+        frac /= 10;
+    }
+    return d + 6;
+}
+
+/* "%e" (six decimals, exponent of at least two digits) */
+static char *put_e6(char *d, double v)
+{
+    if (!isfinite(v))
+        return d + sprintf(d, "%e", v);
+    if (signbit(v)) {
+        *d++ = '-';
+        v = -v;
+    }
+    if (v == 0.0) {
+        memcpy(d, "0.000000e+00", 12);
+        return d + 12;
+    }
+    int e2;
+    (void)frexp(v, &e2);
+    int E = (int)floor((e2 - 1) * 0.30102999566398120);    /* floor(log10(2^(e2-1))) <= floor(log10 v) */
+    if (E < -340 || E > 320)
+        return d + sprintf(d, "%e", v);
+    long double q = (long double)v * pow10_tab[350 + 6 - E];
+    if (q >= 1e7L) {                                       /* the estimate can be one low */
+        ++E;
+        q = (long double)v * pow10_tab[350 + 6 - E];
+    }
+    /* q in [10^6, 10^7): seven digits.  Too close to a boundary to trust the last bits of q: printf decides. */
+    const long double fl = floorl(q), fr = q - fl;
+    if (!(q >= 1e6L + 1e-5L) || !(q < 1e7L - 1e-5L) || (fr > 0.5L - 1e-6L && fr < 0.5L + 1e-6L))
+        return d + sprintf(d, "%e", v);
+    unsigned long D = (unsigned long)fl + (fr > 0.5L ? 1u : 0u);
+    if (D >= 10000000ul) {
+        D /= 10;
+        ++E;
+    }
+    char t[8];
+    for (int k = 6; k >= 0; --k) {
+        t[k] = (char)('0' + D % 10);
+        D /= 10;
+    }
+    *d++ = t[0];
+    *d++ = '.';
+    memcpy(d, t + 1, 6);
+    d += 6;
+    *d++ = 'e';
+    *d++ = E < 0 ? '-' : '+';
+    unsigned a = (unsigned)(E < 0 ? -E : E);
+    if (a >= 100) {
+        *d++ = (char)('0' + a / 100);
+        a %= 100;
+    }
+    *d++ = (char)('0' + a / 10);
+    *d++ = (char)('0' + a % 10);
+    return d;
+}
+
 static int fmt_ll(char *dst, double v, char sep)
 {
-    int n = isnan(v) ? sprintf(dst, "-nan") : sprintf(dst, "%e", v);   /* "-nan": x86 printf for 0/0 */
-    dst[n] = sep;
-    return n + 1;
+    char *d = isnan(v) ? put_str(dst, "-nan") : put_e6(dst, v);        /* "-nan": x86 printf for 0/0 */
+    *d++ = sep;
+    return (int)(d - dst);
+}
+
+/* --fmt-check N: put_e6 / put_lf6 against sprintf on N random doubles (several distributions); prints the
+ * number of differences (0 expected) and how many values took the sprintf way out */
+static int fmt_check(long n)
+{
+    fmt_init();
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    long bad = 0, shown = 0;
+    char a[400], b[400];
+    for (long i = 0; i < n; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        double v;
+        switch (i % 6) {
+        case 0: { uint64_t bits = x; memcpy(&v, &bits, 8); break; }                       /* any bit pattern */
+        case 1: v = (double)(x >> 11) / 9007199254740992.0; break;                         /* [0,1) */
+        case 2: v = ldexp((double)(x >> 11) / 9007199254740992.0, -(int)(x % 1070)); break; /* likelihood-like */
+        case 3: v = (double)(x % 20000001) / 1e7 * pow(10.0, (int)(x >> 40) % 40 - 20); break; /* short decimals */
+        case 4: v = (double)(x % 2000001) / 128.0 / 15625.0; break;                         /* %lf ties: k/2^7 scaled */
+        default: v = (double)((x >> 20) % 5009) / 5008.0; break;                           /* allele frequencies */
+        }
+        if (isnan(v))
+            continue;
+        *put_e6(a, v) = 0;
+        sprintf(b, "%e", v);
+        int diff = strcmp(a, b) != 0;
+        *put_lf6(a, v) = 0;
+        sprintf(b, "%lf", v);
+        diff |= strcmp(a, b) != 0;
+        if (diff) {
+            ++bad;
+            if (shown++ < 5)
+                printf("DIFF %a: %s vs %s\n", v, a, b);
+        }
+    }
+    printf("fmt-check: %ld values, %ld differences\n", n, bad);
+    return bad != 0;
 }
 
 /* a row that passed the target-independent part of the filter chain */
@@ -827,9 +992,18 @@ static void *fmt_rows(void *arg)
             j->cap = nc;
         }
         char *d = j->buf + j->len;
-        d += sprintf(d, "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u", chr, id, R->pos, ref, alt, f, (unsigned)pl->cov,
-                     (unsigned)j->s_nr[i], (unsigned)j->s_na[i], row_allele(c->row, j->tgt, 0),
-                     row_allele(c->row, j->tgt, 1));
+        /* "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u" (src/ibdgem.c:731-733) */
+        d = put_str(d, chr); *d++ = '\t';
+        d = put_str(d, id); *d++ = '\t';
+        d = put_u64(d, R->pos); *d++ = '\t';
+        d = put_str(d, ref); *d++ = '\t';
+        d = put_str(d, alt); *d++ = '\t';
+        d = put_lf6(d, f); *d++ = '\t';
+        d = put_u64(d, pl->cov); *d++ = '\t';
+        d = put_u64(d, j->s_nr[i]); *d++ = '\t';
+        d = put_u64(d, j->s_na[i]); *d++ = '\t';
+        d = put_u64(d, row_allele(c->row, j->tgt, 0)); *d++ = '\t';
+        d = put_u64(d, row_allele(c->row, j->tgt, 1));
         if (j->plan) {
             *d++ = '\n';
         } else {
@@ -1073,6 +1247,7 @@ int main(int argc, char **argv)
 {
     const clock_t t_start = clock();
     phase("start");
+    fmt_init();
     const char *hap_fn = NULL, *legend_fn = NULL, *indv_fn = NULL, *pu_fn = NULL, *vcf_fn = NULL;
     const char *sample_fn = NULL, *sample_csv = NULL, *bg_fn = NULL, *af_fn = NULL, *pos_fn = NULL;
     const char *uchr = NULL, *out_dir = NULL, *devices_arg = "0";
@@ -1111,6 +1286,7 @@ int main(int argc, char **argv)
         case 1002: opt_threads = atoi(optarg); break;
         case 1003: cache_fn = optarg; break;
         case 1004: dump_panel_fn = optarg; break;   /* test hook: the packed rows + clean flags as a binary file */
+        case 1005: exit(fmt_check(atol(optarg)));   /* test hook: the number conversions against printf */
         case 1000:                                  /* test hook: the first N values of the read-thinning stream */
             for (long i = atol(optarg); i > 0; --i)
                 printf("%d\n", glibc_rand());

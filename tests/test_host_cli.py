@@ -398,3 +398,13 @@ def test_threaded_pileup_reader_on_messy_lines(tmp_path):
         assert got.returncode == want.returncode
         assert got.stdout == want.stdout and strip(got.stderr) == strip(want.stderr)
     assert "Problem parsing garbage" in want.stderr and "Cannot parse ? in reads field" in want.stderr
+
+
+def test_number_conversions_equal_printf():
+    """The per-site table is written with the program's own %e / %lf conversions (long double / 128-bit integer
+    arithmetic, sprintf for whatever falls within 1e-6 of a rounding boundary): against sprintf on two million
+    random doubles -- raw bit patterns, [0,1), likelihood-like magnitudes down to 1e-322, short decimals, %lf ties
+    (k/2^7), allele frequencies -- there must be no difference."""
+    r = subprocess.run([_exe(), "--fmt-check", "2000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-500:]
+    assert "2000000 values, 0 differences" in r.stdout
