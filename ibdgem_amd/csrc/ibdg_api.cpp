@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -138,6 +139,12 @@ struct ibdg_ctx {
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
+    long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
+    // page-locked staging for large panels from pageable memory (staged_upload)
+    static constexpr int STAGE_WORKERS = 8;
+    static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+    void *stage[2 * STAGE_WORKERS] = {};
+    hipEvent_t stage_ev[2 * STAGE_WORKERS] = {};
 };
 
 namespace {
@@ -368,6 +375,84 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
     return 0;
 }
 
+// A large panel in ordinary (pageable) host memory: a team of host threads copies it piece by piece into
+// page-locked staging buffers (two per thread) and every piece goes to the device by DMA as soon as it is
+// staged.  The runtime's own path for pageable memory locks the caller's pages chunk by chunk, which is quick
+// for memory in huge pages (46 GB/s for a fresh anonymous allocation) and slow for 4 KiB pages -- a mapped
+// file from the page cache, the host program's packed-panel cache: 0.18-0.28 s for 2.56 GB.
+struct StageJob {
+    ibdg_ctx *c;
+    const char *src;
+    size_t rw, dw, n_rows, rows_per_piece;
+    int worker, n_workers;
+    hipError_t err = hipSuccess;
+};
+
+void stage_worker(StageJob *j)
+{
+    ibdg_ctx *c = j->c;
+    if ((j->err = hipSetDevice(c->device)) != hipSuccess)
+        return;
+    const size_t n_pieces = (j->n_rows + j->rows_per_piece - 1) / j->rows_per_piece;
+    int turn = 0;
+    for (size_t p = (size_t)j->worker; p < n_pieces; p += (size_t)j->n_workers, turn ^= 1) {
+        const int b = 2 * j->worker + turn;
+        const size_t r0 = p * j->rows_per_piece, nr = std::min(j->rows_per_piece, j->n_rows - r0);
+        if ((j->err = hipEventSynchronize(c->stage_ev[b])) != hipSuccess)     // the buffer's previous piece has left
+            return;
+        memcpy(c->stage[b], j->src + r0 * j->rw, nr * j->rw);
+        j->err = hipMemcpy2DAsync((char *)c->panel.p + r0 * j->dw, j->dw, c->stage[b], j->rw, j->rw, nr,
+                                  hipMemcpyHostToDevice, c->stream);
+        if (j->err == hipSuccess)
+            j->err = hipEventRecord(c->stage_ev[b], c->stream);
+        if (j->err != hipSuccess)
+            return;
+    }
+}
+
+int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t dw)
+{
+    int T = (int)std::min<unsigned>(ibdg_ctx::STAGE_WORKERS, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t rows_per_piece = std::max<size_t>(1, ibdg_ctx::STAGE_BYTES / rw);
+    for (int b = 0; b < 2 * T; ++b) {
+        if (!c->stage[b])
+            HIP_TRY(c, hipHostMalloc(&c->stage[b], ibdg_ctx::STAGE_BYTES, hipHostMallocDefault));
+        if (!c->stage_ev[b]) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[b], hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->stage_ev[b], c->stream));       // "free" from the start
+        }
+    }
+    std::vector<StageJob> jobs((size_t)T);
+    std::vector<std::thread> th;
+    for (int w = 0; w < T; ++w) {
+        jobs[(size_t)w].c = c;
+        jobs[(size_t)w].src = (const char *)src;
+        jobs[(size_t)w].rw = rw;
+        jobs[(size_t)w].dw = dw;
+        jobs[(size_t)w].n_rows = n_rows;
+        jobs[(size_t)w].rows_per_piece = rows_per_piece;
+        jobs[(size_t)w].worker = w;
+        jobs[(size_t)w].n_workers = T;
+        th.emplace_back(stage_worker, &jobs[(size_t)w]);
+    }
+    for (auto &t : th)
+        t.join();
+    for (const StageJob &j : jobs)
+        if (j.err != hipSuccess)
+            return fail(c, "[::] ERROR in ibdg_upload_panel: staged copy: %s", hipGetErrorString(j.err));
+    return 0;
+}
+
+bool is_plain_host_memory(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();          // unknown to the runtime: ordinary memory
+        return true;
+    }
+    return a.type == hipMemoryTypeUnregistered;
+}
+
 int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
 {
     const size_t rw = ibdg_row_words(c->n_ids) * 8, dw = (size_t)c->stride * 8;
@@ -375,7 +460,13 @@ int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
         return 0;
     if (rw != dw)
         HIP_TRY(c, hipMemsetAsync(c->panel.p, 0, n_rows * dw, c->stream));
-    HIP_TRY(c, hipMemcpy2DAsync(c->panel.p, dw, src, rw, rw, n_rows, kind, c->stream));
+    if (kind == hipMemcpyHostToDevice && n_rows * rw >= ((size_t)256 << 20) && c->opt_staged_upload &&
+        is_plain_host_memory(src)) {
+        if (staged_upload(c, src, n_rows, rw, dw))
+            return 1;
+    } else {
+        HIP_TRY(c, hipMemcpy2DAsync(c->panel.p, dw, src, rw, rw, n_rows, kind, c->stream));
+    }
     if (!c->opt_count_in_run) {
         ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, n_rows, (uint32_t *)c->alt_count.p,
                                c->stream);
@@ -708,6 +799,12 @@ void ibdg_destroy(ibdg_ctx *c)
     for (hipEvent_t ev : c->ev_up)
         if (ev)
             (void)hipEventDestroy(ev);
+    for (int b = 0; b < 2 * ibdg_ctx::STAGE_WORKERS; ++b) {
+        if (c->stage_ev[b])
+            (void)hipEventDestroy(c->stage_ev[b]);
+        if (c->stage[b])
+            (void)hipHostFree(c->stage[b]);
+    }
     if (c->info_h)
         (void)hipHostFree(c->info_h);
     for (auto &E : c->evs)
@@ -1343,6 +1440,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
+    if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");
         c->opt_cpw = value; return 0;

@@ -1429,6 +1429,7 @@ int main(int argc, char **argv)
                 DIE("%s\n", dev_job.err[d] ? dev_job.err[d] : "[::] ERROR in ibdg_create");
             if (ibdg_upload_panel(e, packed, n_rows, n_ids))      /* every GPU holds the whole panel */
                 DIE("%s\n", ibdg_last_error(e));
+            phase("panel upload (copy, alt counts, transposition)");
             if (opt_ref_order) {                                  /* background list in the -B file's order (:741) */
                 if (ibdg_set_option(e, "ld_variant", 3) || (has_B && ibdg_set_background_order(e, bg.idx, bg.n)))
                     DIE("%s\n", ibdg_last_error(e));
@@ -1439,7 +1440,7 @@ int main(int argc, char **argv)
             DIE("[::] ERROR: --devices needs at least one device index.\n");
         if (ibdg_get_alt_counts(engs[0], 0, n_rows, alt_count))
             DIE("%s\n", ibdg_last_error(engs[0]));
-        phase("device start, panel upload, alt counts");
+        phase("alt counts back to the host");
     } else {
         for (size_t r = 0; r < n_rows; ++r) {           /* --plan: same integers, on the host */
             unsigned c = 0;

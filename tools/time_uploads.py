@@ -10,9 +10,20 @@ eng = ibdgem_amd.Engine(0, 0.02, 20)
 t0 = time.perf_counter(); eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], 2504); t1 = time.perf_counter()
 print("upload_panel_dev (transpose + alt counts)", round(t1 - t0, 4), "s")
 host = panel.cpu().numpy().view(np.uint64)
-for _ in range(2):
+for staged in (0, 1, 0, 1):
+    eng.set_option("staged_upload", staged)
     t0 = time.perf_counter(); eng.upload_panel(host, 2504); t1 = time.perf_counter()
-    print(f"upload_panel from pageable host memory ({host.nbytes / 1e9:.2f} GB)", round(t1 - t0, 4), "s", f"{host.nbytes / (t1 - t0) / 1e9:.1f} GB/s")
+    print(f"upload_panel from pageable host memory ({host.nbytes / 1e9:.2f} GB), staged_upload={staged}", round(t1 - t0, 4), "s", f"{host.nbytes / (t1 - t0) / 1e9:.1f} GB/s")
+import mmap, tempfile
+with tempfile.NamedTemporaryFile(dir="/dev/shm") as fh:       # the same bytes as a mapped file (4 KiB pages from the page cache)
+    fh.write(host.tobytes()); fh.flush()
+    mm = mmap.mmap(fh.fileno(), 0, prot=mmap.PROT_READ)
+    arr = np.frombuffer(mm, dtype=np.uint64).reshape(host.shape)
+    for staged in (0, 1, 0, 1):
+        eng.set_option("staged_upload", staged)
+        t0 = time.perf_counter(); eng.upload_panel(arr, 2504); t1 = time.perf_counter()
+        print(f"upload_panel from a mapped file, staged_upload={staged}", round(t1 - t0, 4), "s", f"{host.nbytes / (t1 - t0) / 1e9:.1f} GB/s")
+    del arr; mm.close()
 del host
 idx = np.arange(rows, dtype=np.uint32)
 for _ in range(2):

@@ -1,0 +1,24 @@
+import os, sys, tempfile, subprocess, time, struct
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import bench
+rows = 4_000_000
+dev = torch.device("cuda", 0)
+panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
+words = panel.cpu().numpy().view(np.uint64)
+del panel
+exe = os.path.join(bench.REPO, "ibdgem_amd", "host", "ibdgem")
+with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+    bench.write_pileup_and_legend(d, n_ref, n_alt, 2504, rows)
+    open(os.path.join(d, "p.hap"), "w").write("placeholder\n")
+    st = os.stat(os.path.join(d, "p.hap"))
+    with open(os.path.join(d, "p.cache"), "wb") as fh:
+        hdr = struct.pack("<8sIIQQQqq", b"IBDGPNL2", 2504, 0, rows, words.shape[1], st.st_size, st.st_mtime_ns // 10**9, st.st_mtime_ns % 10**9)
+        fh.write(hdr); fh.write(np.ones(rows, np.uint8).tobytes()); fh.write(b"\0" * (-(len(hdr) + rows) % 4096)); fh.write(words.tobytes())
+    base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o", "--summary-only"]
+    os.makedirs(os.path.join(d, "o"))
+    for rep in range(3):
+        t0 = time.perf_counter()
+        r = subprocess.run(base, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1"), capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        print(f"{dt:.3f} s", " | ".join(l[8:] for l in r.stderr.splitlines() if l.startswith("## time")))
