@@ -1490,7 +1490,9 @@ int main(int argc, char **argv)
     uint32_t *s_row = io_alloc((n_cand ? n_cand : 1) * 4, pin), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
     uint8_t *s_nr = io_alloc(n_cand ? n_cand : 1, pin), *s_na = io_alloc(n_cand ? n_cand : 1, pin);
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
-    double *site_af = io_alloc((n_cand ? n_cand : 1) * 8, pin), *site_ll = io_alloc((n_cand ? n_cand : 1) * 24, pin);
+    /* the per-site values are only fetched for the per-site table: no 128 MB of page-locked memory for --summary-only */
+    const size_t n_site_out = opt_summary_only && !opt_plan ? 1 : (n_cand ? n_cand : 1);
+    double *site_af = io_alloc(n_site_out * 8, pin), *site_ll = io_alloc(n_site_out * 24, pin);
     if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("page-locked result arrays");

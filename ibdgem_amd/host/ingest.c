@@ -451,8 +451,8 @@ int ingest_hap(const char *fn, unsigned n_ids, int threads, uint64_t **packed, u
 
 /* ---- cache file --------------------------------------------------------------------------
  * header | ok flags | zero padding to a 4096-byte boundary | packed rows.  The rows are not read
- * but mapped: loading the cache costs page-table entries, not a 2.56 GB copy, and the engine's
- * host-to-device copy reads the page cache directly. */
+ * but mapped: loading the cache costs nothing up front, and the engine's host-to-device copy (a team
+ * of threads staging through page-locked buffers) reads the page cache directly. */
 #define CACHE_ALIGN 4096u
 typedef struct {
     char magic[8];               /* "IBDGPNL2" */
@@ -500,8 +500,9 @@ int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, 
                 *packed_out = malloc(8);
                 rc = *packed_out ? 0 : 1;
             } else {
-                /* MAP_POPULATE: the page-table entries for the whole file in one go instead of 600 000 faults */
-                void *m = mmap(NULL, bytes, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)off);
+                /* not MAP_POPULATE: the engine's staging team touches the pages from eight threads while it copies,
+                 * which costs nothing extra there, where populating up front took 50-60 ms on this thread */
+                void *m = mmap(NULL, bytes, PROT_READ, MAP_PRIVATE, fd, (off_t)off);
                 if (m != MAP_FAILED) {
                     *packed_out = m;           /* lives as long as the program; never freed by the caller */
                     rc = 0;

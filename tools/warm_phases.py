@@ -1,3 +1,5 @@
+"""Phase clocks of the host program on the warm 4M-row run (packed-panel cache + text -> summary file), three runs:
+    python tools/warm_phases.py   (on a GPU box)"""
 import os, sys, tempfile, subprocess, time, struct
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
