@@ -209,3 +209,37 @@ def test_config5_500_comparison_individuals_in_one_launch(chr1, oracle):
         assert not bad, bad[:5]
         assert checked == n_win
         print(f"target slot {i}: oracle on all {checked} windows, max rel {worst:.2e}")
+
+
+def test_large_panel_from_host_memory_goes_through_the_staging_team():
+    """ibdg_upload_panel of 256 MB and more from ordinary host memory is staged by a team of host threads
+    through page-locked buffers; from a mapped file (what the host program's packed-panel cache is) and from
+    an anonymous array, with the option on and off, the device must hold the same rows: alt counts of every
+    row equal numpy's, and a comparison gives the same bits."""
+    import mmap
+    import tempfile
+    N, L = 2504, 450_000                                       # 288 MB of packed rows
+    rng = np.random.default_rng(77)
+    words = rng.integers(0, 2 ** 63, size=(L, 80), dtype=np.int64).view(np.uint64)
+    words[:, 78] &= np.uint64((1 << 8) - 1)                    # individuals 2496..2503: 8 bits of the last chunk
+    words[:, 79] &= np.uint64((1 << 8) - 1)
+    want = np.unpackbits(words.view(np.uint8), axis=1).sum(axis=1, dtype=np.uint32)
+    nr = rng.integers(0, 3, size=L).astype(np.uint8)
+    na = rng.integers(0, 3, size=L).astype(np.uint8)
+    results = []
+    with tempfile.NamedTemporaryFile(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as fh:
+        fh.write(words.tobytes())
+        fh.flush()
+        mm = mmap.mmap(fh.fileno(), 0, prot=mmap.PROT_READ)
+        mapped = np.frombuffer(mm, dtype=np.uint64).reshape(L, 80)
+        with E.Engine() as eng:
+            for src, staged in ((mapped, 1), (words, 1), (words, 0), (mapped, 0)):
+                eng.set_option("staged_upload", staged)
+                eng.upload_panel(src, N)
+                assert (eng.alt_counts(0, L) == want).all()
+                eng.upload_sites(None, nr, na, 100)
+                eng.run([2500], ld=True)
+                results.append(eng.window_ll(0))
+        del mapped, src                                        # the mapping goes with its last array
+    for r in results[1:]:
+        assert (bits(r) == bits(results[0])).all()
