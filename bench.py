@@ -626,8 +626,13 @@ def main():
     eng.sync()
     dt_recount = (time.perf_counter() - t1) / n_rc
     eng.set_option("async", 0)
-    alt_ms = float(np.mean([eng.run_ms(b)["alt_count"] for b in range(min(n_rc, 32))]))
+    alt_in_run_ms = float(np.mean([eng.run_ms(b)["alt_count"] for b in range(min(n_rc, 32))]))
+    # k_alt_count alone on the chip: recount inside non-LD runs (nothing on the main stream beside it)
+    for _ in range(6):
+        eng.run(targets, ld=False)
+    alt_ms = float(np.mean([eng.run_ms(b)["alt_count"] for b in range(5)]))
     eng.set_option("count_in_run", 0)
+    eng.run(targets, ld=True)
     # the dominant kernel alone: 32 more queued steps timed through the kernel's own dispatch packet
     # (hipExtLaunchKernel start/stop events; slower per step than one event record, hence not in the
     # timed region above)
@@ -709,6 +714,9 @@ def main():
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},
             "host_queue_ms_per_step": dt_host / args.steps * 1e3,
             "alt_count_ms": alt_ms,
+            "alt_count_note": "k_alt_count alone on the chip (2.56 GB panel); inside an --LD run it is throttled to 4 single-wave "
+                              "workgroups per CU so that the --LD workgroups keep their wave slots: alt_count_in_ld_run_ms",
+            "alt_count_in_ld_run_ms": alt_in_run_ms,
             "upload_sites_ms": up["pageable_ms"],
             "upload_sites": up,
             "engine_clock": engine_clock,

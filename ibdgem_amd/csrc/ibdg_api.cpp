@@ -139,6 +139,8 @@ struct ibdg_ctx {
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
+    long opt_recount_blocks = 4;     // single-wave workgroups per CU of k_alt_count when it runs inside an --LD run
+                                     // (0 = the full grid; 4 measured best: tools/recount_sweep.py)
     long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
     // page-locked staging for large panels from pageable memory (staged_upload)
     static constexpr int STAGE_WORKERS = 8;
@@ -1317,8 +1319,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // stream2, queued after the critical path so that the --LD launches reach the device first
     HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
     if (recount) {
+        // beside the --LD kernel: few long-lived waves (opt_recount_blocks per CU), so that the recount does not
+        // take the wave slots the --LD workgroups need -- it is bound by HBM, they by instruction issue
         ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
-                               c->stream2);
+                               c->stream2, ld_mode ? (unsigned)(c->n_cu * c->opt_recount_blocks) : 0u);
         c->counts_valid = true;
         HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
     }
@@ -1441,6 +1445,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
+    if (!strcmp(name, "recount_blocks_per_cu")) {
+        if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: recount_blocks_per_cu must be 0..128");
+        c->opt_recount_blocks = value; return 0;
+    }
     if (!strcmp(name, "chunks_per_wave")) {
         if (value < 0 || value > 5) return fail(c, "[::] ERROR in ibdg_set_option: chunks_per_wave must be 0..5");
         c->opt_cpw = value; return 0;

@@ -379,7 +379,7 @@ void launch_ld_ordered_sum(const OrdArgs &a, hipStream_t st)
 // launch wrappers
 // ---------------------------------------------------------------------------
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
-                      hipStream_t st)
+                      hipStream_t st, unsigned max_blocks)
 {
     if (n_rows == 0)
         return;
@@ -391,7 +391,9 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
     const size_t lds = (size_t)loads * 64 * 4;
     if (lds <= 16 * 1024) {
         const size_t R = 64 / g, n_groups = (n_rows + R - 1) / R;
-        const size_t blocks = n_groups < 256 * 32 * 4 ? n_groups : 256 * 32 * 4;      // a few rounds of 32 waves per CU
+        size_t blocks = n_groups < 256 * 32 * 4 ? n_groups : 256 * 32 * 4;            // a few rounds of 32 waves per CU
+        if (max_blocks && blocks > max_blocks)
+            blocks = max_blocks;
         auto kern = k_alt_count<0>;
         switch (loads) {
         case 1: kern = k_alt_count<1>; break;

@@ -201,7 +201,8 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * ibdg_sync, ibdg_run_ms and every ibdg_get_* wait for them -- lets a caller
  * queue one run per comparison individual without a host round trip between
  * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
- * so the timed region covers it); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
+ * so the timed region covers it; beside the --LD kernel the recount runs with "recount_blocks_per_cu"
+ * single-wave workgroups per CU, default 4, 0 = its full grid); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
  * ordinary host memory goes to the device through page-locked staging buffers filled by a team of host
  * threads instead of the runtime's pageable-memory path); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference
