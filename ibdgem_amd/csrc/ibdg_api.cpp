@@ -139,6 +139,7 @@ struct ibdg_ctx {
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
     long opt_recbytes = 12 * 1024;   // LDS budget for one run's segment records
+    long opt_site_blocks = 4;        // 256-thread workgroups per CU of k_site inside an --LD run (0 = a thread per site)
     long opt_recount_blocks = 4;     // single-wave workgroups per CU of k_alt_count when it runs inside an --LD run
                                      // (0 = the full grid; 4 measured best: tools/recount_sweep.py)
     long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
@@ -1326,7 +1327,12 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         c->counts_valid = true;
         HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
     }
-    ibdg::launch_site(sa, (unsigned)T, c->stream2);
+    // beside the --LD kernel the per-site kernel gets few long-lived workgroups (opt_site_blocks per CU, shared among
+    // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
+    unsigned site_blocks = 0;
+    if (ld_mode && c->opt_site_blocks > 0)
+        site_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
+    ibdg::launch_site(sa, (unsigned)T, c->stream2, site_blocks);
     HIP_TRY(c, hipEventRecord(E.s2[1], c->stream2));
 
     ibdg::WinArgs wa;
@@ -1445,6 +1451,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
+    if (!strcmp(name, "site_blocks_per_cu")) {
+        if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: site_blocks_per_cu must be 0..128");
+        c->opt_site_blocks = value; return 0;
+    }
     if (!strcmp(name, "recount_blocks_per_cu")) {
         if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: recount_blocks_per_cu must be 0..128");
         c->opt_recount_blocks = value; return 0;

@@ -214,7 +214,8 @@ void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t w
 // chip); a small number (e.g. 8 per CU) when it runs beside a kernel that should keep most of the slots
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st, unsigned max_blocks = 0);
-void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st);
+// max_blocks: 0 = a thread per site; otherwise at most that many 256-thread workgroups per target (grid-stride)
+void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
 void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st);
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st);
 

@@ -107,81 +107,112 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 // pow(1-f,2.0) and pow(f,2.0) come from pow_tab (indexed by alt count) or, with
 // an -A override, from the per-site fo array {f, pow(1-f,2), pow(f,2)}.
 // ---------------------------------------------------------------------------
+// U sites per thread and turn (their gathers are in flight together): 1 with a thread per site, 4 with the few
+// long-lived workgroups that run beside the --LD kernel
+template <int U>
 __global__ __launch_bounds__(256) void k_site(SiteArgs a)
 {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_sites)
-        return;
     const unsigned t = blockIdx.y;
-    const uint2 rc = a.rec_all[s];
-    const uint64_t *row = a.panel + (size_t)rc.x * a.stride;
-    const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc.y);
-    const double p00 = L[0], p01 = L[1], p11 = L[2];
+    const uint32_t tgt = a.targets[t];
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    // grid-stride: the launch may hold fewer threads than sites (few long-lived workgroups beside the --LD kernel)
+    for (size_t s0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < a.n_sites; s0 += U * step) {
+        uint2 rc[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t s = s0 + (size_t)u * step;
+            live[u] = s < a.n_sites;
+            rc[u] = live[u] ? a.rec_all[s] : make_uint2(0, 0);
+        }
+        uint32_t k[U];
+        uint2 w[U];
+        double p00[U], p01[U], p11[U], fo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc[u].y);
+            p00[u] = L[0];
+            p01[u] = L[1];
+            p11[u] = L[2];
+            k[u] = live[u] ? a.alt_count[rc[u].x] : 0u;
+            if (a.t32) {
+                // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
+                // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
+                const uint2 *tw = reinterpret_cast<const uint2 *>(
+                    a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc[u].x >> 6)) * 64 + (tgt & 63));
+                w[u] = live[u] ? tw[(rc[u].x >> 5) & 1] : make_uint2(0, 0);
+            } else {
+                const uint64_t *row = a.panel + (size_t)rc[u].x * a.stride;
+                const uint64_t r0 = live[u] ? row[2 * (tgt >> 6)] : 0, r1 = live[u] ? row[2 * (tgt >> 6) + 1] : 0;
+                w[u] = make_uint2((uint32_t)((r0 >> (tgt & 63)) & 1u) << (rc[u].x & 31),
+                                  (uint32_t)((r1 >> (tgt & 63)) & 1u) << (rc[u].x & 31));
+            }
+            fo[u] = a.fo && live[u] ? a.fo[3 * (s0 + (size_t)u * step)] : __longlong_as_double(0x7ff8000000000000ll);
+        }
+        double f[U], pw1[U], pw2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f[u] = (double)k[u] / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
+            pw1[u] = a.pow_tab[2 * k[u]];
+            pw2[u] = a.pow_tab[2 * k[u] + 1];
+            if (fo[u] == fo[u]) {          // not NaN: -A override (src/ibdgem.c:609-614)
+                const size_t s = s0 + (size_t)u * step;
+                f[u] = fo[u];
+                pw1[u] = a.fo[3 * s + 1];
+                pw2[u] = a.fo[3 * s + 2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u])
+                continue;
+            const size_t s = s0 + (size_t)u * step;
+            const unsigned A0 = (w[u].x >> (rc[u].x & 31)) & 1u, A1 = (w[u].y >> (rc[u].x & 31)) & 1u;
+            const unsigned g = A0 + A1;
+            const double omf = 1 - f[u];
+            double ibd0 = 1.0;
+            if (!(p00[u] == 1 || p01[u] == 1 || p11[u] == 1)) {
+                const double t1 = pw1[u] * p00[u];
+                const double t2 = ((2 * omf) * f[u]) * p01[u];
+                const double t3 = pw2[u] * p11[u];
+                ibd0 = (t1 + t2) + t3;
+                if (ibd0 == 0.0)
+                    ibd0 = 2.2250738585072014e-308;      // DBL_MIN
+            }
+            double ibd1;
+            if (g == 0)
+                ibd1 = (f[u] * p01[u]) + (omf * p00[u]);
+            else if (g == 1)
+                ibd1 = ((0.5 * p01[u]) + ((0.5 * omf) * p00[u])) + ((0.5 * f[u]) * p11[u]);
+            else
+                ibd1 = (omf * p01[u]) + (f[u] * p11[u]);
+            if (ibd1 == 0.0)
+                ibd1 = 2.2250738585072014e-308;
+            const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
 
-    const uint32_t k = a.alt_count[rc.x];
-    double f = (double)k / (double)(int)(2u * a.n_ids);
-    double pw1 = a.pow_tab[2 * k], pw2 = a.pow_tab[2 * k + 1];
-    if (a.fo) {
-        const double fo = a.fo[3 * s];
-        if (fo == fo) {          // not NaN: -A override (src/ibdgem.c:609-614)
-            f = fo;
-            pw1 = a.fo[3 * s + 1];
-            pw2 = a.fo[3 * s + 2];
+            if (t == 0)
+                a.af[s] = f[u];
+            double *o = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
+            o[0] = ibd0;
+            o[1] = ibd1;
+            o[2] = ibd2;
         }
     }
-    const uint32_t tgt = a.targets[t];
-    unsigned A0, A1;
-    if (a.t32) {
-        // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
-        // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
-        const uint2 *tw = reinterpret_cast<const uint2 *>(
-            a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc.x >> 6)) * 64 + (tgt & 63));
-        const uint2 w = tw[(rc.x >> 5) & 1];
-        A0 = (w.x >> (rc.x & 31)) & 1u;
-        A1 = (w.y >> (rc.x & 31)) & 1u;
-    } else {
-        A0 = (unsigned)(row[2 * (tgt >> 6)] >> (tgt & 63)) & 1u;
-        A1 = (unsigned)(row[2 * (tgt >> 6) + 1] >> (tgt & 63)) & 1u;
-    }
-    const unsigned g = A0 + A1;
-
-    const double omf = 1 - f;
-    double ibd0 = 1.0;
-    if (!(p00 == 1 || p01 == 1 || p11 == 1)) {
-        const double t1 = pw1 * p00;
-        const double t2 = ((2 * omf) * f) * p01;
-        const double t3 = pw2 * p11;
-        ibd0 = (t1 + t2) + t3;
-        if (ibd0 == 0.0)
-            ibd0 = 2.2250738585072014e-308;      // DBL_MIN
-    }
-    double ibd1;
-    if (g == 0)
-        ibd1 = (f * p01) + (omf * p00);
-    else if (g == 1)
-        ibd1 = ((0.5 * p01) + ((0.5 * omf) * p00)) + ((0.5 * f) * p11);
-    else
-        ibd1 = (omf * p01) + (f * p11);
-    if (ibd1 == 0.0)
-        ibd1 = 2.2250738585072014e-308;
-    const double ibd2 = g == 0 ? p00 : (g == 1 ? p01 : p11);
-
-    if (t == 0)
-        a.af[s] = f;
-    double *o = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
-    o[0] = ibd0;
-    o[1] = ibd1;
-    o[2] = ibd2;
 }
 
 // ---------------------------------------------------------------------------
 // K3: window products S0,S1,S2 over the covered rows of a window, in row order
-// (src/ibdgem.c:562, :665-667, :755).  One wave per (window, target); lanes
-// stage the rows' three values through LDS, lanes 0..2 multiply sequentially.
-// In --LD mode only LIBD2 = S2 is written (src/ibdgem.c:752); LIBD0/LIBD1 of
-// the window come from the LD kernel.
+// (src/ibdgem.c:562, :665-667, :755).  One thread per (window, target): the rows' values are
+// fetched eight rows ahead of the sequential products (the loads do not depend on the chain), so a
+// window costs ~13 memory round trips, and the whole kernel is a few hundred waves -- it runs beside
+// the --LD kernel without taking its wave slots (a wave per window did: 35 000 waves, each parked on
+// a chain of dependent LDS reads).  In --LD mode only LIBD2 = S2 is written (src/ibdgem.c:752);
+// LIBD0/LIBD1 of the window come from the LD kernel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_window_prod(WinArgs a)
+// The stand-alone form (non-LD runs, nothing else on the chip): one wave per (window, target); lanes stage the
+// rows' three values through LDS, lanes 0..2 multiply sequentially.  Twice as fast alone as the thread-per-window
+// form below (0.031 against 0.052 ms at 4M rows), but 35 000 waves that each sit on a chain of dependent LDS reads.
+__global__ __launch_bounds__(64) void k_window_prod_wave(WinArgs a)
 {
     __shared__ double buf[64 * 3];
     const unsigned w = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
@@ -205,6 +236,51 @@ __global__ __launch_bounds__(64) void k_window_prod(WinArgs a)
     }
     if (lane < 3 && (!a.ld_mode || lane == 2))
         a.win_ll[((size_t)t * a.n_win + w) * 3 + lane] = acc;
+}
+
+// The form that runs beside the --LD kernel: one thread per (window, target).
+__global__ __launch_bounds__(64) void k_window_prod(WinArgs a)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = blockIdx.y;
+    if (w >= a.n_win)
+        return;
+    const uint64_t begin = (uint64_t)w * a.window;
+    const uint32_t end = (uint32_t)min(begin + a.window, (uint64_t)a.n_cov);
+    const double *ll = a.site_ll + (size_t)t * a.n_sites * 3;
+    double s0 = 1.0, s1 = 1.0, s2 = 1.0;
+    for (uint32_t j = (uint32_t)begin; j < end; j += 8) {
+        uint32_t site[8];
+        double v0[8], v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            site[u] = j + u < end ? a.cov_site[j + u] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v0[u] = v1[u] = v2[u] = 1.0;
+            if (site[u] != 0xffffffffu) {
+                const double *src = ll + (size_t)site[u] * 3;
+                if (!a.ld_mode) {
+                    v0[u] = src[0];
+                    v1[u] = src[1];
+                }
+                v2[u] = src[2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + u < end) {                       // (times 1.0 would be exact too, but keep to the rows there are)
+                s0 *= v0[u];
+                s1 *= v1[u];
+                s2 *= v2[u];
+            }
+    }
+    double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
+    if (!a.ld_mode) {
+        o[0] = s0;
+        o[1] = s1;
+    }
+    o[2] = s2;
 }
 
 // ---------------------------------------------------------------------------
@@ -417,19 +493,28 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
                        alt_count);
 }
 
-void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st)
+void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks)
 {
     if (a.n_sites == 0 || n_targets == 0)
         return;
-    dim3 grid((unsigned)((a.n_sites + 255) / 256), n_targets);
-    hipLaunchKernelGGL(k_site, grid, dim3(256), 0, st, a);
+    size_t blocks = (a.n_sites + 255) / 256;
+    if (max_blocks && blocks > max_blocks)
+        blocks = max_blocks;
+    dim3 grid((unsigned)blocks, n_targets);
+    if (max_blocks)
+        hipLaunchKernelGGL(k_site<4>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_site<1>, grid, dim3(256), 0, st, a);
 }
 
 void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st)
 {
     if (a.n_win == 0 || n_targets == 0)
         return;
-    hipLaunchKernelGGL(k_window_prod, dim3(a.n_win, n_targets), dim3(64), 0, st, a);
+    if (a.ld_mode)
+        hipLaunchKernelGGL(k_window_prod, dim3((a.n_win + 63) / 64, n_targets), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_window_prod_wave, dim3(a.n_win, n_targets), dim3(64), 0, st, a);
 }
 
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st)
