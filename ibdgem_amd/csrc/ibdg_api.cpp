@@ -1329,8 +1329,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
     // beside the --LD kernel the per-site kernel gets few long-lived workgroups (opt_site_blocks per CU, shared among
     // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
+    // (not when the alt counts are recounted in this run: the second stream's chain count -> per-site -> products is
+    // then the longer one of the two, and its short kernels should be short)
+    const bool shadow = ld_mode && !recount;
     unsigned site_blocks = 0;
-    if (ld_mode && c->opt_site_blocks > 0)
+    if (shadow && c->opt_site_blocks > 0)
         site_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
     ibdg::launch_site(sa, (unsigned)T, c->stream2, site_blocks);
     HIP_TRY(c, hipEventRecord(E.s2[1], c->stream2));
@@ -1344,7 +1347,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     wa.n_win = c->n_win;
     wa.ld_mode = ld_mode ? 1 : 0;
     wa.win_ll = (double *)c->win_ll.p;
-    ibdg::launch_window_prod(wa, (unsigned)T, c->stream2);
+    ibdg::launch_window_prod(wa, (unsigned)T, c->stream2, shadow);
     HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
     c->last_s2 = E.s2[2];
     c->s2_pending = true;

@@ -216,7 +216,9 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
                       hipStream_t st, unsigned max_blocks = 0);
 // max_blocks: 0 = a thread per site; otherwise at most that many 256-thread workgroups per target (grid-stride)
 void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
-void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st);
+// small_footprint: the thread-per-window form (a few hundred waves; for running beside the --LD kernel) instead of
+// the wave-per-window form (faster when it has the chip to itself)
+void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st, bool small_footprint);
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st);
 
 }  // namespace ibdg

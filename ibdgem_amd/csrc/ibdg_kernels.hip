@@ -507,11 +507,11 @@ void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned
         hipLaunchKernelGGL(k_site<1>, grid, dim3(256), 0, st, a);
 }
 
-void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st)
+void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st, bool small_footprint)
 {
     if (a.n_win == 0 || n_targets == 0)
         return;
-    if (a.ld_mode)
+    if (small_footprint)
         hipLaunchKernelGGL(k_window_prod, dim3((a.n_win + 63) / 64, n_targets), dim3(64), 0, st, a);
     else
         hipLaunchKernelGGL(k_window_prod_wave, dim3(a.n_win, n_targets), dim3(64), 0, st, a);

@@ -18,7 +18,7 @@ def rate(n=100):
     return (time.perf_counter() - t0) / n * 1e3
 print("no recount", round(rate(), 4), "ms/step")
 eng.set_option("count_in_run", 1)
-for b in (3, 4, 5, 6, 4, 5):
+for b in (3, 4, 5, 6, 4):
     eng.set_option("recount_blocks_per_cu", b)
     rate(20)
     ms = rate()
