@@ -369,20 +369,92 @@ __device__ __forceinline__ double ld_value(int eK, const uint4 &p1, const uint4 
     return __builtin_ldexp(m1 * m2, eK + (int)p1.z + (int)p2.z);
 }
 
-// One segment: fetch its record and tile words, advance the ring, count.  OP is `=` for the first
-// segment of a window (the counters start there, so nothing has to be zeroed) and `+=` after it.
-#define IBDG_COV_PLANE_OP(OP, k, cov)                                       \
-    {                                                                       \
-        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
-        c0[k] OP __popc(u0);                                                \
-        c1[k] OP __popc(u1);                                                \
-        ch[k] OP __popc(hom & (cov));                                       \
-        g00[k] OP __popc(u0 & at.x);                                        \
-        g01[k] OP __popc(u1 & at.x);                                        \
-        g10[k] OP __popc(u0 & at.y);                                        \
-        g11[k] OP __popc(u1 & at.y);                                        \
-    }
-#define IBDG_SEGMENT(OP)                                                                                        \
+// The counting itself is written in assembly, one statement per group of (mask, count) pairs, for the sake of ONE
+// scalar instruction inside every pair:
+//     v_and_b32 t, x, m ; s_nop 0 ; v_bcnt_u32_b32 c, t, c
+// Back to back, a 1:1 stream of v_and_b32 (2.2 cycles per wave alone) and v_bcnt_u32_b32 (4.2) issues at 3.8-4.0
+// cycles per instruction; with one scalar instruction per pair -- s_nop 0, any SALU instruction, before or after
+// the count -- it issues at 3.2, the average of its parts; two per pair, one per four vector instructions or
+// s_nop 1 lose it again (tools/ubench/nop_mix.hip, profiles/r02_nop_mix.txt).  hipcc knows nothing of this and
+// moves scalar work of the loop into the stream wherever it fits, so the pairs are fenced by scheduling barriers
+// (IBDG_SEGMENT) and everything scalar is computed before them.
+// A0..: what the count starts from -- "0" for the first segment of a window (the counters start there, nothing is
+// zeroed between windows), the counter itself afterwards.
+// One statement per segment (per weight plane in the kernel for several individuals): between two asm statements
+// hipcc's hazard recogniser puts an s_nop of its own, a second scalar instruction for that pair.
+#define IBDG_PAIR_SET(tmp, a, b, cnt) \
+    "v_and_b32 %[" #tmp "], %[" #a "], %[" #b "]\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #cnt "], %[" #tmp "], 0\n\t"
+#define IBDG_PAIR_ADD(tmp, a, b, cnt) \
+    "v_and_b32 %[" #tmp "], %[" #a "], %[" #b "]\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #cnt "], %[" #tmp "], %[" #cnt "]\n\t"
+// C(x0) C(x1) C(x0&x1) and the four G(x,t) of weight plane k (u0 = x0 & cov, u1 = x1 & cov are shared)
+#define IBDG_COV_PLANE_TEXT(P, k) \
+    P(u0, x0, cov##k, c0##k) P(u1, x1, cov##k, c1##k) P(t, hom, cov##k, ch##k) \
+    P(t, u0, at0, g00##k) P(t, u1, at0, g01##k) P(t, u0, at1, g10##k) P(t, u1, at1, g11##k)
+#define IBDG_ALT_TEXT(P) P(t, x0, alt0, a00) P(t, x1, alt0, a10) P(t, x0, alt1, a01) P(t, x1, alt1, a11)
+#define IBDG_SEG_TEXT(P) IBDG_COV_PLANE_TEXT(P, 0) IBDG_COV_PLANE_TEXT(P, 1) IBDG_COV_PLANE_TEXT(P, 2) IBDG_ALT_TEXT(P)
+#define IBDG_CNT3(C, name, arr) [name##0] C(arr[0]), [name##1] C(arr[1]), [name##2] C(arr[2])
+
+// the 25 counts of one segment for one comparison individual
+template <bool FIRST>
+__device__ __forceinline__ void count_segment(uint32_t (&c0)[3], uint32_t (&c1)[3], uint32_t (&ch)[3], uint32_t (&g00)[3],
+                                              uint32_t (&g01)[3], uint32_t (&g10)[3], uint32_t (&g11)[3], uint32_t (&A0)[2],
+                                              uint32_t (&A1)[2], uint32_t x0, uint32_t x1, uint32_t hom, uint32_t cov0,
+                                              uint32_t cov1, uint32_t cov2, uint32_t alt0, uint32_t alt1, uint32_t at0, uint32_t at1)
+{
+    uint32_t u0, u1, t;
+#define IBDG_OUT_SET(v) "=&v"(v)
+#define IBDG_OUT_ADD(v) "+v"(v)
+#define IBDG_SEG_OPERANDS(C)                                                                                              \
+    : IBDG_CNT3(C, c0, c0), IBDG_CNT3(C, c1, c1), IBDG_CNT3(C, ch, ch), IBDG_CNT3(C, g00, g00), IBDG_CNT3(C, g01, g01),   \
+      IBDG_CNT3(C, g10, g10), IBDG_CNT3(C, g11, g11), [a00] C(A0[0]), [a01] C(A0[1]), [a10] C(A1[0]), [a11] C(A1[1]),     \
+      [u0] "=&v"(u0), [u1] "=&v"(u1), [t] "=&v"(t)                                                                        \
+    : [x0] "v"(x0), [x1] "v"(x1), [hom] "v"(hom), [cov0] "v"(cov0), [cov1] "v"(cov1), [cov2] "v"(cov2), [alt0] "v"(alt0), \
+      [alt1] "v"(alt1), [at0] "v"(at0), [at1] "v"(at1)
+    if (FIRST)
+        asm volatile(IBDG_SEG_TEXT(IBDG_PAIR_SET) IBDG_SEG_OPERANDS(IBDG_OUT_SET));
+    else
+        asm volatile(IBDG_SEG_TEXT(IBDG_PAIR_ADD) IBDG_SEG_OPERANDS(IBDG_OUT_ADD));
+#undef IBDG_SEG_OPERANDS
+}
+
+// the same for four comparison individuals, one weight plane per statement: the common three counts and 4 x 4 G(x,t)
+#define IBDG_G4_TEXT(P, j) P(t, u0, ta##j, g##j##0) P(t, u1, ta##j, g##j##1) P(t, u0, tb##j, g##j##2) P(t, u1, tb##j, g##j##3)
+#define IBDG_PLANE4_TEXT(P) P(u0, x0, cov, c0) P(u1, x1, cov, c1) P(t, hom, cov, ch) IBDG_G4_TEXT(P, 0) IBDG_G4_TEXT(P, 1) IBDG_G4_TEXT(P, 2) IBDG_G4_TEXT(P, 3)
+#define IBDG_G4_OPS(C, j) [g##j##0] C(gq[j][0][k]), [g##j##1] C(gq[j][1][k]), [g##j##2] C(gq[j][2][k]), [g##j##3] C(gq[j][3][k])
+template <bool FIRST>
+__device__ __forceinline__ void count_plane_mt(uint32_t &c0, uint32_t &c1, uint32_t &ch, uint32_t (&gq)[4][4][3], int k,
+                                               uint32_t x0, uint32_t x1, uint32_t hom, uint32_t cov, const uint32_t (&tw)[4][2])
+{
+    uint32_t u0, u1, t;
+#define IBDG_P4_OPERANDS(C)                                                                                               \
+    : [c0] C(c0), [c1] C(c1), [ch] C(ch), IBDG_G4_OPS(C, 0), IBDG_G4_OPS(C, 1), IBDG_G4_OPS(C, 2), IBDG_G4_OPS(C, 3),     \
+      [u0] "=&v"(u0), [u1] "=&v"(u1), [t] "=&v"(t)                                                                        \
+    : [x0] "v"(x0), [x1] "v"(x1), [hom] "v"(hom), [cov] "v"(cov), [ta0] "v"(tw[0][0]), [tb0] "v"(tw[0][1]),               \
+      [ta1] "v"(tw[1][0]), [tb1] "v"(tw[1][1]), [ta2] "v"(tw[2][0]), [tb2] "v"(tw[2][1]), [ta3] "v"(tw[3][0]), [tb3] "v"(tw[3][1])
+    if (FIRST)
+        asm volatile(IBDG_PLANE4_TEXT(IBDG_PAIR_SET) IBDG_P4_OPERANDS(IBDG_OUT_SET));
+    else
+        asm volatile(IBDG_PLANE4_TEXT(IBDG_PAIR_ADD) IBDG_P4_OPERANDS(IBDG_OUT_ADD));
+#undef IBDG_P4_OPERANDS
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], uint32_t x0, uint32_t x1, uint32_t alt0, uint32_t alt1)
+{
+    uint32_t t;
+    if (FIRST)
+        asm volatile(IBDG_ALT_TEXT(IBDG_PAIR_SET)
+                     : [a00] "=&v"(A0[0]), [a01] "=&v"(A0[1]), [a10] "=&v"(A1[0]), [a11] "=&v"(A1[1]), [t] "=&v"(t)
+                     : [x0] "v"(x0), [x1] "v"(x1), [alt0] "v"(alt0), [alt1] "v"(alt1));
+    else
+        asm volatile(IBDG_ALT_TEXT(IBDG_PAIR_ADD)
+                     : [a00] "+v"(A0[0]), [a01] "+v"(A0[1]), [a10] "+v"(A1[0]), [a11] "+v"(A1[1]), [t] "=&v"(t)
+                     : [x0] "v"(x0), [x1] "v"(x1), [alt0] "v"(alt0), [alt1] "v"(alt1));
+}
+
+// One segment: fetch its record and tile words, advance the ring, count.  FIRST: the first segment of a window
+// (the counters start there, so nothing has to be zeroed).
+#define IBDG_SEGMENT(FIRST)                                                                                        \
     {                                                                                                           \
         uint4 h0, h1;                                                                                           \
         uint2 x;                                                                                                \
@@ -403,13 +475,9 @@ __device__ __forceinline__ double ld_value(int eK, const uint4 &p1, const uint4 
         const uint32_t cov0 = h0.y, cov1 = h0.z, cov2 = h0.w, alt0 = h1.x, alt1 = h1.y;                         \
         const uint2 at = make_uint2(h1.z, h1.w);                                                                \
         const uint32_t hom = x.x & x.y;                                                                         \
-        IBDG_COV_PLANE_OP(OP, 0, cov0)                                                                          \
-        IBDG_COV_PLANE_OP(OP, 1, cov1)                                                                          \
-        IBDG_COV_PLANE_OP(OP, 2, cov2)                                                                          \
-        A0[0] OP __popc(x.x & alt0);                                                                            \
-        A1[0] OP __popc(x.y & alt0);                                                                            \
-        A0[1] OP __popc(x.x & alt1);                                                                            \
-        A1[1] OP __popc(x.y & alt1);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        count_segment<FIRST>(c0, c1, ch, g00, g01, g10, g11, A0, A1, x.x, x.y, hom, cov0, cov1, cov2, alt0, alt1, at.x, at.y); \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (flags & (1u << 12)) {                                                                               \
             const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
             for (uint32_t k = FC; k < ncov; ++k) {                                                              \
@@ -538,9 +606,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     uint32_t s = 0;
     for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
-        IBDG_SEGMENT(=)                                  // its first segment starts the counters
+        IBDG_SEGMENT(true)                               // its first segment starts the counters
         while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
-            IBDG_SEGMENT(+=)
+            IBDG_SEGMENT(false)
         {
         {
             uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
@@ -590,7 +658,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 }
 
 #undef IBDG_SEGMENT
-#undef IBDG_COV_PLANE_OP
 
 // ---------------------------------------------------------------------------
 // Several comparison individuals per workgroup (BASELINE.json configs[4]: hundreds of them against
@@ -725,22 +792,8 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
                  : "memory");
 }
 
-// One segment for TB comparison individuals (OP as in IBDG_SEGMENT of k_ld_popcount)
-#define IBDG_COV_PLANE_MT(OP, k, cov)                                       \
-    {                                                                       \
-        const uint32_t u0 = x.x & (cov), u1 = x.y & (cov);                  \
-        c0[k] OP __popc(u0);                                                \
-        c1[k] OP __popc(u1);                                                \
-        ch[k] OP __popc(hom & (cov));                                       \
-        _Pragma("unroll") for (int j = 0; j < TB; ++j)                      \
-        {                                                                   \
-            gq[j][0][k] OP __popc(u0 & tw[j][0]);                           \
-            gq[j][1][k] OP __popc(u1 & tw[j][0]);                           \
-            gq[j][2][k] OP __popc(u0 & tw[j][1]);                           \
-            gq[j][3][k] OP __popc(u1 & tw[j][1]);                           \
-        }                                                                   \
-    }
-#define IBDG_SEGMENT_MT(OP)                                                                                     \
+// One segment for TB comparison individuals (FIRST as in IBDG_SEGMENT of k_ld_popcount)
+#define IBDG_SEGMENT_MT(FIRST)                                                                                     \
     {                                                                                                           \
         uint4 h0, h1, h2, h3;                                                                                   \
         uint2 x;                                                                                                \
@@ -762,13 +815,12 @@ __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad
         const uint32_t tw4[4][2] = {{h2.x, h2.y}, {h2.z, h2.w}, {h3.x, h3.y}, {h3.z, h3.w}};                    \
         const uint32_t (&tw)[4][2] = tw4;                                                                       \
         const uint32_t hom = x.x & x.y;                                                                         \
-        IBDG_COV_PLANE_MT(OP, 0, cov0)                                                                          \
-        IBDG_COV_PLANE_MT(OP, 1, cov1)                                                                          \
-        IBDG_COV_PLANE_MT(OP, 2, cov2)                                                                          \
-        A0[0] OP __popc(x.x & alt0);                                                                            \
-        A1[0] OP __popc(x.y & alt0);                                                                            \
-        A0[1] OP __popc(x.x & alt1);                                                                            \
-        A1[1] OP __popc(x.y & alt1);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        count_plane_mt<FIRST>(c0[0], c1[0], ch[0], gq, 0, x.x, x.y, hom, cov0, tw);                             \
+        count_plane_mt<FIRST>(c0[1], c1[1], ch[1], gq, 1, x.x, x.y, hom, cov1, tw);                             \
+        count_plane_mt<FIRST>(c0[2], c1[2], ch[2], gq, 2, x.x, x.y, hom, cov2, tw);                             \
+        count_alt<FIRST>(A0, A1, x.x, x.y, alt0, alt1);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (flags & (1u << 12)) {                                                                               \
             const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
             for (uint32_t k = FC; k < ncov; ++k) {                                                              \
@@ -884,9 +936,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
     uint32_t s = 0;
     for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
-        IBDG_SEGMENT_MT(=)                               // its first segment starts the counters
+        IBDG_SEGMENT_MT(true)                            // its first segment starts the counters
         while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
-            IBDG_SEGMENT_MT(+=)
+            IBDG_SEGMENT_MT(false)
         {
         const uint32_t wc_addr = wc_base + (w - w0) * (IBDG_WCM_WORDS * 4);
         static_assert(TB == 4, "the six-read statement below fetches 8 + 4*4 words");
@@ -956,7 +1008,6 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
 }
 
 #undef IBDG_SEGMENT_MT
-#undef IBDG_COV_PLANE_MT
 
 // Sum the per-chunk partials of a window and take the background average (src/ibdgem.c:751-752).
 // One wave per window: lane c adds chunks c, c+64, .. (coalesced 16-byte loads), then the wave

@@ -1,8 +1,8 @@
 """A/B of two builds of the engine on one box (boxes differ by a few per cent, so never compare across calls):
 
-    python tools/ab_kernel.py build/a/libibdgem_hip.so build/b/libibdgem_hip.so [rows]
+    python tools/ab_kernel.py build/a/libibdgem_hip.so build/b/libibdgem_hip.so [more.so ...] [rows]
 
-Both libraries get the bench workload (same panel, same sites); the dominant --LD kernel is timed through
+All libraries get the bench workload (same panel, same sites); the dominant --LD kernel is timed through
 its own dispatch events, in alternating rounds A B A B ..., and the results of the two are compared bit
 for bit."""
 import os
@@ -15,8 +15,8 @@ import torch
 import bench
 import ibdgem_amd
 
-libs = sys.argv[1:3]
-rows = int(sys.argv[3]) if len(sys.argv) > 3 else 4_000_000
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+rows = ([int(a) for a in sys.argv[1:] if a.isdigit()] or [4_000_000])[0]
 dev = torch.device("cuda", 0)
 panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
 torch.cuda.synchronize()
@@ -32,9 +32,9 @@ wins = []
 for e in engs:
     e.run([7], ld=True)
     wins.append(e.window_ll(0))
-print("results identical:", bool((wins[0].view(np.uint64) == wins[1].view(np.uint64)).all()))
-times = [[], []]
-steps = [[], []]
+print("results identical:", all(bool((wins[0].view(np.uint64) == w.view(np.uint64)).all()) for w in wins[1:]))
+times = [[] for _ in libs]
+steps = [[] for _ in libs]
 for rnd in range(6):
     for i, e in enumerate(engs):
         e.set_option("dispatch_events", 1)
@@ -54,4 +54,5 @@ for rnd in range(6):
 for i, lib in enumerate(libs):
     print(f"{lib}: dominant kernel {np.median(times[i]):.4f} ms (rounds {', '.join(f'{t:.4f}' for t in times[i])}); "
           f"step {np.median(steps[i]):.4f} ms")
-print(f"B/A kernel time: {np.median(times[1]) / np.median(times[0]):.4f}   step: {np.median(steps[1]) / np.median(steps[0]):.4f}")
+for i in range(1, len(libs)):
+    print(f"{libs[i]} / {libs[0]}  kernel time: {np.median(times[i]) / np.median(times[0]):.4f}   step: {np.median(steps[i]) / np.median(steps[0]):.4f}")
