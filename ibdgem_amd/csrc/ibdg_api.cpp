@@ -50,6 +50,7 @@ struct ibdg_ctx {
         bool has_kernel_times = false;
         hipEvent_t s2_start = nullptr;      // stream2: before its first kernel of the run
         hipEvent_t s2[3] = {};              // stream2: after alt-count, per-site, window-product kernels
+        hipEvent_t prep = nullptr;          // main stream: the target operands of the matrix-core kernel are built
         hipEvent_t start = nullptr;         // start_own or the previous run's ld_end
         bool recount = false, ld = false;
     } evs[EV_RING];
@@ -95,6 +96,9 @@ struct ibdg_ctx {
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
     DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, partial;
+    // many comparison individuals (k_ld_mfma): target operands of a batch of groups, window constants per slot,
+    // partial sums per half chunk, background multiplicities without the comparison individual's exclusion
+    DevBuf aimg, wc_slot, partial_h, base_w;
     // pow1/pow2: rho^n, sigma^n as {f64 mantissa, i32 exponent}; powb: (1-eps)^n in the x87 format
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
@@ -135,6 +139,8 @@ struct ibdg_ctx {
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
+    long opt_mfma_targets = 1;   // 8 or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma)
+    long opt_mfma_min = 8;       // smallest (last) group worth a launch of its own
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
@@ -754,7 +760,7 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
             return bail("hipStreamCreate", e);
     }
     for (auto &E : c->evs) {
-        for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2]})
+        for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2], &E.prep})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
     }
     for (hipEvent_t &ev : c->ev_up)
@@ -795,7 +801,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial,
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
         release(*b);
@@ -811,7 +817,7 @@ void ibdg_destroy(ibdg_ctx *c)
     if (c->info_h)
         (void)hipHostFree(c->info_h);
     for (auto &E : c->evs)
-        for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2]})
+        for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2], E.prep})
             if (ev)
                 (void)hipEventDestroy(ev);
     if (c->stream2)
@@ -1117,9 +1123,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             }
             nref[t] = cnt;
         }
-        if (ensure(c, c->weight, wt.size() * 8) || ensure(c, c->nrefpanel, T * 4))
+        // the same without the comparison individual's own exclusion (k_ld_mfma applies that itself)
+        std::vector<double> wb(lanes, 0.0);
+        for (unsigned n = 0; n < c->n_ids; ++n) {
+            const unsigned k = bg_count ? bg_count[n] : 1u;
+            if ((int)n != pu_id && k != 0)
+                wb[n] = (double)k;
+        }
+        if (ensure(c, c->weight, wt.size() * 8) || ensure(c, c->nrefpanel, T * 4) || ensure(c, c->base_w, lanes * 8))
             return 1;
         HIP_TRY(c, hipMemcpyAsync(c->weight.p, wt.data(), wt.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->base_w.p, wb.data(), lanes * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->nrefpanel.p, nref.data(), T * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vectors go out of scope
         c->chain_ok = false;
@@ -1131,7 +1145,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->prev_bg.assign(bg_count, bg_count + c->n_ids);
     }
 
-    bool use_pop = false;
+    bool use_pop = false, s2_after_prep = false;
     if (ld_mode) {
         const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
         if (c->opt_variant == 2 && !can)
@@ -1192,12 +1206,36 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const size_t MT = (size_t)ibdg::ld_popcount_mt_width();
         const bool mt_fits = ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring,
                                                          1) <= 150 * 1024;
-        const size_t n_grp = (c->opt_multi_target && mt_fits && T >= MT) ? T / MT : 0, T_one = T - n_grp * MT;
+        // Eight or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma); the
+        // last group may be short, fewer than mfma_min individuals take the counting kernels below.
+        const size_t TGs = IBDG_TG;
+        size_t n_gg = 0, T_g = 0;
+        if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && c->n_pairs < (1u << 23) &&
+            ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
+            n_gg = T / TGs;
+            T_g = n_gg * TGs;
+            if (T - T_g >= (size_t)c->opt_mfma_min) {
+                n_gg++;
+                T_g = T;
+            }
+        }
+        const size_t T_cnt = T - T_g;      // comparison individuals of the counting kernels: [T_g, T)
+        const size_t n_grp = (c->opt_multi_target && mt_fits && T_cnt >= MT) ? T_cnt / MT : 0, T_one = T_cnt - n_grp * MT;
+        // target operands: 1 KiB per segment and group; groups go in batches of about 2 GiB of them
+        size_t gg_batch = n_gg;
+        if (n_gg) {
+            const size_t per_group = (size_t)c->n_segs * 1024;
+            const size_t fit = per_group ? ((size_t)2 << 30) / per_group : n_gg;
+            gg_batch = fit < 1 ? 1 : (fit < n_gg ? fit : n_gg);
+        }
         if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, T_one * (size_t)c->n_segs * 32) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
-            ensure(c, c->partial, T * (size_t)c->n_win * c->n_chunks * 16))
+            ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
+            ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
+            ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 256) ||
+            ensure(c, c->partial_h, T_g * (size_t)c->n_win * c->n_chunks * 32))
             return 1;
         ibdg::PopArgs pa;
         pa.t32 = (const uint32_t *)c->t32.p;
@@ -1218,7 +1256,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
-        pa.t_base = 0;
+        pa.t_base = (uint32_t)T_g;
         pa.weight = (const double *)c->weight.p;
         pa.lanes = (uint32_t)lanes;
         pa.partial = (double *)c->partial.p;
@@ -1232,6 +1270,42 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             dominant.stop = E.k_stop;
             last.stop = E.ld_end;
         }
+        if (n_gg) {
+            ibdg::MfmaArgs ma;
+            ma.t32 = pa.t32;
+            ma.n_pairs = pa.n_pairs;
+            ma.n_chunks = pa.n_chunks;
+            ma.segs = pa.segs;
+            ma.n_segs = pa.n_segs;
+            ma.wconst = pa.wconst;
+            ma.n_win = pa.n_win;
+            ma.run_begin = pa.run_begin;
+            ma.n_runs = pa.n_runs;
+            ma.win_per_group = pa.win_per_group;
+            ma.max_seg = pa.max_seg;
+            ma.aimg = (uint4 *)c->aimg.p;
+            ma.wc_slot = (uint4 *)c->wc_slot.p;
+            ma.pow_1me = pa.pow_1me;
+            ma.pow_eps = pa.pow_eps;
+            ma.tab_len = pa.tab_len;
+            ma.targets = pa.targets;
+            ma.base_weight = (const double *)c->base_w.p;
+            ma.partial = (double *)c->partial_h.p;
+            for (size_t g0 = 0; g0 < n_gg; g0 += gg_batch) {
+                const size_t nb = n_gg - g0 < gg_batch ? n_gg - g0 : gg_batch;
+                ma.t_base = (uint32_t)(g0 * TGs);
+                ma.n_targets = (uint32_t)((T_g - g0 * TGs) < nb * TGs ? (T_g - g0 * TGs) : nb * TGs);
+                ibdg::launch_win_target_g(ma, (unsigned)nb, c->stream);
+                if (g0 == 0) {
+                    // the second stream (per-site values, window products; high priority) starts behind these
+                    // two short kernels rather than beside them: it starved them (0.57 ms instead of 0.06)
+                    HIP_TRY(c, hipEventRecord(E.prep, c->stream));
+                    s2_after_prep = true;
+                }
+                if (ibdg::launch_ld_mfma(ma, (unsigned)nb, c->stream, ibdg::KernelEvents()))
+                    return fail(c, "[::] ERROR in ibdg_run: the matrix-core --LD kernel could not be launched");
+            }
+        }
         if (n_grp) {
             ibdg::PopArgs pm = pa;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
@@ -1242,19 +1316,29 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 return fail(c, "[::] ERROR in ibdg_run: the multi-target --LD kernel could not be launched");
         }
         if (T_one) {
-            pa.t_base = (uint32_t)(n_grp * MT);
+            pa.t_base = (uint32_t)(T_g + n_grp * MT);
             ibdg::launch_win_target(pa, (unsigned)T_one, c->stream, first);
             if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream, dominant))
                 return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         }
         ibdg::PopFinalArgs fa;
         fa.wconst = pa.wconst;
-        fa.partial = pa.partial;
         fa.n_win = c->n_win;
         fa.n_chunks = c->n_chunks;
         fa.n_refpanel = (const int *)c->nrefpanel.p;
         fa.win_ll = (double *)c->win_ll.p;
-        ibdg::launch_ld_finalize(fa, (unsigned)T, c->stream, last);
+        if (T_g) {
+            fa.partial = (const double *)c->partial_h.p;
+            fa.t_base = 0;
+            fa.halves = 1;
+            ibdg::launch_ld_finalize(fa, (unsigned)T_g, c->stream, T_cnt ? ibdg::KernelEvents() : last);
+        }
+        if (T_cnt) {
+            fa.partial = pa.partial;
+            fa.t_base = (uint32_t)T_g;
+            fa.halves = 0;
+            ibdg::launch_ld_finalize(fa, (unsigned)T_cnt, c->stream, last);
+        }
     } else if (ld_mode) {
         ibdg::LdArgs la;
         la.panel = sa.panel;
@@ -1318,6 +1402,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
 
     // stream2, queued after the critical path so that the --LD launches reach the device first
+    if (s2_after_prep)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.prep, 0));
     HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
     if (recount) {
         // beside the --LD kernel: few long-lived waves (opt_recount_blocks per CU), so that the recount does not
@@ -1450,6 +1536,12 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!c || !name) return 1;
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
+    if (!strcmp(name, "mfma_targets")) { c->opt_mfma_targets = value != 0; return 0; }
+    if (!strcmp(name, "mfma_min")) {
+        if (value < 1 || value > IBDG_TG) return fail(c, "[::] ERROR in ibdg_set_option: mfma_min must be 1..%d", IBDG_TG);
+        c->opt_mfma_min = value;
+        return 0;
+    }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }

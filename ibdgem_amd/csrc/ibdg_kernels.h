@@ -126,20 +126,50 @@ struct PopArgs {
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
 };
 
-struct PopFinalArgs {
-    const WinConst *wconst;
-    const double *partial;
-    uint32_t n_win, n_chunks;
-    const int *n_refpanel;
-    double *win_ll;
-};
-
-void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
-                        uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 // events a dispatch updates with its own start / stop time (either may be null)
 struct KernelEvents {
     hipEvent_t start = nullptr, stop = nullptr;
 };
+
+struct PopFinalArgs {
+    const WinConst *wconst;
+    const double *partial;      // [T][n_win][n_chunks][2], or per half chunk [T][n_win][2 * n_chunks][2] (halves = 1)
+    uint32_t n_win, n_chunks;
+    const int *n_refpanel;
+    double *win_ll;
+    uint32_t t_base = 0;        // first comparison individual of the launch
+    uint32_t halves = 0;        // 1: partial sums per half chunk (k_ld_mfma); a chunk's sum is half 0 + half 1
+};
+
+// ---- many comparison individuals against one panel: the G(x,t) sums as integer matrix products ----------
+// (ibdg_ld_mfma.hip; BASELINE.json configs[4]).  Groups of IBDG_TG comparison individuals.
+#define IBDG_TG 15
+struct MfmaArgs {
+    const uint32_t *t32;        // tile-transposed panel (PopArgs::t32)
+    uint32_t n_pairs, n_chunks;
+    const Seg *segs;
+    uint32_t n_segs;
+    const WinConst *wconst;     // [n_win + 1]
+    uint32_t n_win;
+    const uint32_t *run_begin;  // [n_runs + 1]
+    uint32_t n_runs, win_per_group;
+    uint32_t max_seg;           // most segments in one run (LDS sizing)
+    uint4 *aimg;                // [groups][n_segs][64] target operand of every segment (k_win_target_g)
+    uint4 *wc_slot;             // [groups][n_win][16] per target: 16<t0,cov> 16<t1,cov> 16(AT-<t0,alt>) 16(AT-<t1,alt>)
+    const PowEntry *pow_1me, *pow_eps;
+    uint32_t tab_len;
+    const uint32_t *targets;    // [T]
+    uint32_t t_base;            // first comparison individual of group 0 of this launch
+    uint32_t n_targets;         // comparison individuals of this launch (groups of IBDG_TG, the last may be short)
+    const double *base_weight;  // [lanes] background multiplicity without the comparison individual's exclusion
+    double *partial;            // [T][n_win][2 * n_chunks][2]
+};
+size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
+void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st);
+int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev);
+
+void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
+                        uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,

@@ -32,6 +32,7 @@
 // the unclamped binomial form (no DBL_MIN clamp, exact coefficients); otherwise the strict
 // multiplying kernel in ibdg_kernels.hip is used.
 #include "ibdg_kernels.h"
+#include "ibdg_ld_dev.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -93,13 +94,6 @@ __global__ __launch_bounds__(256) void k_transpose32(const uint64_t *__restrict_
     t32[((size_t)c * n_pairs + pair) * 64 + lane] = make_uint4(x[0], x[1], x[2], x[3]);
 }
 
-// the two haplotype words of one individual for one tile (wave-uniform address -> scalar load)
-__device__ __forceinline__ uint2 tile_words(const uint4 *__restrict__ base, uint32_t tile)
-{
-    const uint2 *p = reinterpret_cast<const uint2 *>(base + (size_t)(tile >> 1) * 64);
-    return p[tile & 1];
-}
-
 // ---------------------------------------------------------------------------
 // Per target, one thread per segment and eight per window: the LDS-ready images the --LD kernel stages
 // with plain contiguous copies -- every segment's 8-word record (IBDG_REC_WORDS, layout above) with the
@@ -152,46 +146,12 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
     }
 }
 
-// v + (v of the lane selected by a DPP control): the cross-lane step of a wave reduction with
-// data-parallel-primitive moves instead of ds_bpermute (no LDS traffic, no lane-index arithmetic).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return v + __hiloint2double(phi, plo);
-}
-
-// Sum over the 64 lanes in a fixed order; the total ends up in lane 63.
-__device__ __forceinline__ double wave_sum_to_lane63(double v)
-{
-    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a 16-lane row holds the row total
-    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // Two wave-wide sums at once through a 1 KiB LDS scratch of the wave: every lane writes its two
 // addends into two arrays of 64 doubles; lane 32j+p then reads elements 2p, 2p+1 of sum j (one
 // 16-byte read at scratch + 16*lane), adds them, and the 32 lanes of half j finish with five
 // exchange-and-add steps.  Every lane of the first half ends up with the total of the first sum,
 // every lane of the second half with the second.  Fixed order, no barrier (the scratch is the wave's
 // own and a wave's LDS operations execute in order); 6 VALU instructions for the two sums of a window.
-// v + (v of lane ^ X within the 32-lane half) through the LDS crossbar (ds_swizzle, bit mode): no VALU
-// move, no LDS memory -- the exchange is issued on the LDS port beside other waves' arithmetic.
-template <int X>
-__device__ __forceinline__ double swz_add(double v)
-{
-    constexpr int pat = (X << 10) | 0x1f;        // and 0x1f, or 0, xor X
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
-    return v + __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, uint32_t scr_r)
 {
     uint4 r;
@@ -212,46 +172,6 @@ __device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, 
     v = swz_add<8>(v);
     v = swz_add<16>(v);
     return v;
-}
-
-// (a << SH) + b and a * M + c as the single instructions they are (v_lshl_add_u32, v_mad_i32_i24): the
-// window end is a chain of these, and hipcc otherwise splits them into shifts and three-operand adds
-// (56 integer instructions per window where 38 do).  a < 2^23 for the multiply (exponents are sums of
-// at most a few thousand reads; the host does not offer this kernel beyond that).
-template <int SH>
-__device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b)
-{
-    uint32_t d;
-    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
-    return d;
-}
-
-template <int M>
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t c)
-{
-    static_assert(M >= -16 && M <= 64, "inline constants only; other multipliers go through mad24r");
-    uint32_t d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(M), "v"(c));
-    return d;
-}
-
-// the same with the multiplier in a register (-32 is not an inline constant)
-__device__ __forceinline__ uint32_t mad24r(uint32_t a, uint32_t m, uint32_t c)
-{
-    uint32_t d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(c));
-    return d;
-}
-
-// sum_k v[k] << k by Horner's rule: KP-1 instructions
-template <int KP>
-__device__ __forceinline__ uint32_t planes_sum(const uint32_t (&v)[KP])
-{
-    uint32_t s = v[KP - 1];
-#pragma unroll
-    for (int k = KP - 2; k >= 0; --k)
-        s = lshl_add<1>(s, v[k]);
-    return s;
 }
 
 // Staging of the window constants: the table base each word indexes is added on the way into LDS
@@ -305,7 +225,6 @@ __device__ __forceinline__ uint4 stage_wc_base(uint4 v, uint32_t i, uint32_t tab
 // per-chunk partial; k_ld_finalize adds the chunks (one wave per window, same fixed order),
 // applies the mantissa of K' and divides.
 // ---------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void;
 
 
 // Issue and wait in ONE statement: an asm output must be final when the statement ends,
@@ -320,23 +239,6 @@ __device__ __forceinline__ void lds_fetch(uint4 &h0, uint4 &h1, uint2 &x, uint32
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(h0), "=&v"(h1), "=&v"(x)
                  : "v"(rec_addr), "v"(x_addr)
-                 : "memory");
-}
-
-__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr)
-{
-    uint4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
-__device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, uint32_t addr1)
-{
-    asm volatile("ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %3\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w0), "=&v"(w1)
-                 : "v"(addr0), "v"(addr1)
                  : "memory");
 }
 
@@ -359,14 +261,6 @@ __device__ __forceinline__ void lds_read_pow10(uint4 (&p)[10], const uint32_t (&
                  : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
                    "v"(ad[8]), "v"(ad[9])
                  : "memory");
-}
-
-// rho^E2 * sigma^E3 * 2^eK from two table entries {m (2 words), e, pad}; the mantissa of K' is
-// applied once per window in k_ld_finalize
-__device__ __forceinline__ double ld_value(int eK, const uint4 &p1, const uint4 &p2)
-{
-    const double m1 = __hiloint2double((int)p1.y, (int)p1.x), m2 = __hiloint2double((int)p2.y, (int)p2.x);
-    return __builtin_ldexp(m1 * m2, eK + (int)p1.z + (int)p2.z);
 }
 
 // The counting itself is written in assembly, one statement per group of (mask, count) pairs, for the sake of ONE
@@ -775,23 +669,6 @@ __device__ __forceinline__ void lds_fetch_mt(uint4 &h0, uint4 &h1, uint4 &h2, ui
                  : "memory");
 }
 
-__device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad)[8])
-{
-    asm volatile("ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %10\n\t"
-                 "ds_read_b128 %3, %11\n\t"
-                 "ds_read_b128 %4, %12\n\t"
-                 "ds_read_b128 %5, %13\n\t"
-                 "ds_read_b128 %6, %14\n\t"
-                 "ds_read_b128 %7, %15\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]),
-                   "=&v"(p[7])
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-                 : "memory");
-}
-
 // One segment for TB comparison individuals (FIRST as in IBDG_SEGMENT of k_ld_popcount)
 #define IBDG_SEGMENT_MT(FIRST)                                                                                     \
     {                                                                                                           \
@@ -1018,13 +895,24 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
     if (w >= a.n_win)
         return;
     const unsigned lane = threadIdx.x & 63;
-    const unsigned t = blockIdx.y;
-    const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks;
+    const unsigned t = blockIdx.y + a.t_base;
     double t0 = 0.0, t1 = 0.0;
-    for (uint32_t c = lane; c < a.n_chunks; c += 64) {
-        const double2 v = p[c];
-        t0 += v.x;
-        t1 += v.y;
+    if (a.halves) {
+        // k_ld_mfma sums 32 individuals per wave: a chunk's sum is (individuals 0..31) + (32..63), the last
+        // addition of the 64-lane tree of wave_sum2
+        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks * 2;
+        for (uint32_t c = lane; c < a.n_chunks; c += 64) {
+            const double2 v = p[2 * c], u = p[2 * c + 1];
+            t0 += v.x + u.x;
+            t1 += v.y + u.y;
+        }
+    } else {
+        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks;
+        for (uint32_t c = lane; c < a.n_chunks; c += 64) {
+            const double2 v = p[c];
+            t0 += v.x;
+            t1 += v.y;
+        }
     }
     t0 = wave_sum_to_lane63(t0);
     t1 = wave_sum_to_lane63(t1);

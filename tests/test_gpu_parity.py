@@ -282,6 +282,7 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
         with E.Engine(0, 0.02, M) as eng:
             eng.set_option("ld_variant", 2)
             eng.set_option("multi_target", mt)
+            eng.set_option("mfma_targets", 0)        # T >= 8 would go through k_ld_mfma (next test)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, 100)
             eng.run(targets, ld=True, bg_count=bg, pu_id=targets[1])
@@ -294,6 +295,45 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
         res = oracle.compare(alle, nr, na, targets[i], window=100, ld=True, max_cov=M,
                              refids=np.repeat(np.arange(N), bg), pu_id=targets[1])
         assert_ld_close(got[1][i][1][:, :2], res["win"][:, :2], f"M={M} target {targets[i]}")
+
+
+@pytest.mark.parametrize("N,L,W,M,cov,T,tmin", [(150, 2600, 100, 20, 2.0, 9, 8), (150, 2600, 100, 40, 9.0, 17, 8),
+                                                (70, 900, 7, 20, 2.0, 31, 8), (200, 500, 64, 3, 1.0, 23, 8),
+                                                (3, 60, 2, 20, 2.0, 3, 1), (33, 700, 30, 20, 2.0, 33, 8),
+                                                (300, 1500, 100, 50, 14.0, 15, 8)])
+def test_many_comparison_individuals_through_the_matrix_cores(oracle, N, L, W, M, cov, T, tmin):
+    """T >= 8: groups of 15 comparison individuals go through k_ld_mfma (the G(x,t) sums as integer matrix
+    products, 32 background individuals per wave), what is left through the counting kernels -- every bit
+    as with one comparison individual per workgroup, and the oracle's values within the bar."""
+    rng = np.random.default_rng(900 + N + T)
+    f = rng.beta(0.4, 1.0, size=L).clip(1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
+    bg = rng.integers(0, 3, size=N).astype(np.uint8)
+    if N == 3:
+        bg[:] = 1
+    got = {}
+    for mfma in (1, 0):
+        with E.Engine(0, 0.02, M) as eng:
+            eng.set_option("ld_variant", 2)
+            eng.set_option("mfma_targets", mfma)
+            eng.set_option("mfma_min", tmin)
+            eng.set_option("multi_target", mfma)         # the comparison runs: one individual per workgroup
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, W)
+            eng.run(targets, ld=True, bg_count=bg, pu_id=targets[1])
+            assert eng.last_ld_variant() == 2
+            got[mfma] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(T)]
+    for i, t in enumerate(targets):
+        assert_bits(got[1][i][0], got[0][i][0], f"site target {t}")
+        assert_bits(got[1][i][1], got[0][i][1], f"window target {t} (#{i} of {T})")
+    for i in (0, T // 2, T - 1):
+        res = oracle.compare(alle, nr, na, targets[i], window=W, ld=True, max_cov=M,
+                             refids=np.repeat(np.arange(N), bg), pu_id=targets[1])
+        assert_ld_close(got[1][i][1][:, :2], res["win"][:, :2], f"N={N} M={M} target {targets[i]}")
 
 
 @pytest.mark.parametrize("N,L,W,M,cov", [(70, 900, 100, 20, 2.0), (200, 500, 7, 40, 9.0), (131, 400, 64, 3, 1.0), (3, 60, 2, 20, 2.0)])

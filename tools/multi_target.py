@@ -8,7 +8,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 Ts = [int(a) for a in sys.argv[2:]] or [1, 4, 16, 64]
 dev = torch.device("cuda", 0)
 panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
-eng = ibdgem_amd.Engine(0, 0.02, 20)
+eng = ibdgem_amd.Engine(0, 0.02, 20, lib_path=os.environ.get("IBDG_LIB") or None)
 for kv in os.environ.get("IBDG_OPTS", "").split(","):
     if kv:
         k, v = kv.split("=")
