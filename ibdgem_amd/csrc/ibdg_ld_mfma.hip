@@ -20,8 +20,8 @@
 // Work split: a wave = 32 background individuals (half a chunk of the transposed panel) x one run of
 // windows x one group of IBDG_TG = 15 comparison individuals; 8 waves per workgroup.
 //   per segment ((window, 32-row tile), as in k_ld_popcount):
-//     B operand: the lane's individual's two tile words, 16 rows per lane half, expanded bit -> byte through
-//                a 256-entry table in LDS (4 reads of 8 bytes);
+//     B operand: the lane's individual's two tile words, 16 rows per lane half, bit -> byte by a shift and the
+//                mask 0x01010101 per dword (rows 4 kb + d + 8 j; a 256-entry table in LDS was slower);
 //     A operand: 16 bytes per lane of the segment's target image (k_win_target_g: weight of row r for target
 //                haplotype m, rows outside the window 0), a coalesced 1 KiB load one segment ahead;
 //     two MFMAs (x0 and x1) accumulate into 2 x 16 registers;  C(x0 & x1) by and + popcount as before.
@@ -52,14 +52,12 @@ constexpr uint32_t PSEUDO = 15;      // the slot whose two rows are the weights:
 // the product, i.e. target-haplotype rows 2 slot, 2 slot + 1 of:
 __device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t i) { return 4 * (i >> 1) + 2 * h + (i & 1); }
 
-// four bits -> four bytes (bit j -> byte j)
-__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
-
 // ---------------------------------------------------------------------------
 // Per group of comparison individuals: (1) the A operand of every segment,
 //     aimg[group][segment][lane l] = 16 bytes: row m = l & 31 (slot m >> 1, target haplotype m & 1),
-//     byte j = weight of tile row 16 (l >> 5) + j:  cov_r where the target haplotype carries the alt allele
-//     on a row of the segment, else 0; slot 15: cov_r (row 30) and alt_r (row 31) themselves;
+//     byte j of dword d = weight of tile row 4 (l >> 5) + d + 8 j (the order in which a shift and the mask
+//     0x01010101 take the background bits out of a tile word):  cov_r where the target haplotype carries the
+//     alt allele on a row of the segment, else 0; slot 15: cov_r (row 30) and alt_r (row 31) themselves;
 // (2) per window and slot the four table offsets 16<t0,cov> 16<t1,cov> 16(AT-<t0,alt>) 16(AT-<t1,alt>)
 //     (k_win_target's window constants).
 // ---------------------------------------------------------------------------
@@ -83,14 +81,14 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
             const uint2 w = tile_words(tt, S.tile);
             sel = th ? w.y : w.x;
         }
-        sel = (sel >> (16 * kb)) & 0xffffu;
+        sel >>= 4 * kb;
         const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24, np = ncov > nalt ? ncov : nalt;
         uint32_t out[4] = {0, 0, 0, 0};
         for (uint32_t k = 0; k < np; ++k) {
-            const uint32_t f = ((use_alt ? S.alt[k] : S.cov[k]) >> (16 * kb)) & sel;
+            const uint32_t f = ((use_alt ? S.alt[k] : S.cov[k]) >> (4 * kb)) & sel;
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                out[w] += spread4((f >> (4 * w)) & 0xfu) << k;          // weights <= 127: no carry between bytes
+            for (int d = 0; d < 4; ++d)
+                out[d] += ((f >> d) & 0x01010101u) << k;                // weights <= 127: no carry between bytes
         }
         a.aimg[((size_t)grp * a.n_segs + s) * 64 + l] = make_uint4(out[0], out[1], out[2], out[3]);
     }
@@ -185,11 +183,11 @@ __device__ __forceinline__ double reduce16_halves(const double (&v)[16], uint32_
     return z;
 }
 
-// LDS per workgroup: window constants (16 B + 16 slots x 16 B per window), the two power tables, the
-// bit -> byte table, the run's segment records
+// LDS per workgroup: window constants (16 B + 16 slots x 16 B per window), the two power tables,
+// the run's segment records
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
 {
-    return (size_t)win_per_group * 17 * 16 + (size_t)tab_len * 32 + 256 * 8 + (size_t)max_seg * 32;
+    return (size_t)win_per_group * 17 * 16 + (size_t)tab_len * 32 + (size_t)max_seg * 32;
 }
 
 __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
@@ -208,8 +206,7 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
     uint4 *wcc = reinterpret_cast<uint4 *>(smem);                  // [win_per_group] eK, 16 AT + rho table, sigma table
     uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][16] per slot
     uint4 *tab = wcs + (size_t)a.win_per_group * 16;                // rho^n then sigma^n
-    uint2 *lut = reinterpret_cast<uint2 *>(tab + 2 * (size_t)a.tab_len);
-    uint4 *rec = reinterpret_cast<uint4 *>(lut + 256);              // [max_seg][2] tile, cov planes | the first six cov masks
+    uint4 *rec = tab + 2 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
@@ -229,8 +226,6 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
     for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
         tab[i] = i < a.tab_len ? reinterpret_cast<const uint4 *>(a.pow_1me)[i]
                                : reinterpret_cast<const uint4 *>(a.pow_eps)[i - a.tab_len];
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
-        lut[i] = make_uint2(spread4(i & 15), spread4(i >> 4));
     // the run's segments: nothing in the loops below goes through the scalar path (a scalar load per segment
     // and its wait cost more than the segment's arithmetic)
     for (uint32_t i = threadIdx.x; i < seg1 - seg0; i += blockDim.x) {
@@ -257,7 +252,7 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
     }
     const uint4 *xt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64 + 32 * (hc & 1) + n;   // + pair * 64
     const uint4 *ai = a.aimg + (size_t)grp * a.n_segs * 64 + lane;                                              // + segment * 64
-    const uint32_t sh = 16 * h;
+    const uint32_t sh = 4 * h;
     uint32_t m32 = (uint32_t)-32;
     asm volatile("" : "+v"(m32));
 
@@ -304,9 +299,13 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
                 xq[PF - 1] = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
                 aq[PF - 1] = ai[(size_t)(s + PF) * 64];
             }
+            // B operand: byte j of dword d of lane half kb = the individual's bit of row 4 kb + d + 8 j -- one shift
+            // and one mask per dword, no table
             const uint32_t b0 = x.x >> sh, b1 = x.y >> sh;
-            const uint2 l0 = lut[b0 & 0xff], l1 = lut[(b0 >> 8) & 0xff], l2 = lut[b1 & 0xff], l3 = lut[(b1 >> 8) & 0xff];
-            const v4i B0 = {(int)l0.x, (int)l0.y, (int)l1.x, (int)l1.y}, B1 = {(int)l2.x, (int)l2.y, (int)l3.x, (int)l3.y};
+            const v4i B0 = {(int)(b0 & 0x01010101u), (int)((b0 >> 1) & 0x01010101u), (int)((b0 >> 2) & 0x01010101u),
+                            (int)((b0 >> 3) & 0x01010101u)};
+            const v4i B1 = {(int)(b1 & 0x01010101u), (int)((b1 >> 1) & 0x01010101u), (int)((b1 >> 2) & 0x01010101u),
+                            (int)((b1 >> 3) & 0x01010101u)};
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
             const uint32_t hom = x.x & x.y;
