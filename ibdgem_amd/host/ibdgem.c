@@ -1236,7 +1236,7 @@ static void *dev_start(void *arg)
     return NULL;
 }
 
-#define TARGET_BATCH 16      /* comparison individuals per engine call when their site lists coincide */
+#define TARGET_BATCH 30      /* comparison individuals per engine call when their site lists coincide: two groups of k_ld_mfma */
 #define DIE(...)                          \
     do {                                  \
         fprintf(stderr, __VA_ARGS__);     \

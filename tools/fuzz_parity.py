@@ -1,7 +1,7 @@
 """Randomised parity sweep (not part of the pytest tiers): many small random configurations of the
 engine against the oracle in one process -- panel width, rows, window, error rate, max coverage,
 depth, sparsity of the pileup, background multiplicities, -N exclusion, batches of comparison
-individuals, launch geometry options.  Prints one line per failure and a summary.
+individuals (the counting kernels and the matrix-core kernel), launch geometry options.  Prints one line per failure and a summary.
 
     python tools/fuzz_parity.py [n_cases] [seed]
 """
@@ -34,7 +34,7 @@ for case in range(n_cases):
     na = rng.binomial(c, f).astype(np.uint8)
     nr = (c - na).astype(np.uint8)
     keep = np.sort(rng.choice(L, size=max(1, int(L * rng.choice([1.0, 1.0, 0.5, 0.05]))), replace=False))
-    T = int(rng.choice([1, 1, 2, 4, 5, 9]))
+    T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40]))     # 8 and more: the matrix-core kernel (k_ld_mfma)
     T = min(T, N)
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
     bg = None if rng.random() < 0.5 else rng.integers(0, 3, size=N).astype(np.uint8)
@@ -46,7 +46,8 @@ for case in range(n_cases):
     opts = {}
     if rng.random() < 0.5:
         opts = {"ring_slots": int(rng.choice([2, 3, 4, 8])), "windows_per_wave": int(rng.choice([1, 2, 5, 16, 64])),
-                "guided_runs": int(rng.choice([0, 1, 4, 16])), "multi_target": int(rng.choice([0, 1]))}
+                "guided_runs": int(rng.choice([0, 1, 4, 16])), "multi_target": int(rng.choice([0, 1])),
+                "mfma_targets": int(rng.choice([0, 1, 1])), "mfma_min": int(rng.choice([1, 2, 8, 15]))}
     desc = f"case {case}: N={N} L={L} keep={len(keep)} W={W} eps={eps} M={M} cov={cov} T={T} bg={'y' if bg is not None else 'n'} pu={pu} variant={variant} {opts}"
     try:
         with E.Engine(0, eps, M) as eng:
