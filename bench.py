@@ -480,6 +480,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-program clocks (warm_e2e, cold_e2e)")
+    ap.add_argument("--no-many", action="store_true", help="skip the run over many comparison individuals")
+    ap.add_argument("--many-targets", type=int, default=60, help="comparison individuals of that run (configs[4] shape)")
     ap.add_argument("--prewarm-ms", type=float, default=80.0,
                     help="untimed steps before the warm-up steps until this much wall time has passed: the chip's clocks take "
                          "~30 ms of load to settle, more than a short --warmup at a fraction of a millisecond per step provides")
@@ -651,6 +653,21 @@ def main():
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
     up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov)
     up["first_call_ms"] = first_upload_ms
+    # BASELINE.json configs[4]'s shape on this rank's rows (not `value`): many comparison individuals in ONE ibdg_run
+    many = None
+    if world == 1 and not args.no_many:
+        many_t = [(args.target + 5 * i) % args.ids for i in range(args.many_targets)]
+        eng.run(many_t, ld=True)
+        best = None
+        for _ in range(3):
+            eng.run(many_t, ld=True)
+            ms = eng.last_run_ms()
+            best = ms if best is None or ms["total"] < best["total"] else best
+        many = {"comparison_individuals": len(many_t), "run_ms": best["total"], "ms_per_individual": best["total"] / len(many_t),
+                "site_individual_pairs_per_s": n_cov * len(many_t) / (best["total"] * 1e-3),
+                "note": "one ibdg_run over that many comparison individuals against the resident panel (device time, best of 3): "
+                        "groups of 15 through k_ld_mfma -- the sums that depend on the comparison individual as integer matrix "
+                        "products (DESIGN.md s4.2); per-site values and window products of all of them included"}
     eng.run(targets, ld=True)
     win_full = eng.window_ll(0) if rank == 0 else None
     ld_variant = eng.last_ld_variant()
@@ -723,8 +740,11 @@ def main():
             "results_to_host": d2h,
             "per_rank": per_rank,
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
+            "many_comparison_individuals": many,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
+        if many:
+            many["vs_one_per_run"] = ms_step / many["ms_per_individual"]        # against the step of one comparison individual
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N=1 only
             s = sample_rows
             eng.upload_sites(np.arange(s, dtype=np.uint32), n_ref[:s], n_alt[:s], args.window)
