@@ -351,7 +351,9 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
             ad[4] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[5] = mad24r(G10, m32, lshl_add<4>(C0, kc1));
             ad[6] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[7] = mad24r(G11, m32, lshl_add<4>(C1, kc1));
             uint4 pw[8];
-            lds_read_pow8(pw, ad);      // (two of the eight through the vector memory path instead: 30 % slower)
+            // (tried: two of the eight through the vector memory path, 30 % slower; plain C++ LDS loads that hipcc
+            // may schedule across comparison individuals instead of this statement with its own wait, 7 % slower)
+            lds_read_pow8(pw, ad);
             const double Q00 = ld_value(eK, pw[0], pw[1]);
             const double Q01 = ld_value(eK, pw[2], pw[3]);
             const double Q10 = ld_value(eK, pw[4], pw[5]);
