@@ -1221,13 +1221,16 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         }
         const size_t T_cnt = T - T_g;      // comparison individuals of the counting kernels: [T_g, T)
         const size_t n_grp = (c->opt_multi_target && mt_fits && T_cnt >= MT) ? T_cnt / MT : 0, T_one = T_cnt - n_grp * MT;
-        // target operands: 1 KiB per segment and group; groups go in batches of about 2 GiB of them
+        // target operands (1 KiB per segment and group) and partial sums (32 B per window, chunk and individual)
+        // exist for one batch of groups at a time: about 1 GiB of operands, eight groups at most
         size_t gg_batch = n_gg;
         if (n_gg) {
             const size_t per_group = (size_t)c->n_segs * 1024;
-            const size_t fit = per_group ? ((size_t)2 << 30) / per_group : n_gg;
-            gg_batch = fit < 1 ? 1 : (fit < n_gg ? fit : n_gg);
+            size_t fit = per_group ? ((size_t)1 << 30) / per_group : n_gg;
+            fit = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
+            gg_batch = fit < n_gg ? fit : n_gg;
         }
+        const size_t T_batch = gg_batch * TGs < T_g ? gg_batch * TGs : T_g;
         if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, T_one * (size_t)c->n_segs * 32) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
@@ -1235,7 +1238,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
             ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
             ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 256) ||
-            ensure(c, c->partial_h, T_g * (size_t)c->n_win * c->n_chunks * 32))
+            ensure(c, c->partial_h, T_batch * (size_t)c->n_win * c->n_chunks * 32))
             return 1;
         ibdg::PopArgs pa;
         pa.t32 = (const uint32_t *)c->t32.p;
@@ -1290,11 +1293,22 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.tab_len = pa.tab_len;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
-            ma.partial = (double *)c->partial_h.p;
+            ibdg::PopFinalArgs fh;
+            fh.wconst = pa.wconst;
+            fh.n_win = c->n_win;
+            fh.n_chunks = c->n_chunks;
+            fh.n_refpanel = (const int *)c->nrefpanel.p;
+            fh.win_ll = (double *)c->win_ll.p;
+            fh.halves = 1;
             for (size_t g0 = 0; g0 < n_gg; g0 += gg_batch) {
                 const size_t nb = n_gg - g0 < gg_batch ? n_gg - g0 : gg_batch;
                 ma.t_base = (uint32_t)(g0 * TGs);
                 ma.n_targets = (uint32_t)((T_g - g0 * TGs) < nb * TGs ? (T_g - g0 * TGs) : nb * TGs);
+                // the kernels index the partial sums by comparison individual: the batch's buffer, moved back by
+                // the individuals before it
+                ma.partial = (double *)c->partial_h.p - (size_t)ma.t_base * c->n_win * c->n_chunks * 4;
+                fh.partial = ma.partial;
+                fh.t_base = ma.t_base;
                 ibdg::launch_win_target_g(ma, (unsigned)nb, c->stream);
                 if (g0 == 0) {
                     // the second stream (per-site values, window products; high priority) starts behind these
@@ -1304,6 +1318,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 }
                 if (ibdg::launch_ld_mfma(ma, (unsigned)nb, c->stream, ibdg::KernelEvents()))
                     return fail(c, "[::] ERROR in ibdg_run: the matrix-core --LD kernel could not be launched");
+                ibdg::launch_ld_finalize(fh, ma.n_targets, c->stream, ibdg::KernelEvents());
             }
         }
         if (n_grp) {
@@ -1327,12 +1342,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         fa.n_chunks = c->n_chunks;
         fa.n_refpanel = (const int *)c->nrefpanel.p;
         fa.win_ll = (double *)c->win_ll.p;
-        if (T_g) {
-            fa.partial = (const double *)c->partial_h.p;
-            fa.t_base = 0;
-            fa.halves = 1;
-            ibdg::launch_ld_finalize(fa, (unsigned)T_g, c->stream, T_cnt ? ibdg::KernelEvents() : last);
-        }
         if (T_cnt) {
             fa.partial = pa.partial;
             fa.t_base = (uint32_t)T_g;

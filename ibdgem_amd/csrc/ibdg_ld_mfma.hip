@@ -329,6 +329,7 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
             lds_read2(p1, p2, lshl_add<4>(CH - (a0 + a1), kc.y), lshl_add<4>(mad24<-2>(CH, C0 + C1), kc.z));
             P2 = ld_value(eK, p1, p2);
         }
+        const uint32_t a0m = 0u - 16u * a0, a1m = 0u - 16u * a1, C0s = 16u * C0, C1s = 16u * C1;
         // (the slots' constants through the scalar path instead of LDS, both halves' and a select: 12 % slower)
         const uint32_t slot_addr = (uint32_t)(uintptr_t)(lds_void *)wcs + ((w - w0) * 16 + 2 * h) * 16;
         double sv[16];                                          // s0, s1 of the lane's eight comparison individuals
@@ -346,10 +347,12 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
             const uint32_t kc0 = kt.x, kc1 = kt.y, kb0 = kt.z, kb1 = kt.w;
             // pDg[At+hx] (:716-719): E3 = <t,cov> + Cx - 2 G(x,t), E2 = AT - <t,alt> - ax + G(x,t)
             uint32_t ad[8];
-            ad[0] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[1] = mad24r(G00, m32, lshl_add<4>(C0, kc0));
-            ad[2] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[3] = mad24r(G01, m32, lshl_add<4>(C1, kc0));
-            ad[4] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[5] = mad24r(G10, m32, lshl_add<4>(C0, kc1));
-            ad[6] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[7] = mad24r(G11, m32, lshl_add<4>(C1, kc1));
+            // (-16 a and 16 C are taken once per window: the sums below are plain additions, which issue at twice
+            // the rate of the shift-and-add forms)
+            ad[0] = lshl_add<4>(G00, kb0 + a0m);   ad[1] = mad24r(G00, m32, kc0 + C0s);
+            ad[2] = lshl_add<4>(G01, kb0 + a1m);   ad[3] = mad24r(G01, m32, kc0 + C1s);
+            ad[4] = lshl_add<4>(G10, kb1 + a0m);   ad[5] = mad24r(G10, m32, kc1 + C0s);
+            ad[6] = lshl_add<4>(G11, kb1 + a1m);   ad[7] = mad24r(G11, m32, kc1 + C1s);
             uint4 pw[8];
             // (tried: two of the eight through the vector memory path, 30 % slower; plain C++ LDS loads that hipcc
             // may schedule across comparison individuals instead of this statement with its own wait, 7 % slower)
