@@ -1426,7 +1426,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
     // (not when the alt counts are recounted in this run: the second stream's chain count -> per-site -> products is
     // then the longer one of the two, and its short kernels should be short)
-    const bool shadow = ld_mode && !recount;
+    // (the matrix-core kernel leaves half of the wave slots free: beside it they run in their fast forms)
+    const bool shadow = ld_mode && !recount && !s2_after_prep;
     unsigned site_blocks = 0;
     if (shadow && c->opt_site_blocks > 0)
         site_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));

@@ -18,7 +18,7 @@
 // (tests: a batched run equals single runs bit for bit).
 //
 // Work split: a wave = 32 background individuals (half a chunk of the transposed panel) x one run of
-// windows x one group of IBDG_TG = 15 comparison individuals; 8 waves per workgroup.
+// windows x one group of IBDG_TG = 15 comparison individuals; 4 waves per workgroup.
 //   per segment ((window, 32-row tile), as in k_ld_popcount):
 //     B operand: the lane's individual's two tile words, 16 rows per lane half, bit -> byte by a shift and the
 //                mask 0x01010101 per dword (rows 4 kb + d + 8 j; a 256-entry table in LDS was slower);
@@ -190,13 +190,20 @@ size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_
     return (size_t)win_per_group * 17 * 16 + (size_t)tab_len * 32 + (size_t)max_seg * 32;
 }
 
-__global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
+#ifndef IBDG_MFMA_WAVES
+#define IBDG_MFMA_WAVES 4           /* waves = half chunks per workgroup (8: 3 % slower; 5 or 6 waves per SIMD spill) */
+#endif
+#ifndef IBDG_MFMA_WAVES_PER_EU
+#define IBDG_MFMA_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(64 * IBDG_MFMA_WAVES) __attribute__((amdgpu_waves_per_eu(IBDG_MFMA_WAVES_PER_EU, IBDG_MFMA_WAVES_PER_EU)))
+void k_ld_mfma(MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     const unsigned grp = blockIdx.z;
-    const uint32_t n_half = 2 * a.n_chunks, n_hgroups = (n_half + 7) / 8;
+    const uint32_t n_half = 2 * a.n_chunks, n_hgroups = (n_half + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
     const uint32_t run = blockIdx.x / n_hgroups, hgroup = blockIdx.x - run * n_hgroups;
     const uint32_t w0 = a.run_begin[run], w1 = a.run_begin[run + 1];
     const uint32_t seg0 = a.wconst[w0].seg_begin, seg1 = a.wconst[w1].seg_begin;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(512) void k_ld_mfma(MfmaArgs a)
     }
     __syncthreads();
 
-    const uint32_t hc = hgroup * 8 + wave;                          // half chunk of this wave
+    const uint32_t hc = hgroup * IBDG_MFMA_WAVES + wave;                          // half chunk of this wave
     if (hc >= n_half)
         return;
     const uint32_t c = hc >> 1, n = lane & 31, h = lane >> 5;
@@ -388,8 +395,8 @@ int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelE
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ld_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
-    const uint32_t n_hgroups = (2 * a.n_chunks + 7) / 8;
-    hipExtLaunchKernelGGL(k_ld_mfma, dim3(a.n_runs * n_hgroups, 1, n_groups), dim3(512), (uint32_t)lds, st, ev.start,
+    const uint32_t n_hgroups = (2 * a.n_chunks + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
+    hipExtLaunchKernelGGL(k_ld_mfma, dim3(a.n_runs * n_hgroups, 1, n_groups), dim3(64 * IBDG_MFMA_WAVES), (uint32_t)lds, st, ev.start,
                           ev.stop, 0, a);
     return 0;
 }
