@@ -1145,7 +1145,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->prev_bg.assign(bg_count, bg_count + c->n_ids);
     }
 
-    bool use_pop = false, s2_after_prep = false;
+    bool use_pop = false, s2_after_prep = false, side_fast = false;
     if (ld_mode) {
         const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
         if (c->opt_variant == 2 && !can)
@@ -1321,6 +1321,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 ibdg::launch_ld_finalize(fh, ma.n_targets, c->stream, ibdg::KernelEvents());
             }
         }
+        // k_ld_mfma (4 waves per SIMD) leaves wave slots to the second stream: its kernels run in their fast forms
+        // (also with a few individuals left to the counting kernels: T = 16 5.5 ms against 6.0; beside
+        // k_ld_popcount_mt alone it makes no difference)
+        side_fast = n_gg > 0;
         if (n_grp) {
             ibdg::PopArgs pm = pa;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
@@ -1427,7 +1431,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // (not when the alt counts are recounted in this run: the second stream's chain count -> per-site -> products is
     // then the longer one of the two, and its short kernels should be short)
     // (the matrix-core kernel leaves half of the wave slots free: beside it they run in their fast forms)
-    const bool shadow = ld_mode && !recount && !s2_after_prep;
+    const bool shadow = ld_mode && !recount && !side_fast;
     unsigned site_blocks = 0;
     if (shadow && c->opt_site_blocks > 0)
         site_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
