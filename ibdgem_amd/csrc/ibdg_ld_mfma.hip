@@ -183,6 +183,23 @@ __device__ __forceinline__ double reduce16_halves(const double (&v)[16], uint32_
     return z;
 }
 
+// The same for eight values: lane n ends up with the total of value 4 (n & 1) + 2 (n >> 1 & 1) + (n >> 2 & 1).
+__device__ __forceinline__ double reduce8_halves(const double (&v)[8], uint32_t n)
+{
+    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4;
+    double u[4], x[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        u[k] = (b0 ? v[k + 4] : v[k]) + swz_get<1>(b0 ? v[k] : v[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        x[k] = (b1 ? u[k + 2] : u[k]) + swz_get<2>(b1 ? u[k] : u[k + 2]);
+    double y = (b2 ? x[1] : x[0]) + swz_get<4>(b2 ? x[0] : x[1]);
+    y = swz_add<8>(y);
+    y = swz_add<16>(y);
+    return y;
+}
+
 // LDS per workgroup: window constants (16 B + 16 slots x 16 B per window), the two power tables,
 // the run's segment records
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
@@ -266,6 +283,11 @@ void k_ld_mfma(MfmaArgs a)
     // where the lane's total of reduce16_halves goes: value 8 (n & 1) + 4 (n >> 1 & 1) + 2 (n >> 2 & 1) + (n >> 3 & 1) is
     // s0 / s1 (odd) of register pair value >> 1; lanes 0..15 of each half store
     const uint32_t val = 8 * (n & 1) + 4 * ((n >> 1) & 1) + 2 * ((n >> 2) & 1) + ((n >> 3) & 1);
+    // (eight-value path: value 4 (n & 1) + 2 (n >> 1 & 1) + (n >> 2 & 1) = register pair; lanes 0..7 store both sums)
+    const uint32_t val8 = 4 * (n & 1) + 2 * ((n >> 1) & 1) + ((n >> 2) & 1), st8_q = slot_of(h, val8);
+    const bool st8_ok = n < 8 && st8_q < cnt && st8_q != PSEUDO;
+    const size_t st8_row = (((size_t)(a.t_base + grp * TG + st8_q) * a.n_win) * n_half + hc) * 2;
+    const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
     const uint32_t st_q = slot_of(h, val >> 1);
     const bool st_ok = n < 16 && st_q < cnt && st_q != PSEUDO;
     const size_t st_row = (((size_t)(a.t_base + grp * TG + st_q) * a.n_win) * n_half + hc) * 2 + (val & 1);   // window 0
@@ -339,9 +361,8 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t a0m = 0u - 16u * a0, a1m = 0u - 16u * a1, C0s = 16u * C0, C1s = 16u * C1;
         // (the slots' constants through the scalar path instead of LDS, both halves' and a select: 12 % slower)
         const uint32_t slot_addr = (uint32_t)(uintptr_t)(lds_void *)wcs + ((w - w0) * 16 + 2 * h) * 16;
-        double sv[16];                                          // s0, s1 of the lane's eight comparison individuals
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) {
+        // ((Q00 + Q01) + Q10) + Q11 of comparison individual slot_of(h, i) (ibdgem.c:716-719, :744-745)
+        auto four_products = [&](uint32_t i) -> double {
             uint32_t G00 = (uint32_t)acc0[2 * i], G10 = (uint32_t)acc0[2 * i + 1];
             uint32_t G01 = (uint32_t)acc1[2 * i], G11 = (uint32_t)acc1[2 * i + 1];
             if (i == 7) {                       // the upper half's last pair is the weights' own rows
@@ -352,10 +373,10 @@ void k_ld_mfma(MfmaArgs a)
             }
             const uint4 kt = lds_read_b128(slot_addr + (4 * (i >> 1) + (i & 1)) * 16);      // slot_of(h, i)
             const uint32_t kc0 = kt.x, kc1 = kt.y, kb0 = kt.z, kb1 = kt.w;
-            // pDg[At+hx] (:716-719): E3 = <t,cov> + Cx - 2 G(x,t), E2 = AT - <t,alt> - ax + G(x,t)
-            uint32_t ad[8];
+            // pDg[At+hx]: E3 = <t,cov> + Cx - 2 G(x,t), E2 = AT - <t,alt> - ax + G(x,t)
             // (-16 a and 16 C are taken once per window: the sums below are plain additions, which issue at twice
             // the rate of the shift-and-add forms)
+            uint32_t ad[8];
             ad[0] = lshl_add<4>(G00, kb0 + a0m);   ad[1] = mad24r(G00, m32, kc0 + C0s);
             ad[2] = lshl_add<4>(G01, kb0 + a1m);   ad[3] = mad24r(G01, m32, kc0 + C1s);
             ad[4] = lshl_add<4>(G10, kb1 + a0m);   ad[5] = mad24r(G10, m32, kc1 + C0s);
@@ -368,14 +389,38 @@ void k_ld_mfma(MfmaArgs a)
             const double Q01 = ld_value(eK, pw[2], pw[3]);
             const double Q10 = ld_value(eK, pw[4], pw[5]);
             const double Q11 = ld_value(eK, pw[6], pw[7]);
-            const double wj = (excl >> i) & 1 ? 0.0 : wgt;
-            sv[2 * i] = wj * P2;                                          // :743
-            sv[2 * i + 1] = wj * (((Q00 + Q01) + Q10) + Q11);             // :744-745
+            return ((Q00 + Q01) + Q10) + Q11;
+        };
+        double s1[8];                                       // the IBD1 addends of the lane's eight comparison individuals
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i)
+            s1[i] = ((excl >> i) & 1 ? 0.0 : wgt) * four_products(i);          // :744-745
+        const double wP2 = wgt * P2;                        // :743
+        // The 32 individuals of the half chunk are summed in the tree of wave_sum2 (neighbours first).
+        if (!any_excl) {
+            // No lane of the wave is one of the group's comparison individuals (all but a few waves): the IBD0
+            // addends are the same for the eight of them -- one butterfly for that sum, the transposed reduction
+            // for the eight IBD1 sums only.
+            double s0 = wP2;
+            s0 = s0 + swz_get<1>(s0);
+            s0 = s0 + swz_get<2>(s0);
+            s0 = swz_add<4>(s0);
+            s0 = swz_add<8>(s0);
+            s0 = swz_add<16>(s0);
+            const double t1 = reduce8_halves(s1, n);
+            if (st8_ok)
+                *reinterpret_cast<double2 *>(a.partial + st8_row + (size_t)w * n_half * 2) = make_double2(s0, t1);
+        } else {
+            double sv[16];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
+                sv[2 * i] = (excl >> i) & 1 ? 0.0 : wP2;
+                sv[2 * i + 1] = s1[i];
+            }
+            const double tot = reduce16_halves(sv, n);
+            if (st_ok)
+                a.partial[st_row + (size_t)w * n_half * 2] = tot;
         }
-        // the 32 individuals of the half chunk, in the tree of wave_sum2 (neighbours first)
-        const double tot = reduce16_halves(sv, n);
-        if (st_ok)
-            a.partial[st_row + (size_t)w * n_half * 2] = tot;
     }
 }
 
