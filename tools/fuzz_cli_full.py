@@ -3,10 +3,12 @@ oracle/_ref/ibdgem, which travels with the snapshot): random small panels and pi
 rows, random flags (--LD in two of three cases, -v -D -M -F -f -w -e -c -p -A -B -N), then the full
 host program against the reference: every output file byte for byte after the command line.
 
-    python tools/fuzz_cli_full.py [n_cases] [seed] [--reference-order]
+    python tools/fuzz_cli_full.py [n_cases] [seed] [--reference-order] [--many-targets]
 
 With --reference-order the host is run in its reference-order mode, in which the --LD columns are
-bit-identical to the reference's, so that not even decimal ties can differ.
+bit-identical to the reference's, so that not even decimal ties can differ.  With --many-targets the
+panels have 17 or 40 individuals and 8 or more of them are comparison individuals, without -v / -D, so
+that the host program batches them and the engine takes them through its matrix-core kernel (k_ld_mfma).
 """
 import os, random, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -19,11 +21,12 @@ EXE = os.path.join(REPO, "ibdgem_amd", "host", "ibdgem")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 EXTRA = ["--reference-order"] if "--reference-order" in sys.argv[3:] else []
+MANY = "--many-targets" in sys.argv[3:]
 bad = 0
 compared = rows_compared = 0
 for case in range(n_cases):
     with tempfile.TemporaryDirectory() as d:
-        N = random.choice([1, 2, 5, 17, 40])
+        N = random.choice([17, 40]) if MANY else random.choice([1, 2, 5, 17, 40])
         L = random.randint(1, 250)
         names = [f"s{n}" for n in range(N)]
         pos = sorted(random.sample(range(100, 100 + 12 * L + 50), L))
@@ -55,8 +58,8 @@ for case in range(n_cases):
                 q = "I" * cov if cov else "*"
                 fh.write(f"{chrom}\t{p}\tN\t{cov}\t{bases}\t{q}\t{q}\n")
         args = ["-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup"]
-        if random.random() < 0.4: args += ["-v"]
-        if random.random() < 0.3: args += ["-D", random.choice(["0.5", "1.0", "3"])]
+        if random.random() < 0.4 and not MANY: args += ["-v"]
+        if random.random() < 0.3 and not MANY: args += ["-D", random.choice(["0.5", "1.0", "3"])]
         if random.random() < 0.4: args += ["-M", random.choice(["1", "3", "8", "30"])]
         if random.random() < 0.3: args += ["-F", random.choice(["0.9", "0.5"])]
         if random.random() < 0.3: args += ["-f", random.choice(["0.05", "0.3"])]
@@ -79,7 +82,7 @@ for case in range(n_cases):
                 fh.write("".join(n + "\n" for n in random.choices(names, k=random.randint(1, N))))
             args += ["-B", "bg.txt"]
         if random.random() < 0.67: args = ["--LD"] + args
-        targets = random.sample(names, random.randint(1, min(3, N)))
+        targets = random.sample(names, random.randint(8, N) if MANY else random.randint(1, min(3, N)))
         args += ["-s", ",".join(targets)]
         sq = args[args.index("-N") + 1] if "-N" in args else "UNKWN"
         out, out2 = os.path.join(d, "out"), os.path.join(d, "out2")
