@@ -139,8 +139,8 @@ struct ibdg_ctx {
     long opt_wpg = 16;     // windows per wave in the fast kernel (upper bound unless set explicitly)
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
-    long opt_mfma_targets = 1;   // 8 or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma)
-    long opt_mfma_min = 8;       // smallest (last) group worth a launch of its own
+    long opt_mfma_targets = 1;   // 5 or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma)
+    long opt_mfma_min = 5;       // smallest (last) group worth a launch of its own (5: 3.2 ms against 3.3 through the counting kernels)
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)
@@ -1206,7 +1206,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const size_t MT = (size_t)ibdg::ld_popcount_mt_width();
         const bool mt_fits = ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring,
                                                          1) <= 150 * 1024;
-        // Eight or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma); the
+        // Five or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma); the
         // last group may be short, fewer than mfma_min individuals take the counting kernels below.
         const size_t TGs = IBDG_TG;
         size_t n_gg = 0, T_g = 0;

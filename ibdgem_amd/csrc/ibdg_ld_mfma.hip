@@ -288,6 +288,7 @@ void k_ld_mfma(MfmaArgs a)
     const bool st8_ok = n < 8 && st8_q < cnt && st8_q != PSEUDO;
     const size_t st8_row = (((size_t)(a.t_base + grp * TG + st8_q) * a.n_win) * n_half + hc) * 2;
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
+    const uint32_t n_iter = 2 * ((cnt + 3) / 4);                   // register pairs that hold comparison individuals
     const uint32_t st_q = slot_of(h, val >> 1);
     const bool st_ok = n < 16 && st_q < cnt && st_q != PSEUDO;
     const size_t st_row = (((size_t)(a.t_base + grp * TG + st_q) * a.n_win) * n_half + hc) * 2 + (val & 1);   // window 0
@@ -392,9 +393,10 @@ void k_ld_mfma(MfmaArgs a)
             return ((Q00 + Q01) + Q10) + Q11;
         };
         double s1[8];                                       // the IBD1 addends of the lane's eight comparison individuals
+        // (a short group occupies the first register pairs only: slots 4j .. 4j+3 are pairs 2j, 2j+1 of the two halves)
 #pragma unroll
         for (uint32_t i = 0; i < 8; ++i)
-            s1[i] = ((excl >> i) & 1 ? 0.0 : wgt) * four_products(i);          // :744-745
+            s1[i] = i < n_iter ? ((excl >> i) & 1 ? 0.0 : wgt) * four_products(i) : 0.0;          // :744-745
         const double wP2 = wgt * P2;                        // :743
         // The 32 individuals of the half chunk are summed in the tree of wave_sum2 (neighbours first).
         if (!any_excl) {

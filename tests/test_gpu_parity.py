@@ -282,7 +282,7 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
         with E.Engine(0, 0.02, M) as eng:
             eng.set_option("ld_variant", 2)
             eng.set_option("multi_target", mt)
-            eng.set_option("mfma_targets", 0)        # T >= 8 would go through k_ld_mfma (next test)
+            eng.set_option("mfma_targets", 0)        # T >= 5 would go through k_ld_mfma (next test)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, 100)
             eng.run(targets, ld=True, bg_count=bg, pu_id=targets[1])
@@ -299,10 +299,11 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
 
 @pytest.mark.parametrize("N,L,W,M,cov,T,tmin", [(150, 2600, 100, 20, 2.0, 9, 8), (150, 2600, 100, 40, 9.0, 17, 8),
                                                 (70, 900, 7, 20, 2.0, 31, 8), (200, 500, 64, 3, 1.0, 23, 8),
-                                                (3, 60, 2, 20, 2.0, 3, 1), (33, 700, 30, 20, 2.0, 33, 8),
+                                                (3, 60, 2, 20, 2.0, 3, 1), (33, 700, 30, 20, 2.0, 33, 8), (90, 800, 100, 20, 2.0, 6, 5),
+                                                (90, 800, 100, 20, 2.0, 21, 5),
                                                 (300, 1500, 100, 50, 14.0, 15, 8)])
 def test_many_comparison_individuals_through_the_matrix_cores(oracle, N, L, W, M, cov, T, tmin):
-    """T >= 8: groups of 15 comparison individuals go through k_ld_mfma (the G(x,t) sums as integer matrix
+    """T >= 5 (mfma_min): groups of 15 comparison individuals go through k_ld_mfma (the G(x,t) sums as integer matrix
     products, 32 background individuals per wave), what is left through the counting kernels -- every bit
     as with one comparison individual per workgroup, and the oracle's values within the bar."""
     rng = np.random.default_rng(900 + N + T)

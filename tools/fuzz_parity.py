@@ -34,7 +34,7 @@ for case in range(n_cases):
     na = rng.binomial(c, f).astype(np.uint8)
     nr = (c - na).astype(np.uint8)
     keep = np.sort(rng.choice(L, size=max(1, int(L * rng.choice([1.0, 1.0, 0.5, 0.05]))), replace=False))
-    T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40]))     # 8 and more: the matrix-core kernel (k_ld_mfma)
+    T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40]))     # 5 and more: the matrix-core kernel (k_ld_mfma)
     T = min(T, N)
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
     bg = None if rng.random() < 0.5 else rng.integers(0, 3, size=N).astype(np.uint8)
