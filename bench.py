@@ -653,6 +653,26 @@ def main():
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
     up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov)
     up["first_call_ms"] = first_upload_ms
+    # BASELINE.json configs[1]'s shape on this rank's rows (not `value`): the non-LD step (per-site values + window products)
+    non_ld = None
+    if world == 1 and not args.no_many:
+        eng.set_option("async", 1)
+        for _ in range(100):
+            eng.run(targets, ld=False)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            eng.run(targets, ld=False)
+        eng.sync()
+        nl_ms = (time.perf_counter() - t0) / 200 * 1e3
+        eng.set_option("async", 0)
+        nl_k = {n: float(np.mean([eng.run_ms(i)[n] for i in range(16)])) for n in ("site", "window")}
+        nl_bytes = 4 + 0.25 + 24.24          # read counts + target alleles + three doubles (+ window results)
+        non_ld = {"ms_per_step": nl_ms, "rows_per_s": n_rows / (nl_ms * 1e-3), "k_site_ms": nl_k["site"],
+                  "k_window_prod_ms": nl_k["window"], "bytes_per_row": nl_bytes,
+                  "hbm_frac": nl_bytes * n_rows / (nl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "note": "non-LD comparison (per-row LIBD0/1/2 + window products, BASELINE.json configs[1] at this row count), "
+                          "queued steps, host wall clock; two short kernels, bound by launch and memory latency at this size"}
     # BASELINE.json configs[4]'s shape on this rank's rows (not `value`): many comparison individuals in ONE ibdg_run
     many = None
     if world == 1 and not args.no_many:
@@ -741,6 +761,7 @@ def main():
             "per_rank": per_rank,
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "many_comparison_individuals": many,
+            "non_ld": non_ld,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }
         if many:
