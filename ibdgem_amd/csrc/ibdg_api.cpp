@@ -1210,7 +1210,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // last group may be short, fewer than mfma_min individuals take the counting kernels below.
         const size_t TGs = IBDG_TG;
         size_t n_gg = 0, T_g = 0;
+        // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
+        const size_t group_bytes = (size_t)c->n_win * c->n_chunks * 32 * TGs + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 256;
         if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && c->n_pairs < (1u << 23) &&
+            group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
             n_gg = T / TGs;
             T_g = n_gg * TGs;
@@ -1227,6 +1230,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (n_gg) {
             const size_t per_group = (size_t)c->n_segs * 1024;
             size_t fit = per_group ? ((size_t)1 << 30) / per_group : n_gg;
+            const size_t fit_p = ((size_t)4 << 30) / ((size_t)c->n_win * c->n_chunks * 32 * TGs + 1);     // partial sums
+            fit = fit < fit_p ? fit : fit_p;
             fit = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
             gg_batch = fit < n_gg ? fit : n_gg;
         }
