@@ -65,33 +65,75 @@ namespace ibdg {
 // x0/x1 = first/second haplotype of individual 64*chunk+lane, bit j = row 32*tile + j.
 // A wave reads one tile pair as one fully coalesced 1 KiB global_load_dwordx4, and the four
 // pairs of an 8-tile "oct" are 4 KiB contiguous.  Tiles are padded to whole octs (zero bits).
-// One wave per (tile pair, chunk); the row words are wave-uniform, each lane extracts its
-// own individual's bit.
+//
+// One wave per (tile pair, chunk): lane j loads the chunk's two haplotype words of row 64 q + j (16 bytes;
+// the eight waves of a workgroup take eight neighbouring chunks, i.e. whole 128-byte pieces of the rows), and
+// the two 64 x 64 bit matrices (rows on lanes, individuals on bits) are transposed in registers by the
+// recursive block exchange: at block size s lane l and lane l ^ s swap the off-diagonal s x s blocks --
+//     l & s == 0:  w = (w & K) | (t << s & ~K),      l & s != 0:  w = (w & ~K) | (t >> s & K),
+// t = the partner's word, K = the bits whose index has bit s clear -- as ONE v_alignbit (a rotation by s or
+// 32 - s, whichever the lane needs) and ONE v_bfi per 32-bit word and step; the exchanges are a
+// v_permlane32_swap (s = 32), ds_swizzle (16, 4) and DPP moves (8, 2, 1).  ~65 vector instructions per KiB,
+// where the first version (every lane picking its bit out of 128 wave-uniform row words) spent ~400 and
+// read every row word through the scalar cache: 9.4 ms for the 2.56 GB panel then.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_transpose32(const uint64_t *__restrict__ panel,
+template <int S>
+__device__ __forceinline__ uint32_t partner_word(uint32_t w)
+{
+    if (S == 16 || S == 4)
+        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)w, (S << 10) | 0x1f);
+    constexpr int ctrl = S == 8 ? 0x128 /* row_ror:8 */ : (S == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* [1,0,3,2] */);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, ctrl, 0xf, 0xf, true);
+}
+
+template <int S>
+__device__ __forceinline__ uint32_t block_exchange(uint32_t w, uint32_t lane)
+{
+    constexpr uint32_t K = S == 16 ? 0x0000ffffu : S == 8 ? 0x00ff00ffu : S == 4 ? 0x0f0f0f0fu : S == 2 ? 0x33333333u : 0x55555555u;
+    const bool up = lane & S;
+    const uint32_t t = partner_word<S>(w);
+    const uint32_t rot = __builtin_amdgcn_alignbit(t, t, up ? S : 32 - S);      // t >> s (up) or t << s, as a rotation
+    const uint32_t keep = up ? ~K : K;
+    return (w & keep) | (rot & ~keep);                                           // v_bfi_b32
+}
+
+__global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict__ panel,
                                                      uint32_t stride, size_t n_rows,
                                                      uint32_t n_chunks, uint32_t n_pairs,
                                                      uint4 *__restrict__ t32)
 {
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
-    const unsigned c = blockIdx.y * 4 + wave;
+    const unsigned c = blockIdx.y * 8 + wave;
     if (c >= n_chunks)
         return;
     const uint32_t pair = blockIdx.x;
-    uint32_t x[4] = {0, 0, 0, 0};
-    const size_t r0 = (size_t)pair * 64;
-#pragma unroll 8
-    for (unsigned j = 0; j < 64; ++j) {
-        const size_t r = r0 + j;
-        if (r < n_rows) {
-            const uint64_t w0 = panel[r * stride + 2 * c], w1 = panel[r * stride + 2 * c + 1];
-            const uint32_t b0 = (uint32_t)((w0 >> lane) & 1u) << (j & 31);
-            const uint32_t b1 = (uint32_t)((w1 >> lane) & 1u) << (j & 31);
-            if (j < 32) { x[0] |= b0; x[1] |= b1; } else { x[2] |= b0; x[3] |= b1; }
-        }
+    const size_t r = (size_t)pair * 64 + lane;
+    uint4 w = make_uint4(0, 0, 0, 0);                 // {plane 0 lo, hi, plane 1 lo, hi} of row r
+    if (r < n_rows)
+        w = *reinterpret_cast<const uint4 *>(panel + r * stride + 2 * c);
+    // s = 32: the high halves of lanes 0..31 and the low halves of lanes 32..63 change places
+    {
+        auto p0 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);
+        w.x = p0[0];
+        w.y = p0[1];
+        auto p1 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);
+        w.z = p1[0];
+        w.w = p1[1];
     }
-    t32[((size_t)c * n_pairs + pair) * 64 + lane] = make_uint4(x[0], x[1], x[2], x[3]);
+#define IBDG_T_STEP(S)                       \
+    w.x = block_exchange<S>(w.x, lane);      \
+    w.y = block_exchange<S>(w.y, lane);      \
+    w.z = block_exchange<S>(w.z, lane);      \
+    w.w = block_exchange<S>(w.w, lane);
+    IBDG_T_STEP(16)
+    IBDG_T_STEP(8)
+    IBDG_T_STEP(4)
+    IBDG_T_STEP(2)
+    IBDG_T_STEP(1)
+#undef IBDG_T_STEP
+    // lane = individual now; w.x / w.y = rows 0..31 / 32..63 of the first haplotype, w.z / w.w of the second
+    t32[((size_t)c * n_pairs + pair) * 64 + lane] = make_uint4(w.x, w.z, w.y, w.w);
 }
 
 // ---------------------------------------------------------------------------
@@ -931,7 +973,7 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
 {
     if (n_pairs == 0)
         return;
-    hipLaunchKernelGGL(k_transpose32, dim3(n_pairs, (n_chunks + 3) / 4), dim3(256), 0, st, panel, stride,
+    hipLaunchKernelGGL(k_transpose32, dim3(n_pairs, (n_chunks + 7) / 8), dim3(512), 0, st, panel, stride,
                        n_rows, n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
 }
 
