@@ -1676,6 +1676,16 @@ int main(int argc, char **argv)
         free(w_first); free(w_last); free(w_ncov); free(win_ll);
         phase("per individual: output files");
     }
+#if !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
+    if (!getenv("IBDGEM_KEEP_TEARDOWN")) {
+        /* every output file is closed: leave without tearing the device contexts and the runtime down -- the driver
+         * reclaims the memory of a process that ends, and freeing 5 GB of it buffer by buffer plus the runtime's
+         * own exit handlers cost ~0.06 s of a 0.6 s run (the sanitizer builds keep the orderly way out) */
+        fprintf(stderr, "Run time: %f minutes.\n", ((double)(clock() - t_start) / CLOCKS_PER_SEC) / 60);
+        fflush(NULL);
+        _exit(EXIT_SUCCESS);
+    }
+#endif
     for (int d = 0; d < n_eng; ++d)
         ibdg_destroy(engs[d]);
     phase("engine shutdown");
