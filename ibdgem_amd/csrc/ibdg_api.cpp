@@ -1309,11 +1309,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 const size_t nb = n_gg - g0 < gg_batch ? n_gg - g0 : gg_batch;
                 ma.t_base = (uint32_t)(g0 * TGs);
                 ma.n_targets = (uint32_t)((T_g - g0 * TGs) < nb * TGs ? (T_g - g0 * TGs) : nb * TGs);
-                // the kernels index the partial sums by comparison individual: the batch's buffer, moved back by
-                // the individuals before it
-                ma.partial = (double *)c->partial_h.p - (size_t)ma.t_base * c->n_win * c->n_chunks * 4;
+                ma.partial = (double *)c->partial_h.p;          // the batch's individuals, the first one first
                 fh.partial = ma.partial;
                 fh.t_base = ma.t_base;
+                fh.p_t0 = ma.t_base;
                 ibdg::launch_win_target_g(ma, (unsigned)nb, c->stream);
                 if (g0 == 0) {
                     // the second stream (per-site values, window products; high priority) starts behind these

@@ -139,6 +139,7 @@ struct PopFinalArgs {
     double *win_ll;
     uint32_t t_base = 0;        // first comparison individual of the launch
     uint32_t halves = 0;        // 1: partial sums per half chunk (k_ld_mfma); a chunk's sum is half 0 + half 1
+    uint32_t p_t0 = 0;          // comparison individual whose partial sums come first in `partial`
 };
 
 // ---- many comparison individuals against one panel: the G(x,t) sums as integer matrix products ----------
@@ -162,7 +163,7 @@ struct MfmaArgs {
     uint32_t t_base;            // first comparison individual of group 0 of this launch
     uint32_t n_targets;         // comparison individuals of this launch (groups of IBDG_TG, the last may be short)
     const double *base_weight;  // [lanes] background multiplicity without the comparison individual's exclusion
-    double *partial;            // [T][n_win][2 * n_chunks][2]
+    double *partial;            // [individuals of this launch][n_win][2 * n_chunks][2], individual t_base first
 };
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st);

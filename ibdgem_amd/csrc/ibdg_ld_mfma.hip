@@ -286,12 +286,12 @@ void k_ld_mfma(MfmaArgs a)
     // (eight-value path: value 4 (n & 1) + 2 (n >> 1 & 1) + (n >> 2 & 1) = register pair; lanes 0..7 store both sums)
     const uint32_t val8 = 4 * (n & 1) + 2 * ((n >> 1) & 1) + ((n >> 2) & 1), st8_q = slot_of(h, val8);
     const bool st8_ok = n < 8 && st8_q < cnt && st8_q != PSEUDO;
-    const size_t st8_row = (((size_t)(a.t_base + grp * TG + st8_q) * a.n_win) * n_half + hc) * 2;
+    const size_t st8_row = (((size_t)(grp * TG + st8_q) * a.n_win) * n_half + hc) * 2;
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
     const uint32_t n_iter = 2 * ((cnt + 3) / 4);                   // register pairs that hold comparison individuals
     const uint32_t st_q = slot_of(h, val >> 1);
     const bool st_ok = n < 16 && st_q < cnt && st_q != PSEUDO;
-    const size_t st_row = (((size_t)(a.t_base + grp * TG + st_q) * a.n_win) * n_half + hc) * 2 + (val & 1);   // window 0
+    const size_t st_row = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2 + (val & 1);   // window 0
 
     uint32_t s = seg0;
     // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested PF

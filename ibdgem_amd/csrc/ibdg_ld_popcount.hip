@@ -942,14 +942,14 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
     if (a.halves) {
         // k_ld_mfma sums 32 individuals per wave: a chunk's sum is (individuals 0..31) + (32..63), the last
         // addition of the 64-lane tree of wave_sum2
-        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks * 2;
+        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)(t - a.p_t0) * a.n_win + w) * a.n_chunks * 2;
         for (uint32_t c = lane; c < a.n_chunks; c += 64) {
             const double2 v = p[2 * c], u = p[2 * c + 1];
             t0 += v.x + u.x;
             t1 += v.y + u.y;
         }
     } else {
-        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)t * a.n_win + w) * a.n_chunks;
+        const double2 *p = reinterpret_cast<const double2 *>(a.partial) + ((size_t)(t - a.p_t0) * a.n_win + w) * a.n_chunks;
         for (uint32_t c = lane; c < a.n_chunks; c += 64) {
             const double2 v = p[c];
             t0 += v.x;
