@@ -23,13 +23,16 @@
 //     B operand: the lane's individual's two tile words, 16 rows per lane half, bit -> byte by a shift and the
 //                mask 0x01010101 per dword (rows 4 kb + d + 8 j; a 256-entry table in LDS was slower);
 //     A operand: 16 bytes per lane of the segment's target image (k_win_target_g: weight of row r for target
-//                haplotype m, rows outside the window 0), a coalesced 1 KiB load one segment ahead;
+//                haplotype m, rows outside the window 0), a coalesced 1 KiB load two segments ahead;
 //     two MFMAs (x0 and x1) accumulate into 2 x 16 registers;  C(x0 & x1) by and + popcount as before.
 //   per window: result register pair i of lane half h holds G(x, t0), G(x, t1) of comparison individual
 //     slot(h, i) for the lane's background individual, so every lane finishes 8 (individual, comparison
-//     individual) pairs without any exchange: four table products each, the weights, and a 32-lane
-//     butterfly sum per half (two comparison individuals at a time).  The two halves of a chunk are added
-//     by k_ld_finalize (halves = 1) -- the last addition of the 64-lane tree.
+//     individual) pairs without any exchange: four table products each, the weights, and the sums over the 32
+//     lanes of each half by a transposed reduction (reduce8_halves / reduce16_halves: every value through the
+//     tree of wave_sum2).  The two halves of a chunk are added by k_ld_finalize (halves = 1) -- the last
+//     addition of the 64-lane tree.  Nothing in the loops goes through the scalar memory path: the run's
+//     segment records are staged into LDS once per workgroup (a scalar load per segment cost more than the
+//     segment's arithmetic).
 // Operand / result layout of the instruction: tools/ubench/mfma_i8_layout.hip (checked on the device).
 #include "ibdg_kernels.h"
 #include "ibdg_ld_dev.h"
