@@ -415,6 +415,15 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
                 "summary_equals_engine_windows_7digits": bool(same), "host_threads": int(threads),
                 "note": "ibdgem_amd/host/ibdgem --LD, packed-panel cache (2.56 GB) + legend + pileup text -> output files, "
                         "process start and device initialisation included, files in page cache, best of 2"}
+        # the same with 30 comparison individuals (one batch of the host program, two groups of k_ld_mfma): what a
+        # further individual costs end to end once the panel is on the device
+        many_names = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(30))
+        mbase = [a if a != f"ind{target}" else many_names for a in base]
+        os.makedirs(os.path.join(d, "o4"))
+        t_many = timed_run(mbase + ["-O", "o4", "--summary-only"], d)
+        warm["many_individuals"] = {"individuals": 30, "summary_only_s": t_many,
+                                    "s_per_further_individual": (t_many - t_sum) / 29,
+                                    "phases_s": run_phases(mbase + ["-O", "o4", "--summary-only"], d)}
         for fn in ("p.cache",):
             os.remove(os.path.join(d, fn))
         # ---- cold: text .hap of the first cold_rows rows

@@ -763,15 +763,6 @@ static unsigned cull(unsigned count, double cull_p)
     return kept;
 }
 
-static void print_ll(FILE *fp, double v, char sep)
-{
-    if (isnan(v))
-        fputs("-nan", fp);                 /* what x86 printf shows for the reference's 0/0 */
-    else
-        fprintf(fp, "%e", v);
-    fputc(sep, fp);
-}
-
 /* ---- per-site rows of the tab file, formatted by a team of threads ---------------------------
  * The reference prints one fprintf per row (src/ibdgem.c:731-733): 4M rows x 14 columns per
  * comparison individual.  Here the rows are cut into contiguous ranges, every thread formats its
@@ -1054,6 +1045,67 @@ static int write_rows_parallel(FILE *tab, fmt_job proto, size_t n, int threads)
     }
     for (int t = 0; t < threads; ++t)
         free(jobs[t].buf);
+    return rc;
+}
+
+/* ---- the rows of the summary file (:751-756), formatted by the same team ---------------------- */
+typedef struct {
+    size_t a, b;                         /* windows [a, b) */
+    const uint32_t *s_row, *w_first, *w_last, *w_ncov;
+    const double *win_ll;
+    char *buf;
+    size_t len;
+} sum_job;
+
+static void *fmt_summary(void *arg)
+{
+    sum_job *j = arg;
+    char *q = j->buf;
+    for (size_t w = j->a; w < j->b; ++w) {
+        q = put_u64(q, w + 1); *q++ = '\t';
+        q = put_u64(q, rows[j->s_row[j->w_first[w]]].pos); *q++ = '\t';
+        q = put_u64(q, rows[j->s_row[j->w_last[w]]].pos); *q++ = '\t';
+        q += fmt_ll(q, j->win_ll[3 * w], '\t');
+        q += fmt_ll(q, j->win_ll[3 * w + 1], '\t');
+        q += fmt_ll(q, j->win_ll[3 * w + 2], '\t');
+        q = put_u64(q, j->w_ncov[w]); *q++ = '\n';
+    }
+    j->len = (size_t)(q - j->buf);
+    return NULL;
+}
+
+/* 160 bytes hold any row: three integers of at most 20 digits, three numbers of at most 24 characters */
+static int write_summary_parallel(FILE *sum, sum_job proto, size_t n_win, int threads)
+{
+    sum_job jobs[64];
+    pthread_t tid[64];
+    int started[64] = {0};
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    const int team = n_win < 2048 ? 1 : threads;
+    char *all = malloc(n_win * 160 + 16);
+    if (!all)
+        return 1;
+    for (int t = 0; t < team; ++t) {
+        jobs[t] = proto;
+        jobs[t].a = n_win * (size_t)t / (size_t)team;
+        jobs[t].b = n_win * (size_t)(t + 1) / (size_t)team;
+        jobs[t].buf = all + jobs[t].a * 160;
+        jobs[t].len = 0;
+    }
+    for (int t = 0; t + 1 < team; ++t)
+        started[t] = pthread_create(&tid[t], NULL, fmt_summary, &jobs[t]) == 0;
+    for (int t = 0; t < team; ++t)
+        if (!started[t])
+            fmt_summary(&jobs[t]);
+    for (int t = 0; t + 1 < team; ++t)
+        if (started[t])
+            pthread_join(tid[t], NULL);
+    int rc = 0;
+    for (int t = 0; t < team; ++t)
+        if (fwrite(jobs[t].buf, 1, jobs[t].len, sum) != jobs[t].len)
+            rc = 1;
+    free(all);
     return rc;
 }
 
@@ -1503,12 +1555,29 @@ int main(int argc, char **argv)
         const uint32_t tgt = targets.idx[ti];
         const char *tname = ids.names[tgt];
         fprintf(stderr, "Running %s-vs-%s comparison...\n", opt_sq, tname);
-        unsigned long skipped = 0, final_total = 0, final_dist[128] = {0};
-        size_t n = 0;
-        for (size_t r = 0, ci = 0; r < n_rows; ++r) {
-            if (row_fate[r] == 0) {
-                if (rows[r].gt_failed)
+        /* Without -v and -D the site list does not depend on the comparison individual (:584, :627-628): it is
+         * built for the first one and kept -- 9 ms per individual at 4M rows, more than its engine time.  The
+         * reference's message for rows whose genotypes did not parse is repeated per individual as it prints it. */
+        static unsigned long skipped, final_total, final_dist[128];
+        static size_t n;
+        const int same_sites = !has_v && cull_p == 1.0 && ti > 0;
+        static size_t n_gt_failed;
+        if (same_sites) {
+            for (size_t r = 0; r < n_rows && n_gt_failed; ++r)
+                if (row_fate[r] == 0 && rows[r].gt_failed)
                     fprintf(stderr, "Failed to parse genotype fields at %lu. Skipping to next site.\n", rows[r].pos);
+        } else {
+            n_gt_failed = 0;
+            skipped = final_total = 0;
+            memset(final_dist, 0, sizeof final_dist);
+            n = 0;
+        }
+        for (size_t r = 0, ci = 0; r < n_rows && !same_sites; ++r) {
+            if (row_fate[r] == 0) {
+                if (rows[r].gt_failed) {
+                    fprintf(stderr, "Failed to parse genotype fields at %lu. Skipping to next site.\n", rows[r].pos);
+                    n_gt_failed++;
+                }
                 skipped++;
                 continue;
             }
@@ -1650,16 +1719,20 @@ int main(int argc, char **argv)
                 quit(1);
             }
         }
-        for (size_t w = 0; w < n_win; ++w) {
-            const unsigned long start = rows[s_row[w_first[w]]].pos, end = rows[s_row[w_last[w]]].pos;
-            if (opt_plan) {
-                printf("## WINDOW %zu\t%lu\t%lu\t%u\n", w + 1, start, end, w_ncov[w]);
-            } else {
-                fprintf(sum, "%zu\t%lu\t%lu\t", w + 1, start, end);
-                print_ll(sum, win_ll[3 * w], '\t');
-                print_ll(sum, win_ll[3 * w + 1], '\t');
-                print_ll(sum, win_ll[3 * w + 2], '\t');
-                fprintf(sum, "%u\n", w_ncov[w]);
+        if (opt_plan) {
+            for (size_t w = 0; w < n_win; ++w)
+                printf("## WINDOW %zu\t%lu\t%lu\t%u\n", w + 1, rows[s_row[w_first[w]]].pos, rows[s_row[w_last[w]]].pos,
+                       w_ncov[w]);
+        } else {
+            /* the summary rows (:751-756) through the program's own conversions, by the team of threads: with many
+             * comparison individuals per run the seven stdio calls per window were the longest item of an individual
+             * (25 ms of 33 at 35 000 windows) */
+            sum_job sj;
+            memset(&sj, 0, sizeof sj);
+            sj.s_row = s_row; sj.w_first = w_first; sj.w_last = w_last; sj.w_ncov = w_ncov; sj.win_ll = win_ll;
+            if (write_summary_parallel(sum, sj, n_win, opt_threads > 0 ? opt_threads : default_threads())) {
+                fprintf(stderr, "[::] ERROR writing the summary rows of %s.\n", tname);
+                quit(1);
             }
         }
         /* footer (:761-768) */
