@@ -1618,10 +1618,11 @@ int main(int argc, char **argv)
             }
         } else {
             /* one contiguous window range per GPU, evaluated concurrently, gathered in order */
-            size_t cuts[65];
+            static size_t cuts[65];                    /* kept with the site list */
             shard_job jobs[64];
             pthread_t th[64];
-            window_cuts(s_nr, s_na, n, (unsigned)opt_window, n_eng, cuts);
+            if (!same_sites)
+                window_cuts(s_nr, s_na, n, (unsigned)opt_window, n_eng, cuts);
             for (int d = 0; d < n_eng; ++d) {
                 shard_job *j = &jobs[d];
                 memset(j, 0, sizeof *j);
