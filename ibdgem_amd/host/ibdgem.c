@@ -866,10 +866,13 @@ static char *put_e6(char *d, double v)
         q = (long double)v * pow10_tab[350 + 6 - E];
     }
     /* q in [10^6, 10^7): seven digits.  Too close to a boundary to trust the last bits of q: printf decides. */
-    const long double fl = floorl(q), fr = q - fl;
-    if (!(q >= 1e6L + 1e-5L) || !(q < 1e7L - 1e-5L) || (fr > 0.5L - 1e-6L && fr < 0.5L + 1e-6L))
+    if (!(q >= 1e6L + 1e-5L) || !(q < 1e7L - 1e-5L))
         return d + sprintf(d, "%e", v);
-    unsigned long D = (unsigned long)fl + (fr > 0.5L ? 1u : 0u);
+    const unsigned long Dq = (unsigned long)q;             /* q > 0: truncation is the floor (no libm call) */
+    const long double fr = q - (long double)Dq;
+    if (fr > 0.5L - 1e-6L && fr < 0.5L + 1e-6L)
+        return d + sprintf(d, "%e", v);
+    unsigned long D = Dq + (fr > 0.5L ? 1u : 0u);
     if (D >= 10000000ul) {
         D /= 10;
         ++E;
