@@ -53,28 +53,49 @@ def algorithmic_bytes_per_site(n_ids, n_targets):
 
 
 # ----------------------------------------------------------------------------- synthetic data (GPU, torch = plumbing)
+def _block_generators(torch, dev, block, seed):
+    """Two streams per block: `g` for the panel's bits, `g2` for what the read counts need (the allele
+    frequencies, the comparison individual's own two bits per row, depth, reads).  Keeping them apart lets a
+    rank learn the read counts of ALL rows (for the window cut points) without generating the panel."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed * 1000003 + block)
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed((seed * 1000003 + block) ^ 0x5BD1E995)
+    return g, g2
+
+
+def gen_counts(torch, dev, block, seed):
+    """Rows [block*BLOCK_ROWS, +BLOCK_ROWS): allele frequency, the comparison individual's two alleles,
+    n_ref, n_alt -- a few bytes per row, no panel."""
+    _, g2 = _block_generators(torch, dev, block, seed)
+    R = BLOCK_ROWS
+    u = torch.rand(R, generator=g2, device=dev, dtype=torch.float64)
+    f = torch.clamp(u ** (1.0 / 0.3), 1e-3, 0.999).to(torch.float32)      # Beta(0.3, 1)
+    tb = torch.rand(R, 2, generator=g2, device=dev) < f[:, None]
+    a0 = tb[:, 0].to(torch.float32)
+    a1 = tb[:, 1].to(torch.float32)
+    cov = torch.poisson(torch.full((R,), 2.0, device=dev), generator=g2).clamp_(max=20)
+    p_alt = (a0 + a1) * 0.5 * (1 - 2 * 0.02) + 0.02          # g=0: eps, g=1: 0.5, g=2: 1-eps
+    n_alt = torch.binomial(cov, p_alt, generator=g2)
+    n_ref = cov - n_alt
+    return f, tb, n_ref.to(torch.uint8), n_alt.to(torch.uint8)
+
+
 def gen_block(torch, dev, block, n_ids, target, seed):
     """Rows [block*BLOCK_ROWS, +BLOCK_ROWS): packed panel words, n_ref, n_alt.  Deterministic in
     (seed, block), independent of how blocks are spread over ranks."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed * 1000003 + block)
+    g, _ = _block_generators(torch, dev, block, seed)
+    f, tb, n_ref, n_alt = gen_counts(torch, dev, block, seed)
     R = BLOCK_ROWS
     chunks = (n_ids + 63) // 64
-    u = torch.rand(R, generator=g, device=dev, dtype=torch.float64)
-    f = torch.clamp(u ** (1.0 / 0.3), 1e-3, 0.999).to(torch.float32)      # Beta(0.3, 1)
     bits = torch.rand(R, chunks * 64, 2, generator=g, device=dev) < f[:, None, None]
     bits[:, n_ids:, :] = False
+    bits[:, target, :] = tb                                  # the comparison individual is a panel member
     # [R][chunk][bit][plane] -> word[2*chunk+plane] bit
     b = bits.view(R, chunks, 64, 2).permute(0, 1, 3, 2).to(torch.int64)
     weights = (torch.ones(64, dtype=torch.int64, device=dev) << torch.arange(64, device=dev))
     words = (b * weights).sum(dim=-1).reshape(R, chunks * 2).contiguous()
-    a0 = bits[:, target, 0].to(torch.float32)
-    a1 = bits[:, target, 1].to(torch.float32)
-    cov = torch.poisson(torch.full((R,), 2.0, device=dev), generator=g).clamp_(max=20)
-    p_alt = (a0 + a1) * 0.5 * (1 - 2 * 0.02) + 0.02          # g=0: eps, g=1: 0.5, g=2: 1-eps
-    n_alt = torch.binomial(cov, p_alt, generator=g)
-    n_ref = cov - n_alt
-    return words, n_ref.to(torch.uint8), n_alt.to(torch.uint8)
+    return words, n_ref, n_alt
 
 
 def build_shard(torch, dev, row0, row1, n_ids, target, seed):
@@ -484,6 +505,17 @@ def traffic_bytes(args, world):
 
 
 # ----------------------------------------------------------------------------- main
+def launcher_command(n_ranks, argv):
+    """The command `python bench.py --gpus N` runs when nobody launched it under torch.distributed.run: one rank
+    per GPU of this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve) at a free port."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -513,6 +545,12 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child
+        # processes, before this process has imported torch or made any GPU call (it never does), hand rank 0's
+        # JSON line through (the children inherit stdout) and leave with the launcher's exit code
+        sys.exit(subprocess.run(launcher_command(args.gpus, sys.argv[1:])).returncode)
+
     import torch
     import torch.distributed as dist
     import ibdgem_amd
@@ -521,7 +559,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     # BENCH_FORCE_DEVICE / BENCH_BACKEND exist only to rehearse the multi-rank path on a one-GPU box
@@ -544,12 +582,9 @@ def main():
     if world > 1:
         nr_all, na_all = [], []
         for blk in range((L + BLOCK_ROWS - 1) // BLOCK_ROWS):
-            g = torch.Generator(device=dev)
-            # read counts need the target's alleles, i.e. the block's bits: generate and drop
-            w, nr, na = gen_block(torch, dev, blk, args.ids, args.target, args.seed)
+            _, _, nr, na = gen_counts(torch, dev, blk, args.seed)      # a few bytes per row; no panel bits
             nr_all.append(nr.cpu().numpy())
             na_all.append(na.cpu().numpy())
-            del w
         nr_all = np.concatenate(nr_all)[:L]
         na_all = np.concatenate(na_all)[:L]
         from ibdgem_amd.sharding import shard_rows
@@ -741,7 +776,7 @@ def main():
         out = {
             "metric": "SNP-sites/sec in --LD mode, chr1, 2504-indiv panel",
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_step, "clock": "step", "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"--LD, {L} SNP rows (synthetic chr1), {args.ids}-individual phased panel, "
                                    f"window {args.window}, 1 comparison individual (BASELINE.json configs[3])",
