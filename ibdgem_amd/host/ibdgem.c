@@ -6,9 +6,12 @@
  * What stays on the CPU is what the north star leaves there: option parsing, text parsing
  * and the integer row filter chain of compare_impute (reference src/ibdgem.c:572-630).
  * What the reference computes per row and per window in that loop (:632-667, :669-722,
- * :736-756) is one ibdg_run per batch of comparison individuals.  There is no CPU
- * implementation of that arithmetic here: without a HIP device the program stops with the
- * engine's error, except for --plan (below), which never needs the engine.
+ * :736-756) is one ibdg_run per batch of comparison individuals.  On a machine without a HIP
+ * device a non-LD run (BASELINE configs[0]: "plumbing, runs without a GPU") takes the per-row
+ * values and the window products from the library's own host twins of the reference's math seam
+ * (ibdg_pdg_table / ibdg_pdg_ibd0 / ibdg_pdg_ibd1, src/ibd-math.h:14-63) in the reference's
+ * sequential order (host_nonld below); an --LD run without a device stops with the engine's
+ * error -- the background-panel loop exists on the device only.
  *
  * Differences from the reference, all outside the BASELINE configs:
  *   - VCF input (-V) follows the IMPUTE semantics: any number of comparison individuals (the
@@ -1256,6 +1259,69 @@ static void *filter_rows(void *arg)
     return NULL;
 }
 
+/* ---- a non-LD comparison without a device (BASELINE configs[0]) -----------------------------------
+ * The per-row columns (src/ibdgem.c:632-651) from the library's host twins of find_pDgG / find_pDgf /
+ * find_pDgIBD1 -- the operations and the bits of the device kernel k_site -- and the window products
+ * multiplied in row order (:665-667), rows without reads left out (:657-663). */
+typedef struct {
+    size_t a, b;
+    const cand_t *cand;
+    const uint32_t *s_cand;
+    const uint8_t *s_nr, *s_na;
+    const double *pdg;          /* ibdg_pdg_table */
+    unsigned tgt;
+    double *site_af, *site_ll;
+} host_site_job;
+
+static void *host_site_rows(void *arg)
+{
+    host_site_job *j = arg;
+    const size_t d = (size_t)opt_max_cov + 1;
+    for (size_t i = j->a; i < j->b; ++i) {
+        const cand_t *c = &j->cand[j->s_cand[i]];
+        const double *p = j->pdg + ((size_t)j->s_nr[i] * d + j->s_na[i]) * 3;
+        const unsigned a0 = row_allele(c->row, j->tgt, 0), a1 = row_allele(c->row, j->tgt, 1);
+        j->site_af[i] = c->f;
+        j->site_ll[3 * i] = ibdg_pdg_ibd0(c->f, p[0], p[1], p[2]);
+        j->site_ll[3 * i + 1] = ibdg_pdg_ibd1(a0, a1, c->f, p[0], p[1], p[2]);
+        j->site_ll[3 * i + 2] = p[a0 + a1];                                  /* :643-651 */
+    }
+    return NULL;
+}
+
+static void host_nonld(const cand_t *cand, const uint32_t *s_cand, const uint8_t *s_nr, const uint8_t *s_na, size_t n,
+                       unsigned tgt, const double *pdg, int threads, double *site_af, double *site_ll,
+                       const uint32_t *w_first, const uint32_t *w_last, size_t n_win, double *win_ll)
+{
+    host_site_job jobs[64];
+    pthread_t th[64];
+    int T = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    if (n < 65536)
+        T = 1;
+    for (int t = 0; t < T; ++t) {
+        host_site_job *j = &jobs[t];
+        j->a = n * (size_t)t / (size_t)T; j->b = n * (size_t)(t + 1) / (size_t)T;
+        j->cand = cand; j->s_cand = s_cand; j->s_nr = s_nr; j->s_na = s_na; j->pdg = pdg; j->tgt = tgt;
+        j->site_af = site_af; j->site_ll = site_ll;
+        if (T == 1 || pthread_create(&th[t], NULL, host_site_rows, j) != 0) {
+            host_site_rows(j);
+            th[t] = pthread_self();
+        }
+    }
+    for (int t = 0; t < T; ++t)
+        if (!pthread_equal(th[t], pthread_self()))
+            pthread_join(th[t], NULL);
+    for (size_t w = 0; w < n_win; ++w) {
+        double s0 = 1.0, s1 = 1.0, s2 = 1.0;                                  /* :562 */
+        for (size_t i = w_first[w]; i <= w_last[w]; ++i) {
+            if (s_nr[i] + s_na[i] == 0)
+                continue;
+            s0 *= site_ll[3 * i]; s1 *= site_ll[3 * i + 1]; s2 *= site_ll[3 * i + 2];
+        }
+        win_ll[3 * w] = s0; win_ll[3 * w + 1] = s1; win_ll[3 * w + 2] = s2;
+    }
+}
+
 /* engine contexts created on a thread of their own while the main thread parses the inputs */
 typedef struct {
     int dev[64], n;
@@ -1473,11 +1539,25 @@ int main(int argc, char **argv)
     ibdg_ctx *engs[64];
     int n_eng = 0;
     uint32_t *alt_count = malloc((n_rows ? n_rows : 1) * sizeof *alt_count);
+    int host_math = 0;              /* no device and a non-LD run: the library's host twins do the arithmetic */
+    double *pdg_tab = NULL;
     if (!opt_plan) {
         /* the contexts were being created (device start-up, ~0.2 s) while the inputs were parsed */
         pthread_join(g_dev_thread, NULL);
         g_dev_started = 0;
         phase("device start (the part not hidden behind parsing)");
+        if (dev_job.n > 0 && !dev_job.eng[0] && !opt_ld && ibdg_device_count() == 0) {
+            const size_t d = (size_t)opt_max_cov + 1;
+            pdg_tab = malloc(d * d * 3 * sizeof *pdg_tab);
+            if (!pdg_tab || ibdg_pdg_table(opt_eps, opt_max_cov, pdg_tab))
+                DIE("[::] ERROR: cannot build the P(D|G) table.\n");
+            host_math = 1;
+            dev_job.n = 0;
+            fprintf(stderr, "No HIP device found: per-row and window likelihoods are computed on the host (non-LD runs only).\n");
+        }
+    }
+    const int no_engine = opt_plan || host_math;
+    if (!no_engine) {
         for (int d = 0; d < dev_job.n; ++d) {
             ibdg_ctx *e = dev_job.eng[d];
             if (!e)
@@ -1541,19 +1621,19 @@ int main(int argc, char **argv)
     /* ---- per comparison individual (:522-773) ------------------------------------------ */
     /* the arrays that cross the engine's boundary live in page-locked memory when a device is in use
      * (ibdg_host_alloc: copies at link speed, 45+ GB/s instead of ~17 through a staging buffer) */
-    const int pin = !opt_plan;
+    const int pin = !no_engine;
     uint32_t *s_row = io_alloc((n_cand ? n_cand : 1) * 4, pin), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
     uint8_t *s_nr = io_alloc(n_cand ? n_cand : 1, pin), *s_na = io_alloc(n_cand ? n_cand : 1, pin);
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
     /* the per-site values are only fetched for the per-site table: no 128 MB of page-locked memory for --summary-only */
-    const size_t n_site_out = opt_summary_only && !opt_plan ? 1 : (n_cand ? n_cand : 1);
+    const size_t n_site_out = opt_summary_only && !no_engine ? 1 : (n_cand ? n_cand : 1);
     double *site_af = io_alloc(n_site_out * 8, pin), *site_ll = io_alloc(n_site_out * 24, pin);
     if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("page-locked result arrays");
     /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
      * reads anew for each (src/ibdgem.c:584, :627-628) */
-    const int batchable = !opt_plan && !has_v && cull_p == 1.0;
+    const int batchable = !no_engine && !has_v && cull_p == 1.0;
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
         const char *tname = ids.names[tgt];
@@ -1604,7 +1684,7 @@ int main(int argc, char **argv)
         size_t n_win = 0;
         uint32_t *w_first = NULL, *w_last = NULL, *w_ncov = NULL;
         double *win_ll = NULL;
-        if (opt_plan) {
+        if (no_engine) {
             size_t covered = 0;
             for (size_t i = 0; i < n; ++i)
                 covered += (s_nr[i] + s_na[i]) > 0;
@@ -1618,6 +1698,11 @@ int main(int argc, char **argv)
                 w_last[w] = (uint32_t)i;
                 w_ncov[w]++;
                 k++;
+            }
+            if (host_math) {
+                win_ll = malloc((n_win + 1) * 24);
+                host_nonld(cand, s_cand, s_nr, s_na, n, tgt, pdg_tab, opt_threads > 0 ? opt_threads : default_threads(),
+                           site_af, site_ll, w_first, w_last, n_win, win_ll);
             }
         } else {
             /* one contiguous window range per GPU, evaluated concurrently, gathered in order */

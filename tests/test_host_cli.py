@@ -190,6 +190,74 @@ def test_pileup_parser_edge_cases(tmp_path):
     assert "Incorrect number of bases read in" in res.stderr
 
 
+# ------------------------------------------------------------------------------------------- no device (configs[0])
+def _run_no_device(args, cwd, out, expect_ok=True):
+    """The host program on a machine without a HIP device (none visible): non-LD runs take the per-row values and
+    window products from the library's host twins of the reference's math seam (reference src/ibd-math.h:14-63)."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", IBDGEM_KEEP_TEARDOWN="1")
+    res = subprocess.run([_exe()] + args + ["-O", str(out)], cwd=cwd, capture_output=True, text=True, env=env)
+    if expect_ok:
+        assert res.returncode == 0, res.stderr
+    return res
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_no_device_run_reproduces_the_reference_fixture_files(k, tmp_path):
+    """BASELINE configs[0]: supplementary/ibdgem-test, non-LD, IMPUTE input, without a GPU -- all 18 files
+    byte for byte (line 1 of the tab files, the echoed command, aside)."""
+    res = _run_no_device(["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", f"test{k}.pileup", "-N", f"sample{k}"],
+                         FIX_IN, tmp_path)
+    assert "computed on the host" in res.stderr
+    for t in (1, 2, 3):
+        for kind in ("tab", "summary"):
+            fn = f"sample{k}.sample{t}.{kind}.txt"
+            got = _read(str(tmp_path / fn))
+            want = _read(os.path.join(G.GOLD, "ibdgem-test", "output", fn))
+            if kind == "tab":
+                assert got[0].startswith("# Entered command: ") and got[0].endswith(" ")
+                got, want = got[1:], want[1:]
+            assert got == want, fn
+
+
+@pytest.mark.parametrize("tag,case", _syn_cases() + [("synV", c) for c in sorted(G.cases("synV")["cases"])])
+def test_no_device_run_on_synthetic_cases(tag, case, tmp_path):
+    """Non-LD cases: every output file equals the reference's.  --LD cases run here WITHOUT --LD: the per-site
+    table of the reference does not depend on --LD (src/ibdgem.c:731-733 prints ibd0/1/2 of the row), so their tab
+    files must still match; with --LD and no device the program stops with the engine's message."""
+    meta = G.cases(tag)
+    args = meta["base_args"] + meta["cases"][case]
+    ld = "--LD" in args
+    inp = os.path.join(G.GOLD, tag, "input")
+    if ld:
+        res = _run_no_device(args, inp, tmp_path, expect_ok=False)
+        assert res.returncode != 0 and "no HIP device" in res.stderr
+        args = [a for a in args if a != "--LD"]
+    _run_no_device(args, inp, tmp_path)
+    ref = os.path.join(G.GOLD, tag, case, "ref7")
+    for fn in sorted(os.listdir(ref)):
+        if ld and not fn.endswith(".tab.txt.gz"):
+            continue
+        got = _read(str(tmp_path / fn[:-3]))
+        want = _read(os.path.join(ref, fn))
+        if fn.endswith(".tab.txt.gz"):
+            got = got[1:]
+        assert got == want, f"{tag}/{case}/{fn}"
+
+
+def test_no_device_summary_only_and_threads(tmp_path):
+    meta = G.cases("synA")
+    args = meta["base_args"] + meta["cases"]["nonld_all_targets_w2"]
+    inp = os.path.join(G.GOLD, "synA", "input")
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    _run_no_device(args, inp, tmp_path / "a")
+    _run_no_device(args + ["--summary-only", "--threads", "3"], inp, tmp_path / "b")
+    names = sorted(os.listdir(tmp_path / "a"))
+    assert sorted(os.listdir(tmp_path / "b")) == [n for n in names if n.endswith(".summary.txt")]
+    for n in os.listdir(tmp_path / "b"):
+        assert _read(str(tmp_path / "a" / n)) == _read(str(tmp_path / "b" / n))
+
+
 # ------------------------------------------------------------------------------------------- GPU
 def _run_full(args, cwd, out):
     res = subprocess.run([_exe()] + args + ["-O", str(out)], cwd=cwd, capture_output=True, text=True)
