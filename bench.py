@@ -368,6 +368,24 @@ def write_pileup_and_legend(d, n_ref, n_alt, n_ids, rows):
             fh.write("".join([f"1\t{100 + 10 * i}\t{tails[key[i]]}" for i in range(a, min(rows, a + 500_000))]))
 
 
+def write_panel_cache(path, words_all, n_ids, st):
+    """The host program's packed-panel cache (ibdgem_amd/host/ingest.c): header naming the .hap file's size and
+    mtime | row-is-clean flags | alt-allele counts | packed rows, the last two on 4096-byte boundaries."""
+    import struct
+    rows = words_all.shape[0]
+    with open(path, "wb") as fh:
+        hdr = struct.pack("<8sIIQQQqq", b"IBDGPNL3", n_ids, 0, rows, words_all.shape[1], st.st_size,
+                          st.st_mtime_ns // 1_000_000_000, st.st_mtime_ns % 1_000_000_000)
+        fh.write(hdr)
+        fh.write(np.ones(rows, dtype=np.uint8).tobytes())
+        fh.write(b"\0" * (-(len(hdr) + rows) % 4096))
+        for a in range(0, rows, 500_000):
+            fh.write(np.bitwise_count(words_all[a:a + 500_000]).sum(axis=1, dtype=np.uint32).tobytes())
+        fh.write(b"\0" * (-(rows * 4) % 4096))
+        for a in range(0, rows, 500_000):
+            fh.write(np.ascontiguousarray(words_all[a:a + 500_000]).tobytes())
+
+
 def timed_run(cmd, cwd, repeat=2):
     best = None
     for _ in range(repeat):
@@ -411,14 +429,7 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
         with open(os.path.join(d, "p.hap"), "w") as fh:
             fh.write("placeholder: the packed-panel cache p.cache stands for the .hap text\n")
         st = os.stat(os.path.join(d, "p.hap"))
-        with open(os.path.join(d, "p.cache"), "wb") as fh:
-            hdr = struct.pack("<8sIIQQQqq", b"IBDGPNL2", n_ids, 0, rows, words_all.shape[1], st.st_size,
-                              st.st_mtime_ns // 1_000_000_000, st.st_mtime_ns % 1_000_000_000)
-            fh.write(hdr)
-            fh.write(np.ones(rows, dtype=np.uint8).tobytes())
-            fh.write(b"\0" * (-(len(hdr) + rows) % 4096))          # the rows start on a 4096-byte boundary (ingest.c)
-            for a in range(0, rows, 500_000):
-                fh.write(np.ascontiguousarray(words_all[a:a + 500_000]).tobytes())
+        write_panel_cache(os.path.join(d, "p.cache"), words_all, n_ids, st)
         base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", f"ind{target}", "--LD",
                 "-w", str(window), "--threads", threads, "--panel-cache", "p.cache"]
         os.makedirs(os.path.join(d, "o1"))
@@ -436,6 +447,15 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
                 "summary_equals_engine_windows_7digits": bool(same), "host_threads": int(threads),
                 "note": "ibdgem_amd/host/ibdgem --LD, packed-panel cache (2.56 GB) + legend + pileup text -> output files, "
                         "process start and device initialisation included, files in page cache, best of 2"}
+        # the same comparison spread over four engine contexts (--devices 0,0,0,0: all on THIS box's one GPU, so no
+        # speed-up is to be had; what it shows is the cost of the decomposition -- every context receives only the
+        # panel rows of its window range, all uploads at once -- and that the summary file does not change by a byte)
+        os.makedirs(os.path.join(d, "o5"))
+        t_four = timed_run(base + ["-O", "o5", "--summary-only", "--devices", "0,0,0,0"], d)
+        same4 = open(os.path.join(d, "o5", f"UNKWN.ind{target}.summary.txt"), "rb").read() == \
+            open(os.path.join(d, "o1", f"UNKWN.ind{target}.summary.txt"), "rb").read()
+        warm["four_contexts_one_gpu"] = {"summary_only_s": t_four, "summary_identical_to_one_context": bool(same4),
+                                         "phases_s": run_phases(base + ["-O", "o5", "--summary-only", "--devices", "0,0,0,0"], d)}
         # the same with 30 comparison individuals (one batch of the host program, two groups of k_ld_mfma): what a
         # further individual costs end to end once the panel is on the device
         many_names = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(30))

@@ -340,6 +340,7 @@ static char *arena;
 static size_t arena_len, arena_cap;
 static uint64_t *packed;
 static size_t row_words;
+static uint32_t *alt_count_h;            /* alt alleles per panel row, counted on the host (ingest.c) or read from the cache */
 
 static uint32_t arena_add(const char *s)
 {
@@ -581,10 +582,18 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
     size_t n_hap = 0;
     int rc = 1;
     if (cache_fn)
-        rc = ingest_cache_load(cache_fn, hap_fn, n_ids, &packed, &ok, &n_hap);
+        rc = ingest_cache_load(cache_fn, hap_fn, n_ids, &packed, &ok, &alt_count_h, &n_hap);
     if (rc) {
-        rc = ingest_hap(hap_fn, n_ids, opt_threads > 0 ? opt_threads : default_threads(), &packed, &ok, &n_hap);
-        if (!rc && cache_fn && ingest_cache_store(cache_fn, hap_fn, n_ids, packed, ok, n_hap))
+        const int team = opt_threads > 0 ? opt_threads : default_threads();
+        rc = ingest_hap(hap_fn, n_ids, team, &packed, &ok, &n_hap);
+        if (!rc) {
+            alt_count_h = malloc((n_hap ? n_hap : 1) * sizeof *alt_count_h);
+            if (!alt_count_h)
+                rc = 1;
+            else
+                ingest_alt_counts(packed, n_hap, n_ids, team, alt_count_h);
+        }
+        if (!rc && cache_fn && ingest_cache_store(cache_fn, hap_fn, n_ids, packed, ok, alt_count_h, n_hap))
             fprintf(stderr, "Could not write the panel cache %s (continuing without it).\n", cache_fn);
     }
     if (threaded)
@@ -701,6 +710,10 @@ static int read_genotypes_vcf(const char *vcf_fn, names_t *ids)
     }
     free(alle);
     ls_close(vcf);
+    alt_count_h = malloc((n_rows ? n_rows : 1) * sizeof *alt_count_h);
+    if (!alt_count_h)
+        return 1;
+    ingest_alt_counts(packed, n_rows, n_ids, 1, alt_count_h);
     return 0;
 }
 
@@ -1322,6 +1335,62 @@ static void host_nonld(const cand_t *cand, const uint32_t *s_cand, const uint8_t
     }
 }
 
+/* ---- the panel's way to the device(s) ---------------------------------------------------------------
+ * One thread per device, all at once.  With one site list for all comparison individuals (no -v, no -D)
+ * and several devices, a device receives only the panel rows of its window range (windows are independent,
+ * reference src/ibdgem.c:558-570) and its sites are numbered from the slice's first row;
+ * otherwise every device receives the whole panel.  The copies overlap the host's filter chain: the -F/-f
+ * filter takes its alt-allele counts from the host side (ingest.c), not from a device. */
+typedef struct {
+    ibdg_ctx *eng;
+    size_t r0, n;                /* panel rows [r0, r0 + n) */
+    unsigned n_ids;
+    const uint32_t *bg_idx;      /* --reference-order: the -B list in file order */
+    size_t bg_n;
+    int ref_order, has_B;
+    int failed;
+    pthread_t th;
+    int started;
+} upload_job;
+
+static void *upload_run(void *arg)
+{
+    upload_job *j = arg;
+    j->failed = 1;
+    if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
+        return NULL;
+    if (j->ref_order) {                                   /* background list in the -B file's order (:741) */
+        if (ibdg_set_option(j->eng, "ld_variant", 3) || (j->has_B && ibdg_set_background_order(j->eng, j->bg_idx, j->bg_n)))
+            return NULL;
+    }
+    j->failed = 0;
+    return NULL;
+}
+
+static void uploads_start(upload_job *u, int n)
+{
+    for (int d = 0; d < n; ++d) {
+        u[d].started = pthread_create(&u[d].th, NULL, upload_run, &u[d]) == 0;
+        if (!u[d].started)
+            upload_run(&u[d]);
+    }
+}
+
+/* returns the first device whose upload failed, or -1 */
+static int uploads_join(upload_job *u, int n)
+{
+    int bad = -1;
+    for (int d = 0; d < n; ++d) {
+        if (u[d].started) {
+            pthread_join(u[d].th, NULL);
+            u[d].started = 0;
+        }
+        if (u[d].failed && bad < 0)
+            bad = d;
+    }
+    return bad;
+}
+
 /* engine contexts created on a thread of their own while the main thread parses the inputs */
 typedef struct {
     int dev[64], n;
@@ -1538,7 +1607,6 @@ int main(int argc, char **argv)
     /* ---- engine: panel upload, alt counts back for the AF filter ---------------------- */
     ibdg_ctx *engs[64];
     int n_eng = 0;
-    uint32_t *alt_count = malloc((n_rows ? n_rows : 1) * sizeof *alt_count);
     int host_math = 0;              /* no device and a non-LD run: the library's host twins do the arithmetic */
     double *pdg_tab = NULL;
     if (!opt_plan) {
@@ -1557,33 +1625,36 @@ int main(int argc, char **argv)
         }
     }
     const int no_engine = opt_plan || host_math;
+    static upload_job ups[64];
+    int uploads_pending = 0;
+    /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
+     * reads anew for each (src/ibdgem.c:584, :627-628) */
+    const int batchable = !no_engine && !has_v && cull_p == 1.0;
+    int slice_mode = 0;             /* several devices and one site list: every device holds its window range's rows only */
     if (!no_engine) {
         for (int d = 0; d < dev_job.n; ++d) {
             ibdg_ctx *e = dev_job.eng[d];
             if (!e)
                 DIE("%s\n", dev_job.err[d] ? dev_job.err[d] : "[::] ERROR in ibdg_create");
-            if (ibdg_upload_panel(e, packed, n_rows, n_ids))      /* every GPU holds the whole panel */
-                DIE("%s\n", ibdg_last_error(e));
-            phase("panel upload (copy, alt counts, transposition)");
-            if (opt_ref_order) {                                  /* background list in the -B file's order (:741) */
-                if (ibdg_set_option(e, "ld_variant", 3) || (has_B && ibdg_set_background_order(e, bg.idx, bg.n)))
-                    DIE("%s\n", ibdg_last_error(e));
-            }
             engs[n_eng++] = e;
         }
         if (n_eng == 0)
             DIE("[::] ERROR: --devices needs at least one device index.\n");
-        if (ibdg_get_alt_counts(engs[0], 0, n_rows, alt_count))
-            DIE("%s\n", ibdg_last_error(engs[0]));
-        phase("alt counts back to the host");
-    } else {
-        for (size_t r = 0; r < n_rows; ++r) {           /* --plan: same integers, on the host */
-            unsigned c = 0;
-            for (size_t w = 0; w < row_words; ++w)
-                c += (unsigned)__builtin_popcountll(packed[r * row_words + w]);
-            alt_count[r] = c;
+        slice_mode = batchable && n_eng > 1;
+        for (int d = 0; d < n_eng; ++d) {
+            memset(&ups[d], 0, sizeof ups[d]);
+            ups[d].eng = engs[d]; ups[d].r0 = 0; ups[d].n = n_rows; ups[d].n_ids = n_ids;
+            ups[d].ref_order = opt_ref_order; ups[d].has_B = has_B; ups[d].bg_idx = bg.idx; ups[d].bg_n = bg.n;
+        }
+        if (!slice_mode) {
+            /* whole panel to every device, all copies at once, under the filter chain below */
+            uploads_start(ups, n_eng);
+            uploads_pending = 1;
         }
     }
+    if (!alt_count_h)
+        DIE("[::] ERROR: no genotype rows.\n");
+    const uint32_t *alt_count = alt_count_h;
 
     /* ---- target-independent part of the row filter chain (:589-626) -------------------
      * Rows are independent here: a team of threads takes contiguous row ranges, each fills its own part
@@ -1631,9 +1702,7 @@ int main(int argc, char **argv)
     if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("page-locked result arrays");
-    /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
-     * reads anew for each (src/ibdgem.c:584, :627-628) */
-    const int batchable = !no_engine && !has_v && cull_p == 1.0;
+    uint32_t *s_row_dev = NULL;     /* slice_mode: the site list's rows counted from each device's first row */
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
         const char *tname = ids.names[tgt];
@@ -1711,10 +1780,36 @@ int main(int argc, char **argv)
             pthread_t th[64];
             if (!same_sites)
                 window_cuts(s_nr, s_na, n, (unsigned)opt_window, n_eng, cuts);
+            if (slice_mode && ti == 0) {
+                /* every device gets the panel rows from its first site's row to its last site's row, and its
+                 * sites are numbered within that slice */
+                s_row_dev = io_alloc((n ? n : 1) * 4, 1);
+                if (!s_row_dev)
+                    DIE("[::] ERROR: out of memory for %zu rows.\n", n);
+                for (int d = 0; d < n_eng; ++d) {
+                    const size_t a = cuts[d], b = cuts[d + 1];
+                    ups[d].r0 = a < b ? s_row[a] : 0;
+                    ups[d].n = a < b ? (size_t)s_row[b - 1] + 1 - ups[d].r0 : 0;
+                    for (size_t i = a; i < b; ++i)
+                        s_row_dev[i] = s_row[i] - (uint32_t)ups[d].r0;
+                    if (timing_on > 0)
+                        fprintf(stderr, "## panel slice of device %d: rows %zu + %zu of %zu\n", d, ups[d].r0, ups[d].n, n_rows);
+                }
+                uploads_start(ups, n_eng);
+                uploads_pending = 1;
+            }
+            if (uploads_pending) {
+                const int bad = uploads_join(ups, n_eng);
+                uploads_pending = 0;
+                if (bad >= 0)
+                    DIE("%s\n", ibdg_last_error(engs[bad]));
+                phase("panel upload (copy, alt counts, transposition; the part not hidden behind the filter chain)");
+            }
+            int th_started[64] = {0};
             for (int d = 0; d < n_eng; ++d) {
                 shard_job *j = &jobs[d];
                 memset(j, 0, sizeof *j);
-                j->eng = engs[d]; j->row = s_row; j->nr = s_nr; j->na = s_na; j->fo = s_fo;
+                j->eng = engs[d]; j->row = slice_mode ? s_row_dev : s_row; j->nr = s_nr; j->na = s_na; j->fo = s_fo;
                 j->a = cuts[d]; j->b = cuts[d + 1]; j->window = (unsigned)opt_window;
                 j->want_sites = !opt_summary_only;
                 if (batchable) {
@@ -1732,19 +1827,23 @@ int main(int argc, char **argv)
                 }
                 j->bg_count = bg_count; j->pu_id = (int)pu_id; j->ld = opt_ld;
                 j->site_af = site_af; j->site_ll = site_ll;
-                if (n_eng == 1)
+                /* (no thread to be had: the shard runs here -- never exit() while other shard threads are
+                 * inside the GPU runtime) */
+                th_started[d] = n_eng > 1 && pthread_create(&th[d], NULL, shard_run, j) == 0;
+                if (!th_started[d])
                     shard_run(j);
-                else if (pthread_create(&th[d], NULL, shard_run, j))
-                    DIE("[::] ERROR: cannot start a worker thread.\n");
             }
             n_win = 0;
+            int shard_failed = -1;
             for (int d = 0; d < n_eng; ++d) {
-                if (n_eng > 1)
+                if (th_started[d])
                     pthread_join(th[d], NULL);
-                if (jobs[d].failed)
-                    DIE("%s\n", ibdg_last_error(jobs[d].eng));
+                if (jobs[d].failed && shard_failed < 0)
+                    shard_failed = d;
                 n_win += jobs[d].n_win;
             }
+            if (shard_failed >= 0)
+                DIE("%s\n", ibdg_last_error(jobs[shard_failed].eng));
             w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = malloc((n_win + 1) * 4);
             win_ll = malloc((n_win + 1) * 24);
             size_t wo = 0;

@@ -449,13 +449,65 @@ int ingest_hap(const char *fn, unsigned n_ids, int threads, uint64_t **packed, u
     return ingest_stream(fn, n_ids, threads, packed, ok, n_rows);
 }
 
-/* ---- cache file --------------------------------------------------------------------------
- * header | ok flags | zero padding to a 4096-byte boundary | packed rows.  The rows are not read
- * but mapped: loading the cache costs nothing up front, and the engine's host-to-device copy (a team
- * of threads staging through page-locked buffers) reads the page cache directly. */
-#define CACHE_ALIGN 4096u
+/* ---- alternate-allele counts of the packed rows (find_f_impute / find_f_vcf, reference
+ * src/ibd-parse.c:91-110: the number of '1' alleles of a row over ALL individuals) -------------
+ * The host needs them for its -F/-f filter before any device has seen the panel (a device gets only
+ * the rows of its window range, which are known after the filter); the engine recounts its own rows
+ * (k_alt_count) for the per-row arithmetic. */
 typedef struct {
-    char magic[8];               /* "IBDGPNL2" */
+    const uint64_t *packed;
+    size_t a, b, words;
+    uint32_t *out;
+} cnt_job;
+
+static void *count_rows(void *arg)
+{
+    cnt_job *j = arg;
+    for (size_t r = j->a; r < j->b; ++r) {
+        const uint64_t *row = j->packed + r * j->words;
+        unsigned c = 0;
+        for (size_t w = 0; w < j->words; ++w)
+            c += (unsigned)__builtin_popcountll(row[w]);
+        j->out[r] = c;
+    }
+    return NULL;
+}
+
+void ingest_alt_counts(const uint64_t *packed, size_t n_rows, unsigned n_ids, int threads, uint32_t *out)
+{
+    cnt_job jobs[64];
+    pthread_t th[64];
+    int started[64] = {0};
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (n_rows < 4096) threads = 1;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].packed = packed;
+        jobs[t].words = row_words_of(n_ids);
+        jobs[t].a = n_rows * (size_t)t / (size_t)threads;
+        jobs[t].b = n_rows * (size_t)(t + 1) / (size_t)threads;
+        jobs[t].out = out;
+    }
+    for (int t = 0; t + 1 < threads; ++t)
+        started[t] = pthread_create(&th[t], NULL, count_rows, &jobs[t]) == 0;
+    for (int t = 0; t < threads; ++t)
+        if (!started[t])
+            count_rows(&jobs[t]);
+    for (int t = 0; t + 1 < threads; ++t)
+        if (started[t])
+            pthread_join(th[t], NULL);
+}
+
+/* ---- cache file --------------------------------------------------------------------------
+ * header | ok flags | zero padding to a 4096-byte boundary | alt-allele counts (u32 per row) | padding |
+ * packed rows.  The rows are not read but mapped: loading the cache costs nothing up front, and the
+ * engine's host-to-device copy (a team of threads staging through page-locked buffers) reads the page
+ * cache directly.  The counts are what the host's -F/-f filter needs of the panel, so a warm run
+ * starts filtering without touching the 2.56 GB of rows. */
+#define CACHE_ALIGN 4096u
+#define CACHE_MAGIC "IBDGPNL3"
+typedef struct {
+    char magic[8];               /* CACHE_MAGIC */
     uint32_t n_ids, reserved;
     uint64_t n_rows, row_words;
     uint64_t src_size;
@@ -473,14 +525,20 @@ static int stat_src(const char *fn, cache_hdr *h)
     return 0;
 }
 
-static size_t cache_rows_offset(size_t n_rows)
+static size_t cache_counts_offset(size_t n_rows)
 {
     const size_t raw = sizeof(cache_hdr) + n_rows;
     return (raw + CACHE_ALIGN - 1) / CACHE_ALIGN * CACHE_ALIGN;
 }
 
+static size_t cache_rows_offset(size_t n_rows)
+{
+    const size_t raw = cache_counts_offset(n_rows) + n_rows * 4;
+    return (raw + CACHE_ALIGN - 1) / CACHE_ALIGN * CACHE_ALIGN;
+}
+
 int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed_out, uint8_t **ok_out,
-                      size_t *n_rows_out)
+                      uint32_t **alt_out, size_t *n_rows_out)
 {
     const int fd = open(cache_fn, O_RDONLY);
     if (fd < 0)
@@ -489,13 +547,16 @@ int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, 
     memset(&want, 0, sizeof want);
     int rc = 1;
     uint8_t *ok = NULL;
+    uint32_t *alt = NULL;
     struct stat st;
-    if (fstat(fd, &st) == 0 && pread(fd, &h, sizeof h, 0) == (ssize_t)sizeof h && memcmp(h.magic, "IBDGPNL2", 8) == 0 &&
+    if (fstat(fd, &st) == 0 && pread(fd, &h, sizeof h, 0) == (ssize_t)sizeof h && memcmp(h.magic, CACHE_MAGIC, 8) == 0 &&
         stat_src(hap_fn, &want) == 0 && h.n_ids == n_ids && h.row_words == row_words_of(n_ids) &&
         h.src_size == want.src_size && h.src_mtime_s == want.src_mtime_s && h.src_mtime_ns == want.src_mtime_ns) {
         const size_t n = (size_t)h.n_rows, bytes = n * (size_t)h.row_words * 8, off = cache_rows_offset(n);
         ok = malloc(n ? n : 1);
-        if (ok && (size_t)st.st_size >= off + bytes && pread(fd, ok, n, sizeof h) == (ssize_t)n) {
+        alt = malloc((n ? n : 1) * sizeof *alt);
+        if (ok && alt && (size_t)st.st_size >= off + bytes && pread(fd, ok, n, sizeof h) == (ssize_t)n &&
+            pread(fd, alt, n * 4, (off_t)cache_counts_offset(n)) == (ssize_t)(n * 4)) {
             if (bytes == 0) {
                 *packed_out = malloc(8);
                 rc = *packed_out ? 0 : 1;
@@ -510,22 +571,25 @@ int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, 
             }
             if (!rc) {
                 *ok_out = ok;
+                *alt_out = alt;
                 *n_rows_out = n;
             }
         }
     }
     close(fd);
-    if (rc)
+    if (rc) {
         free(ok);
+        free(alt);
+    }
     return rc;
 }
 
 int ingest_cache_store(const char *cache_fn, const char *hap_fn, unsigned n_ids, const uint64_t *packed,
-                       const uint8_t *ok, size_t n_rows)
+                       const uint8_t *ok, const uint32_t *alt, size_t n_rows)
 {
     cache_hdr h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "IBDGPNL2", 8);
+    memcpy(h.magic, CACHE_MAGIC, 8);
     h.n_ids = n_ids;
     h.n_rows = n_rows;
     h.row_words = row_words_of(n_ids);
@@ -538,10 +602,12 @@ int ingest_cache_store(const char *cache_fn, const char *hap_fn, unsigned n_ids,
     if (!f)
         return 1;
     const size_t bytes = n_rows * (size_t)h.row_words * 8;
-    const size_t pad = cache_rows_offset(n_rows) - (sizeof h + n_rows);
+    const size_t pad = cache_counts_offset(n_rows) - (sizeof h + n_rows);
+    const size_t pad2 = cache_rows_offset(n_rows) - (cache_counts_offset(n_rows) + n_rows * 4);
     static const char zeros[CACHE_ALIGN];
     int rc = !(fwrite(&h, sizeof h, 1, f) == 1 && fwrite(ok, 1, n_rows, f) == n_rows &&
-               fwrite(zeros, 1, pad, f) == pad && fwrite(packed, 1, bytes, f) == bytes);
+               fwrite(zeros, 1, pad, f) == pad && fwrite(alt, 4, n_rows, f) == n_rows &&
+               fwrite(zeros, 1, pad2, f) == pad2 && fwrite(packed, 1, bytes, f) == bytes);
     if (fclose(f) != 0)
         rc = 1;
     if (!rc && rename(tmp, cache_fn) != 0)

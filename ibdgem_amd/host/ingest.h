@@ -14,10 +14,18 @@
  * The arrays are malloc'ed; returns 0, or 1 on I/O / memory failure. */
 int ingest_hap(const char *fn, unsigned n_ids, int threads, uint64_t **packed, uint8_t **ok, size_t *n_rows);
 
+/* Alternate-allele count of every packed row (the number of set bits: find_f_impute / find_f_vcf,
+ * reference src/ibd-parse.c:91-110), by a team of threads. */
+void ingest_alt_counts(const uint64_t *packed, size_t n_rows, unsigned n_ids, int threads, uint32_t *out);
+
 /* Cache file = header (panel width, row count, size and mtime of the .hap file it was made from),
- * ok flags, packed rows.  load returns 1 when the file is missing or was made from another input. */
+ * ok flags, alt-allele counts, packed rows.  load returns 1 when the file is missing or was made from
+ * another input.  *packed of a successful load is a read-only MAPPING of the file that lives as long as
+ * the program: the caller must not free() it, and a file truncated or rewritten in place by somebody
+ * else during the run raises SIGBUS in whoever reads the rows (ingest_cache_store itself replaces the
+ * file by rename, which leaves an existing mapping intact).  ok and alt are malloc'ed. */
 int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed, uint8_t **ok,
-                      size_t *n_rows);
+                      uint32_t **alt, size_t *n_rows);
 int ingest_cache_store(const char *cache_fn, const char *hap_fn, unsigned n_ids, const uint64_t *packed,
-                       const uint8_t *ok, size_t n_rows);
+                       const uint8_t *ok, const uint32_t *alt, size_t n_rows);
 #endif

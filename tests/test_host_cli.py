@@ -304,16 +304,36 @@ def test_cli_reproduces_the_reference_on_synthetic_cases(tag, case, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,devices", [("ld_default", "0,0"), ("ld_downsample", "0,0,0"), ("ld_varsites", "0,0,0,0,0"),
-                                          ("nonld_all_targets_w2", "0,0,0")])
-def test_cli_window_sharding_over_several_contexts(case, devices, tmp_path):
+@pytest.mark.parametrize("tag,case,devices", [("synA", "ld_default", "0,0"), ("synA", "ld_downsample", "0,0,0"),
+                                              ("synA", "ld_varsites", "0,0,0,0,0"), ("synA", "nonld_all_targets_w2", "0,0,0"),
+                                              ("synA", "ld_bg20_w64", "0,0,0,0"), ("synA", "ld_pu_in_panel", "0,0,0"),
+                                              ("synA", "ld_af_file", "0,0"), ("synA", "ld_positions", "0,0,0,0,0,0"),
+                                              ("synB", "ld_w37", "0,0,0,0,0,0,0"), ("synB", "ld_pu_named", "0,0")])
+def test_cli_window_sharding_over_several_contexts(tag, case, devices, tmp_path):
     """--devices: the windows of each comparison are cut into contiguous ranges, one per engine
     context (here several contexts on the one GPU of the test box), evaluated by one host thread
-    each and gathered on the host -- output files still byte-identical to the reference's."""
-    meta = G.cases("synA")
-    _run_full(meta["base_args"] + meta["cases"][case] + ["--devices", devices], os.path.join(G.GOLD, "synA", "input"),
-              tmp_path)
-    ref = os.path.join(G.GOLD, "synA", case, "ref7")
+    each and gathered on the host -- output files still byte-identical to the reference's.  Without -v / -D
+    (one site list for all comparison individuals) a context holds only the panel rows of its window range
+    (windows are independent, reference src/ibdgem.c:558-570); with them, the whole panel."""
+    meta = G.cases(tag)
+    args = meta["base_args"] + meta["cases"][case] + ["--devices", devices]
+    res = subprocess.run([_exe()] + args + ["-O", str(tmp_path)], cwd=os.path.join(G.GOLD, tag, "input"),
+                         capture_output=True, text=True, env=dict(os.environ, IBDGEM_TIMING="1"))
+    assert res.returncode == 0, res.stderr
+    slices = [l.split() for l in res.stderr.splitlines() if l.startswith("## panel slice of device")]
+    n_dev = devices.count(",") + 1
+    if "-v" in args:
+        assert not slices
+    elif "-D" not in args or slices:         # (-D thins the reads only when the depth is above the target)
+        assert len(slices) == n_dev
+        total = int(slices[0][-1])
+        first = [int(x[6]) for x in slices]
+        count = [int(x[8]) for x in slices]
+        live = [(a, c) for a, c in zip(first, count) if c]
+        # contiguous window ranges: ascending, and only the two rows at a cut may be shared... no row twice
+        assert all(a + c <= b for (a, c), (b, _) in zip(live, live[1:]))
+        assert sum(count) <= total and (n_dev == 1 or max(count) < total)
+    ref = os.path.join(G.GOLD, tag, case, "ref7")
     for fn in sorted(os.listdir(ref)):
         got = _read(str(tmp_path / fn[:-3]))
         want = _read(os.path.join(ref, fn))

@@ -14,9 +14,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     bench.write_pileup_and_legend(d, n_ref, n_alt, 2504, rows)
     open(os.path.join(d, "p.hap"), "w").write("placeholder\n")
     st = os.stat(os.path.join(d, "p.hap"))
-    with open(os.path.join(d, "p.cache"), "wb") as fh:
-        hdr = struct.pack("<8sIIQQQqq", b"IBDGPNL2", 2504, 0, rows, words.shape[1], st.st_size, st.st_mtime_ns // 10**9, st.st_mtime_ns % 10**9)
-        fh.write(hdr); fh.write(np.ones(rows, np.uint8).tobytes()); fh.write(b"\0" * (-(len(hdr) + rows) % 4096)); fh.write(words.tobytes())
+    bench.write_panel_cache(os.path.join(d, "p.cache"), words, 2504, st)
     base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o", "--summary-only"]
     os.makedirs(os.path.join(d, "o"))
     for rep in range(3):
