@@ -15,6 +15,7 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,7 +27,8 @@ namespace {
 // inputs and the reference (src/ibd-math.c:93-95) calls the real pow.
 double (*volatile libm_pow)(double, double) = std::pow;
 
-std::string g_create_error;
+std::string g_create_error;          // of the last failed ibdg_create; contexts may be created from several threads
+std::mutex g_create_error_mu;
 
 struct DevBuf {
     void *p = nullptr;
@@ -148,6 +150,9 @@ struct ibdg_ctx {
     long opt_site_blocks = 4;        // 256-thread workgroups per CU of k_site inside an --LD run (0 = a thread per site)
     long opt_recount_blocks = 4;     // single-wave workgroups per CU of k_alt_count when it runs inside an --LD run
                                      // (0 = the full grid; 4 measured best: tools/recount_sweep.py)
+    long opt_site_results = 1;       // 1: per-site LIBD0/1/2 and AF kept for ibdg_get_site_*; 2: LIBD0/1/2 only; 0: neither --
+                                     // no T x n_sites x 24 B of HBM, no per-site stores (window results only)
+    int res_site_mode = 0;           // the mode the last run's results were produced under
     long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
     // page-locked staging for large panels from pageable memory (staged_upload)
     static constexpr int STAGE_WORKERS = 8;
@@ -165,10 +170,12 @@ int fail(ibdg_ctx *c, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c)
+    if (c) {
         c->err = buf;
-    else
+    } else {
+        std::lock_guard<std::mutex> lk(g_create_error_mu);
         g_create_error = buf;
+    }
     return 1;
 }
 
@@ -721,7 +728,6 @@ double ibdg_pdg_ibd1(unsigned a0, unsigned a1, double f, double p00, double p01,
 
 ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
 {
-    g_create_error.clear();
     if (max_cov < 1 || max_cov > 127) {   // -M >= 1 (ibdgem.c:978); pileup rows have cov < 128 (pileup.c:223)
         fail(nullptr, "[::] ERROR: Invalid maximum estimated coverage (-M) of %u (must be 1..127).", max_cov);
         return nullptr;
@@ -781,7 +787,7 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     while ((1u << c->planes) <= max_cov)
         ++c->planes;
     if (ensure(c, c->lut, c->lut_h.size() * 8)) {
-        g_create_error = c->err;
+        fail(nullptr, "%s", c->err.c_str());
         ibdg_destroy(c);
         return nullptr;
     }
@@ -1094,8 +1100,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     HIP_TRY(c, hipSetDevice(c->device));
 
     const size_t lanes = (size_t)c->n_groups * c->cpw * 64;
-    if (ensure(c, c->targets, T * 4) || ensure(c, c->af, c->n_sites * 8) ||
-        ensure(c, c->site_ll, T * c->n_sites * 24) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
+    const bool want_ll = c->opt_site_results != 0, want_af = c->opt_site_results == 1;
+    if (ensure(c, c->targets, T * 4) || (want_af && ensure(c, c->af, c->n_sites * 8)) ||
+        (want_ll && ensure(c, c->site_ll, T * c->n_sites * 24)) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
     // targets / background weights change rarely between calls (a loop over windows sizes, repeated
     // timing steps): their device copies are rebuilt only when the inputs differ
@@ -1184,7 +1191,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
     }
 
-    ibdg::SiteArgs sa;
+    ibdg::RowsArgs sa;
     sa.panel = (const uint64_t *)c->panel.p;
     sa.stride = c->stride;
     sa.n_ids = c->n_ids;
@@ -1197,8 +1204,14 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.targets = (const uint32_t *)c->targets.p;
     sa.t32 = c->pop_lut_ok ? (const uint4 *)c->t32.p : nullptr;
     sa.n_pairs = c->n_pairs;
-    sa.af = (double *)c->af.p;
-    sa.site_ll = (double *)c->site_ll.p;
+    sa.cov_site = (const uint32_t *)c->cov_site.p;
+    sa.n_cov = c->n_cov;
+    sa.window = c->window;
+    sa.n_win = c->n_win;
+    sa.ld_mode = ld_mode ? 1 : 0;
+    sa.af = want_af ? (double *)c->af.p : nullptr;
+    sa.site_ll = want_ll ? (double *)c->site_ll.p : nullptr;
+    sa.win_ll = (double *)c->win_ll.p;
 
     if (use_pop) {
         // Comparison individuals in groups of MT share one workgroup (and the counts that do not
@@ -1430,28 +1443,18 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         c->counts_valid = true;
         HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
     }
-    // beside the --LD kernel the per-site kernel gets few long-lived workgroups (opt_site_blocks per CU, shared among
+    // the per-row values and the window products, one launch (k_rows_windows).  Beside the exponent-counting --LD
+    // kernel, which holds every wave slot, it gets few long-lived workgroups (opt_site_blocks per CU, shared among
     // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
-    // (not when the alt counts are recounted in this run: the second stream's chain count -> per-site -> products is
-    // then the longer one of the two, and its short kernels should be short)
-    // (the matrix-core kernel leaves half of the wave slots free: beside it they run in their fast forms)
+    // (not when the alt counts are recounted in this run: the second stream's chain count -> rows is then the longer
+    // one of the two, and its kernels should be short; and not beside the matrix-core kernel, which leaves half of
+    // the wave slots free)
     const bool shadow = ld_mode && !recount && !side_fast;
-    unsigned site_blocks = 0;
+    unsigned row_blocks = 0;
     if (shadow && c->opt_site_blocks > 0)
-        site_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
-    ibdg::launch_site(sa, (unsigned)T, c->stream2, site_blocks);
+        row_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
     HIP_TRY(c, hipEventRecord(E.s2[1], c->stream2));
-
-    ibdg::WinArgs wa;
-    wa.site_ll = sa.site_ll;
-    wa.n_sites = c->n_sites;
-    wa.cov_site = (const uint32_t *)c->cov_site.p;
-    wa.n_cov = c->n_cov;
-    wa.window = c->window;
-    wa.n_win = c->n_win;
-    wa.ld_mode = ld_mode ? 1 : 0;
-    wa.win_ll = (double *)c->win_ll.p;
-    ibdg::launch_window_prod(wa, (unsigned)T, c->stream2, shadow);
+    ibdg::launch_rows_windows(sa, (unsigned)T, c->stream2, row_blocks);
     HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
     c->last_s2 = E.s2[2];
     c->s2_pending = true;
@@ -1463,6 +1466,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         return 1;
     c->n_targets = T;
     c->have_results = true;
+    c->res_site_mode = (int)c->opt_site_results;
     return 0;
 }
 
@@ -1479,6 +1483,7 @@ int ibdg_get_site_af(ibdg_ctx *c, double *af)
 {
     if (!c) return 1;
     if (!c->have_results) return fail(c, "[::] ERROR in ibdg_get_site_af: no results (call ibdg_run)");
+    if (c->res_site_mode != 1) return fail(c, "[::] ERROR in ibdg_get_site_af: the run kept no AF column (option site_results)");
     return fetch(c, af, c->af.p, c->n_sites * 8);
 }
 
@@ -1486,6 +1491,7 @@ int ibdg_get_site_ll(ibdg_ctx *c, size_t t, double *out)
 {
     if (!c) return 1;
     if (!c->have_results || t >= c->n_targets) return fail(c, "[::] ERROR in ibdg_get_site_ll: no results for target %zu", t);
+    if (c->res_site_mode == 0) return fail(c, "[::] ERROR in ibdg_get_site_ll: the run kept no per-site results (option site_results)");
     return fetch(c, out, (const char *)c->site_ll.p + t * c->n_sites * 24, c->n_sites * 24);
 }
 
@@ -1519,8 +1525,9 @@ int ibdg_run_ms(ibdg_ctx *c, unsigned back, float out[5])
     out[1] = 0.f;
     if (E.recount)
         HIP_TRY(c, hipEventElapsedTime(&out[1], E.s2_start, E.s2[0]));
-    HIP_TRY(c, hipEventElapsedTime(&v, E.recount ? E.s2[0] : E.s2_start, E.s2[1])); out[2] = v;
-    HIP_TRY(c, hipEventElapsedTime(&v, E.s2[1], E.s2[2])); out[4] = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, E.s2[1], E.s2[2]));
+    out[2] = v;                              // per-row values and window products are one kernel
+    out[4] = 0.f;
     return 0;
 }
 
@@ -1564,6 +1571,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
+    if (!strcmp(name, "site_results")) {
+        if (value < 0 || value > 2) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0, 1 or 2");
+        c->opt_site_results = value; return 0;
+    }
     if (!strcmp(name, "site_blocks_per_cu")) {
         if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: site_blocks_per_cu must be 0..128");
         c->opt_site_blocks = value; return 0;

@@ -7,7 +7,8 @@
 
 namespace ibdg {
 
-struct SiteArgs {
+// per-row values + window products (k_rows_windows)
+struct RowsArgs {
     const uint64_t *panel;      // [n_rows][stride]
     uint32_t stride;            // u64 words per device row
     uint32_t n_ids;
@@ -20,18 +21,13 @@ struct SiteArgs {
     const uint32_t *targets;    // [T]
     const uint4 *t32;           // tile-transposed panel (NULL if not built) and its pairs per chunk
     uint32_t n_pairs;
-    double *af;                 // [n_sites]
-    double *site_ll;            // [T][n_sites][3]
-};
-
-struct WinArgs {
-    const double *site_ll;      // [T][n_sites][3]
-    size_t n_sites;
     const uint32_t *cov_site;   // [n_cov] site index of each covered row
     uint32_t n_cov;
     uint32_t window;
     uint32_t n_win;
-    int ld_mode;
+    int ld_mode;                // 1: of the window products only LIBD2 is written
+    double *af;                 // [n_sites], or NULL: not wanted
+    double *site_ll;            // [T][n_sites][3], or NULL: per-site results not wanted
     double *win_ll;             // [T][n_win][3]
 };
 
@@ -245,11 +241,9 @@ void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t w
 // chip); a small number (e.g. 8 per CU) when it runs beside a kernel that should keep most of the slots
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st, unsigned max_blocks = 0);
-// max_blocks: 0 = a thread per site; otherwise at most that many 256-thread workgroups per target (grid-stride)
-void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
-// small_footprint: the thread-per-window form (a few hundred waves; for running beside the --LD kernel) instead of
-// the wave-per-window form (faster when it has the chip to itself)
-void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st, bool small_footprint);
+// max_blocks: 0 = a wave per window (four per workgroup); otherwise at most that many workgroups per target, which
+// walk the windows grid-stride (few long-lived waves: for running beside the --LD kernel)
+void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st);
 
 }  // namespace ibdg

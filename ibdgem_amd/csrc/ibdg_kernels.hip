@@ -99,188 +99,154 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 }
 
 // ---------------------------------------------------------------------------
-// K1: per-site LIBD0/LIBD1/LIBD2 (tab columns), one thread per (site, target).
+// K1 + K3 in one launch: the per-row LIBD0/LIBD1/LIBD2 (tab columns) and the window products.
 //   f          src/ibd-parse.c:98 (count / (2*n_ids)) or the -A override
 //   ibd0       find_pDgf      src/ibd-math.c:84-101
 //   ibd1       find_pDgIBD1   src/ibd-math.c:104-142
 //   ibd2       src/ibdgem.c:643-651
-// pow(1-f,2.0) and pow(f,2.0) come from pow_tab (indexed by alt count) or, with
-// an -A override, from the per-site fo array {f, pow(1-f,2), pow(f,2)}.
+//   S0,S1,S2   src/ibdgem.c:562, :665-667, :755: products over the covered rows of a window in row
+//              order; in --LD mode only LIBD2 = S2 is written (:752), LIBD0/LIBD1 come from the LD kernels.
+// pow(1-f,2.0) and pow(f,2.0) come from pow_tab (indexed by alt count) or, with an -A override, from
+// the per-site fo array {f, pow(1-f,2), pow(f,2)}.
+//
+// A wave per (window, comparison individual): its lanes take the rows from the window's first covered
+// row up to the next window's (rows without reads in between are printed but join no window,
+// src/ibdgem.c:657-663; the rows before the first window go with window 0, those behind the last one
+// with it), 128 rows per turn with all their gathers in flight, compute the row's three values, store
+// them when per-site results are wanted, and leave the factors -- 1.0 for a row without reads: x * 1.0
+// is x -- in the wave's LDS strip, where three lanes multiply them up in row order.  The per-site triple
+// is never read back (a separate product kernel re-read 24 B per row), and a run that wants window
+// results only (FULL = false in --LD mode: the host program's --summary-only) computes just the IBD2
+// pick of every row: one table look-up, nothing stored.
 // ---------------------------------------------------------------------------
-// U sites per thread and turn (their gathers are in flight together): 1 with a thread per site, 4 with the few
-// long-lived workgroups that run beside the --LD kernel
-template <int U>
-__global__ __launch_bounds__(256) void k_site(SiteArgs a)
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_rows_windows(RowsArgs a)
 {
+    constexpr int NV = FULL ? 3 : 1;                 // values per row kept for the products
+    __shared__ double strip[4][128 * NV];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
     const uint32_t tgt = a.targets[t];
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    // grid-stride: the launch may hold fewer threads than sites (few long-lived workgroups beside the --LD kernel)
-    for (size_t s0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < a.n_sites; s0 += U * step) {
-        uint2 rc[U];
-        bool live[U];
+    double *buf = strip[wave];
+    const uint32_t n_w = a.n_win ? a.n_win : 1;      // no covered row at all: the rows still get their values
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (uint32_t w = blockIdx.x * 4 + wave; w < n_w; w += gridDim.x * 4) {
+        const size_t b = w == 0 ? 0 : a.cov_site[(size_t)w * a.window];
+        const size_t e = w + 1 >= a.n_win ? a.n_sites : a.cov_site[(size_t)(w + 1) * a.window];
+        double acc = 1.0;
+        for (size_t base = b; base < e; base += 128) {
+            uint2 rc[2];
+            bool live[2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t s = s0 + (size_t)u * step;
-            live[u] = s < a.n_sites;
-            rc[u] = live[u] ? a.rec_all[s] : make_uint2(0, 0);
-        }
-        uint32_t k[U];
-        uint2 w[U];
-        double p00[U], p01[U], p11[U], fo[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc[u].y);
-            p00[u] = L[0];
-            p01[u] = L[1];
-            p11[u] = L[2];
-            k[u] = live[u] ? a.alt_count[rc[u].x] : 0u;
-            if (a.t32) {
-                // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
-                // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
-                const uint2 *tw = reinterpret_cast<const uint2 *>(
-                    a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc[u].x >> 6)) * 64 + (tgt & 63));
-                w[u] = live[u] ? tw[(rc[u].x >> 5) & 1] : make_uint2(0, 0);
-            } else {
-                const uint64_t *row = a.panel + (size_t)rc[u].x * a.stride;
-                const uint64_t r0 = live[u] ? row[2 * (tgt >> 6)] : 0, r1 = live[u] ? row[2 * (tgt >> 6) + 1] : 0;
-                w[u] = make_uint2((uint32_t)((r0 >> (tgt & 63)) & 1u) << (rc[u].x & 31),
-                                  (uint32_t)((r1 >> (tgt & 63)) & 1u) << (rc[u].x & 31));
+            for (int u = 0; u < 2; ++u) {
+                const size_t s = base + 64 * u + lane;
+                live[u] = s < e;
+                rc[u] = live[u] ? a.rec_all[s] : make_uint2(0, 0);
             }
-            fo[u] = a.fo && live[u] ? a.fo[3 * (s0 + (size_t)u * step)] : __longlong_as_double(0x7ff8000000000000ll);
-        }
-        double f[U], pw1[U], pw2[U];
+            uint32_t k[2];
+            uint2 tw[2];
+            double p00[2], p01[2], p11[2], fo[2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            f[u] = (double)k[u] / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
-            pw1[u] = a.pow_tab[2 * k[u]];
-            pw2[u] = a.pow_tab[2 * k[u] + 1];
-            if (fo[u] == fo[u]) {          // not NaN: -A override (src/ibdgem.c:609-614)
-                const size_t s = s0 + (size_t)u * step;
-                f[u] = fo[u];
-                pw1[u] = a.fo[3 * s + 1];
-                pw2[u] = a.fo[3 * s + 2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!live[u])
-                continue;
-            const size_t s = s0 + (size_t)u * step;
-            const unsigned A0 = (w[u].x >> (rc[u].x & 31)) & 1u, A1 = (w[u].y >> (rc[u].x & 31)) & 1u;
-            const unsigned g = A0 + A1;
-            const double omf = 1 - f[u];
-            double ibd0 = 1.0;
-            if (!(p00[u] == 1 || p01[u] == 1 || p11[u] == 1)) {
-                const double t1 = pw1[u] * p00[u];
-                const double t2 = ((2 * omf) * f[u]) * p01[u];
-                const double t3 = pw2[u] * p11[u];
-                ibd0 = (t1 + t2) + t3;
-                if (ibd0 == 0.0)
-                    ibd0 = 2.2250738585072014e-308;      // DBL_MIN
-            }
-            double ibd1;
-            if (g == 0)
-                ibd1 = (f[u] * p01[u]) + (omf * p00[u]);
-            else if (g == 1)
-                ibd1 = ((0.5 * p01[u]) + ((0.5 * omf) * p00[u])) + ((0.5 * f[u]) * p11[u]);
-            else
-                ibd1 = (omf * p01[u]) + (f[u] * p11[u]);
-            if (ibd1 == 0.0)
-                ibd1 = 2.2250738585072014e-308;
-            const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
-
-            if (t == 0)
-                a.af[s] = f[u];
-            double *o = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
-            o[0] = ibd0;
-            o[1] = ibd1;
-            o[2] = ibd2;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K3: window products S0,S1,S2 over the covered rows of a window, in row order
-// (src/ibdgem.c:562, :665-667, :755).  One thread per (window, target): the rows' values are
-// fetched eight rows ahead of the sequential products (the loads do not depend on the chain), so a
-// window costs ~13 memory round trips, and the whole kernel is a few hundred waves -- it runs beside
-// the --LD kernel without taking its wave slots (a wave per window did: 35 000 waves, each parked on
-// a chain of dependent LDS reads).  In --LD mode only LIBD2 = S2 is written (src/ibdgem.c:752);
-// LIBD0/LIBD1 of the window come from the LD kernel.
-// ---------------------------------------------------------------------------
-// The stand-alone form (non-LD runs, nothing else on the chip): one wave per (window, target); lanes stage the
-// rows' three values through LDS, lanes 0..2 multiply sequentially.  Twice as fast alone as the thread-per-window
-// form below (0.031 against 0.052 ms at 4M rows), but 35 000 waves that each sit on a chain of dependent LDS reads.
-__global__ __launch_bounds__(64) void k_window_prod_wave(WinArgs a)
-{
-    __shared__ double buf[64 * 3];
-    const unsigned w = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
-    const uint32_t begin = w * a.window;
-    const uint32_t end = min(begin + a.window, a.n_cov);
-    const double *ll = a.site_ll + (size_t)t * a.n_sites * 3;
-    double acc = 1.0;
-    for (uint32_t base = begin; base < end; base += 64) {
-        const uint32_t n = min(64u, end - base);
-        if (lane < n) {
-            const double *src = ll + (size_t)a.cov_site[base + lane] * 3;
-            buf[lane * 3] = src[0];
-            buf[lane * 3 + 1] = src[1];
-            buf[lane * 3 + 2] = src[2];
-        }
-        __syncthreads();
-        if (lane < 3)
-            for (uint32_t j = 0; j < n; ++j)
-                acc *= buf[j * 3 + lane];
-        __syncthreads();
-    }
-    if (lane < 3 && (!a.ld_mode || lane == 2))
-        a.win_ll[((size_t)t * a.n_win + w) * 3 + lane] = acc;
-}
-
-// The form that runs beside the --LD kernel: one thread per (window, target).
-__global__ __launch_bounds__(64) void k_window_prod(WinArgs a)
-{
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned t = blockIdx.y;
-    if (w >= a.n_win)
-        return;
-    const uint64_t begin = (uint64_t)w * a.window;
-    const uint32_t end = (uint32_t)min(begin + a.window, (uint64_t)a.n_cov);
-    const double *ll = a.site_ll + (size_t)t * a.n_sites * 3;
-    double s0 = 1.0, s1 = 1.0, s2 = 1.0;
-    for (uint32_t j = (uint32_t)begin; j < end; j += 8) {
-        uint32_t site[8];
-        double v0[8], v1[8], v2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            site[u] = j + u < end ? a.cov_site[j + u] : 0xffffffffu;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            v0[u] = v1[u] = v2[u] = 1.0;
-            if (site[u] != 0xffffffffu) {
-                const double *src = ll + (size_t)site[u] * 3;
-                if (!a.ld_mode) {
-                    v0[u] = src[0];
-                    v1[u] = src[1];
+            for (int u = 0; u < 2; ++u) {
+                const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc[u].y);
+                p00[u] = L[0];
+                p01[u] = L[1];
+                p11[u] = L[2];
+                k[u] = FULL && live[u] ? a.alt_count[rc[u].x] : 0u;
+                if (a.t32) {
+                    // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
+                    // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
+                    const uint2 *p = reinterpret_cast<const uint2 *>(
+                        a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc[u].x >> 6)) * 64 + (tgt & 63));
+                    tw[u] = live[u] ? p[(rc[u].x >> 5) & 1] : make_uint2(0, 0);
+                } else {
+                    const uint64_t *row = a.panel + (size_t)rc[u].x * a.stride;
+                    const uint64_t r0 = live[u] ? row[2 * (tgt >> 6)] : 0, r1 = live[u] ? row[2 * (tgt >> 6) + 1] : 0;
+                    tw[u] = make_uint2((uint32_t)((r0 >> (tgt & 63)) & 1u) << (rc[u].x & 31),
+                                       (uint32_t)((r1 >> (tgt & 63)) & 1u) << (rc[u].x & 31));
                 }
-                v2[u] = src[2];
+                fo[u] = FULL && a.fo && live[u] ? a.fo[3 * (base + 64 * u + lane)] : qnan;
+            }
+            double f[2], pw1[2], pw2[2];
+            if (FULL) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f[u] = (double)k[u] / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
+                    pw1[u] = a.pow_tab[2 * k[u]];
+                    pw2[u] = a.pow_tab[2 * k[u] + 1];
+                    if (fo[u] == fo[u]) {          // not NaN: -A override (src/ibdgem.c:609-614)
+                        const size_t s = base + 64 * u + lane;
+                        f[u] = fo[u];
+                        pw1[u] = a.fo[3 * s + 1];
+                        pw2[u] = a.fo[3 * s + 2];
+                    }
+                }
+            }
+            // (the strip's previous turn has been read: a wave's LDS operations execute in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const size_t s = base + 64 * u + lane;
+                const unsigned A0 = (tw[u].x >> (rc[u].x & 31)) & 1u, A1 = (tw[u].y >> (rc[u].x & 31)) & 1u;
+                const unsigned g = A0 + A1;
+                const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
+                const bool covered = rc[u].y != 0;            // table offset 0 <=> no reads
+                double *o = buf + (64 * u + lane) * NV;
+                if (FULL) {
+                    const double omf = 1 - f[u];
+                    double ibd0 = 1.0;
+                    if (!(p00[u] == 1 || p01[u] == 1 || p11[u] == 1)) {
+                        const double t1 = pw1[u] * p00[u];
+                        const double t2 = ((2 * omf) * f[u]) * p01[u];
+                        const double t3 = pw2[u] * p11[u];
+                        ibd0 = (t1 + t2) + t3;
+                        if (ibd0 == 0.0)
+                            ibd0 = 2.2250738585072014e-308;      // DBL_MIN
+                    }
+                    double ibd1;
+                    if (g == 0)
+                        ibd1 = (f[u] * p01[u]) + (omf * p00[u]);
+                    else if (g == 1)
+                        ibd1 = ((0.5 * p01[u]) + ((0.5 * omf) * p00[u])) + ((0.5 * f[u]) * p11[u]);
+                    else
+                        ibd1 = (omf * p01[u]) + (f[u] * p11[u]);
+                    if (ibd1 == 0.0)
+                        ibd1 = 2.2250738585072014e-308;
+                    if (live[u]) {
+                        if (a.af && t == 0)
+                            a.af[s] = f[u];
+                        if (a.site_ll) {
+                            double *d = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
+                            d[0] = ibd0;
+                            d[1] = ibd1;
+                            d[2] = ibd2;
+                        }
+                    }
+                    o[0] = covered ? ibd0 : 1.0;
+                    o[1] = covered ? ibd1 : 1.0;
+                    o[2] = covered ? ibd2 : 1.0;
+                } else {
+                    o[0] = covered ? ibd2 : 1.0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n = (uint32_t)(e - base < 128 ? e - base : 128);
+            if (lane < NV) {
+#pragma unroll 8
+                for (uint32_t j = 0; j < n; ++j)
+                    acc *= buf[j * NV + lane];
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (j + u < end) {                       // (times 1.0 would be exact too, but keep to the rows there are)
-                s0 *= v0[u];
-                s1 *= v1[u];
-                s2 *= v2[u];
-            }
+        if (w < a.n_win && lane < NV) {
+            double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
+            if (!FULL)
+                o[2] = acc;
+            else if (!a.ld_mode || lane == 2)
+                o[lane] = acc;
+        }
     }
-    double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
-    if (!a.ld_mode) {
-        o[0] = s0;
-        o[1] = s1;
-    }
-    o[2] = s2;
 }
 
 // ---------------------------------------------------------------------------
@@ -493,28 +459,20 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
                        alt_count);
 }
 
-void launch_site(const SiteArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks)
+void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks)
 {
     if (a.n_sites == 0 || n_targets == 0)
         return;
-    size_t blocks = (a.n_sites + 255) / 256;
+    const uint32_t n_w = a.n_win ? a.n_win : 1;
+    size_t blocks = ((size_t)n_w + 3) / 4;
     if (max_blocks && blocks > max_blocks)
         blocks = max_blocks;
     dim3 grid((unsigned)blocks, n_targets);
-    if (max_blocks)
-        hipLaunchKernelGGL(k_site<4>, grid, dim3(256), 0, st, a);
+    // everything but LIBD2 of the windows unwanted (--LD, no per-site results): the one-value form
+    if (a.ld_mode && !a.site_ll && !a.af)
+        hipLaunchKernelGGL(k_rows_windows<false>, grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(k_site<1>, grid, dim3(256), 0, st, a);
-}
-
-void launch_window_prod(const WinArgs &a, unsigned n_targets, hipStream_t st, bool small_footprint)
-{
-    if (a.n_win == 0 || n_targets == 0)
-        return;
-    if (small_footprint)
-        hipLaunchKernelGGL(k_window_prod, dim3((a.n_win + 63) / 64, n_targets), dim3(64), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_window_prod_wave, dim3(a.n_win, n_targets), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_rows_windows<true>, grid, dim3(256), 0, st, a);
 }
 
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st)

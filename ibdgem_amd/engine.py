@@ -248,13 +248,13 @@ class Engine:
     def last_run_ms(self):
         out = (C.c_float * 5)()
         self._chk(self.lib.ibdg_last_run_ms(self.ctx, out))
-        return dict(total=out[0], alt_count=out[1], site=out[2], ld=out[3], window=out[4])
+        return dict(total=out[0], alt_count=out[1], rows=out[2], ld=out[3])
 
     def run_ms(self, back):
         """Device times of the run `back` calls ago (0 = last); waits for the stream."""
         out = (C.c_float * 5)()
         self._chk(self.lib.ibdg_run_ms(self.ctx, back, out))
-        return dict(total=out[0], alt_count=out[1], site=out[2], ld=out[3], window=out[4])
+        return dict(total=out[0], alt_count=out[1], rows=out[2], ld=out[3])
 
     def run_kernel_ms(self, back=0):
         """Duration of the dominant --LD kernel of the run `back` calls ago (its own dispatch times)."""

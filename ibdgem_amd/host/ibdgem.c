@@ -965,7 +965,7 @@ typedef struct {
     const cand_t *cand;
     const uint32_t *s_cand;
     const pileup_t *pu;
-    const double *site_af, *site_ll;
+    const double *site_ll;
     const uint8_t *s_nr, *s_na;
     unsigned tgt;
     int plan;
@@ -984,7 +984,7 @@ static void *fmt_rows(void *arg)
         const cand_t *c = &j->cand[j->s_cand[i]];
         const row_t *R = &rows[c->row];
         const pu_line *pl = &j->pu->lines[c->pu];
-        const double f = j->plan ? c->f : j->site_af[i];
+        const double f = c->f;           /* alt count / (2 N) or the -A value: the division the engine makes too */
         const char *chr = j->pu->chr_names[pl->chr], *id = arena + R->id_off, *ref = arena + R->ref_off,
                    *alt = arena + R->alt_off;
         /* strings + 3 x %lu/%lf (<= 330 chars for the largest double) + 5 x %u + 3 x %e + separators */
@@ -1147,7 +1147,7 @@ typedef struct {
     const uint8_t *bg_count;
     int pu_id, ld;
     /* outputs, written at the slice's offsets of the comparison-wide arrays */
-    double *site_af, *site_ll;
+    double *site_ll;
     uint32_t *w_first, *w_last, *w_ncov;     /* slice-local arrays, window indices local */
     double *win_ll;
     size_t n_win;
@@ -1171,8 +1171,7 @@ static void *shard_run(void *arg)
     j->win_ll = malloc((j->n_win + 1) * 24);
     if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
         return NULL;
-    if (j->want_sites && (ibdg_get_site_af(j->eng, j->site_af + j->a) ||
-                          ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a)))
+    if (j->want_sites && ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a))
         return NULL;
     j->failed = 0;
     return NULL;
@@ -1283,7 +1282,7 @@ typedef struct {
     const uint8_t *s_nr, *s_na;
     const double *pdg;          /* ibdg_pdg_table */
     unsigned tgt;
-    double *site_af, *site_ll;
+    double *site_ll;
 } host_site_job;
 
 static void *host_site_rows(void *arg)
@@ -1294,7 +1293,6 @@ static void *host_site_rows(void *arg)
         const cand_t *c = &j->cand[j->s_cand[i]];
         const double *p = j->pdg + ((size_t)j->s_nr[i] * d + j->s_na[i]) * 3;
         const unsigned a0 = row_allele(c->row, j->tgt, 0), a1 = row_allele(c->row, j->tgt, 1);
-        j->site_af[i] = c->f;
         j->site_ll[3 * i] = ibdg_pdg_ibd0(c->f, p[0], p[1], p[2]);
         j->site_ll[3 * i + 1] = ibdg_pdg_ibd1(a0, a1, c->f, p[0], p[1], p[2]);
         j->site_ll[3 * i + 2] = p[a0 + a1];                                  /* :643-651 */
@@ -1303,7 +1301,7 @@ static void *host_site_rows(void *arg)
 }
 
 static void host_nonld(const cand_t *cand, const uint32_t *s_cand, const uint8_t *s_nr, const uint8_t *s_na, size_t n,
-                       unsigned tgt, const double *pdg, int threads, double *site_af, double *site_ll,
+                       unsigned tgt, const double *pdg, int threads, double *site_ll,
                        const uint32_t *w_first, const uint32_t *w_last, size_t n_win, double *win_ll)
 {
     host_site_job jobs[64];
@@ -1315,7 +1313,7 @@ static void host_nonld(const cand_t *cand, const uint32_t *s_cand, const uint8_t
         host_site_job *j = &jobs[t];
         j->a = n * (size_t)t / (size_t)T; j->b = n * (size_t)(t + 1) / (size_t)T;
         j->cand = cand; j->s_cand = s_cand; j->s_nr = s_nr; j->s_na = s_na; j->pdg = pdg; j->tgt = tgt;
-        j->site_af = site_af; j->site_ll = site_ll;
+        j->site_ll = site_ll;
         if (T == 1 || pthread_create(&th[t], NULL, host_site_rows, j) != 0) {
             host_site_rows(j);
             th[t] = pthread_self();
@@ -1357,6 +1355,10 @@ static void *upload_run(void *arg)
 {
     upload_job *j = arg;
     j->failed = 1;
+    /* the per-site table needs LIBD0/1/2 of every row (its AF column the host has itself); --summary-only needs
+     * nothing per row: the engine then neither keeps nor computes per-row results beyond the IBD2 pick */
+    if (ibdg_set_option(j->eng, "site_results", opt_summary_only ? 0 : 2))
+        return NULL;
     if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
         return NULL;
     if (j->ref_order) {                                   /* background list in the -B file's order (:741) */
@@ -1413,16 +1415,52 @@ static void quit(int code)
     exit(code);
 }
 
+typedef struct {
+    dev_job_t *job;
+    int d;
+} dev_one_t;
+
+static void *dev_start_one(void *arg)
+{
+    dev_one_t *o = arg;
+    dev_job_t *j = o->job;
+    j->eng[o->d] = ibdg_create(j->dev[o->d], j->eps, j->max_cov);
+    return NULL;
+}
+
+/* The first context brings the runtime up; the others (one per further device: each device's own start-up takes
+ * about as long again) are created side by side.  A failure is reported with the engine's message, which is
+ * per process: with several failing devices it is one of theirs. */
 static void *dev_start(void *arg)
 {
     dev_job_t *j = arg;
-    for (int d = 0; d < j->n; ++d) {
-        j->eng[d] = ibdg_create(j->dev[d], j->eps, j->max_cov);
+    dev_one_t one[64];
+    pthread_t th[64];
+    int started[64] = {0};
+    if (j->n < 1)
+        return NULL;
+    one[0].job = j;
+    one[0].d = 0;
+    dev_start_one(&one[0]);
+    if (!j->eng[0]) {
+        j->err[0] = strdup(ibdg_last_error(NULL));
+        return NULL;
+    }
+    for (int d = 1; d < j->n; ++d) {
+        one[d].job = j;
+        one[d].d = d;
+        started[d] = pthread_create(&th[d], NULL, dev_start_one, &one[d]) == 0;
+        if (!started[d])
+            dev_start_one(&one[d]);
+    }
+    for (int d = 1; d < j->n; ++d)
+        if (started[d])
+            pthread_join(th[d], NULL);
+    for (int d = 1; d < j->n; ++d)
         if (!j->eng[d]) {
             j->err[d] = strdup(ibdg_last_error(NULL));
-            break;                     /* the message of the first failure is the one reported */
+            break;
         }
-    }
     return NULL;
 }
 
@@ -1698,8 +1736,8 @@ int main(int argc, char **argv)
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
     /* the per-site values are only fetched for the per-site table: no 128 MB of page-locked memory for --summary-only */
     const size_t n_site_out = opt_summary_only && !no_engine ? 1 : (n_cand ? n_cand : 1);
-    double *site_af = io_alloc(n_site_out * 8, pin), *site_ll = io_alloc(n_site_out * 24, pin);
-    if (!s_row || !s_cand || !s_nr || !s_na || !site_af || !site_ll)
+    double *site_ll = io_alloc(n_site_out * 24, pin);
+    if (!s_row || !s_cand || !s_nr || !s_na || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("page-locked result arrays");
     uint32_t *s_row_dev = NULL;     /* slice_mode: the site list's rows counted from each device's first row */
@@ -1771,7 +1809,7 @@ int main(int argc, char **argv)
             if (host_math) {
                 win_ll = malloc((n_win + 1) * 24);
                 host_nonld(cand, s_cand, s_nr, s_na, n, tgt, pdg_tab, opt_threads > 0 ? opt_threads : default_threads(),
-                           site_af, site_ll, w_first, w_last, n_win, win_ll);
+                           site_ll, w_first, w_last, n_win, win_ll);
             }
         } else {
             /* one contiguous window range per GPU, evaluated concurrently, gathered in order */
@@ -1826,7 +1864,7 @@ int main(int argc, char **argv)
                     j->do_upload = j->do_run = 1;
                 }
                 j->bg_count = bg_count; j->pu_id = (int)pu_id; j->ld = opt_ld;
-                j->site_af = site_af; j->site_ll = site_ll;
+                j->site_ll = site_ll;
                 /* (no thread to be had: the shard runs here -- never exit() while other shard threads are
                  * inside the GPU runtime) */
                 th_started[d] = n_eng > 1 && pthread_create(&th[d], NULL, shard_run, j) == 0;
@@ -1896,7 +1934,6 @@ int main(int argc, char **argv)
             proto.cand = cand;
             proto.s_cand = s_cand;
             proto.pu = pu;
-            proto.site_af = site_af;
             proto.site_ll = site_ll;
             proto.s_nr = s_nr;
             proto.s_na = s_na;

@@ -171,10 +171,10 @@ int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out
 
 /* Device time of the last ibdg_run, from HIP events on the engine's streams:
  * out[0] total (first launch to last completion), out[1] alt-count kernel
- * (0 if not run), out[2] per-site kernel, out[3] the --LD launches, out[4]
- * window-product kernel (ms).  The per-site and window-product kernels run on
- * a second stream beside the --LD kernels, so the parts overlap and need not
- * add up to the total. */
+ * (0 if not run), out[2] the kernel of the per-row values and window products,
+ * out[3] the --LD launches, out[4] 0 (ms; until ABI 2 the window products were
+ * a kernel of their own).  The per-row kernel runs on a second stream beside
+ * the --LD kernels, so the parts overlap and need not add up to the total. */
 int ibdg_last_run_ms(ibdg_ctx *ctx, float out[5]);
 
 /* The same for the run `back` calls ago (0 = the last one); the engine keeps the
@@ -202,7 +202,11 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * queue one run per comparison individual without a host round trip between
  * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it; beside the --LD kernel the recount runs with "recount_blocks_per_cu"
- * single-wave workgroups per CU, default 4, 0 = its full grid); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
+ * single-wave workgroups per CU, default 4, 0 = its full grid); "site_results" (what ibdg_run keeps per row: 1, the default,
+ * LIBD0/1/2 of every row and comparison individual and the AF column, for ibdg_get_site_ll / ibdg_get_site_af; 2 the same
+ * without the AF column; 0 nothing -- no n_targets x n_sites x 24 bytes of device memory, no per-row stores, and in --LD
+ * mode only the IBD2 pick of a row is computed at all: for callers that want the window table only, e.g. hundreds of
+ * comparison individuals in one call; the two getters then fail); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
  * ordinary host memory goes to the device through page-locked staging buffers filled by a team of host
  * threads instead of the runtime's pageable-memory path); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference

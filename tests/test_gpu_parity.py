@@ -435,6 +435,50 @@ def test_all_sites_zero_coverage():
         assert (eng.site_ll(0)[:, [0, 2]] == 1.0).all()
 
 
+@pytest.mark.parametrize("N,L,W,T", [(70, 900, 100, 1), (150, 2500, 37, 3), (300, 700, 2, 6), (64, 300, 257, 2)])
+def test_site_results_option_changes_no_window_bit(oracle, N, L, W, T):
+    """Option "site_results": 0 keeps (and in --LD mode computes) nothing per row, 2 keeps LIBD0/1/2 without the AF
+    column.  The window table must be the same bits in every mode, --LD or not, and equal the oracle's; rows
+    without reads between and around the windows must not disturb the products (reference src/ibdgem.c:657-667)."""
+    alle, nr, na = synth(77 + N, L, N)
+    nr[:5] = na[:5] = 0                      # rows without reads before the first window ...
+    nr[-7:] = na[-7:] = 0                    # ... and behind the last
+    targets = [(3 + 11 * i) % N for i in range(T)]
+    with E.Engine(0, 0.02, 20) as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, W)
+        for ld in (False, True):
+            eng.set_option("site_results", 1)
+            eng.run(targets, ld=ld)
+            win = [eng.window_ll(i) for i in range(T)]
+            site = [eng.site_ll(i) for i in range(T)]
+            af = eng.site_af()
+            for i, t in enumerate(targets):
+                res = oracle.compare(alle, nr, na, t, window=W, ld=ld)
+                assert_bits(site[i], res["site"], "site")
+                assert_bits(win[i][:, 2], res["win"][:, 2], "LIBD2")
+                if ld:
+                    assert_ld_close(win[i][:, :2], res["win"][:, :2], "LD window")
+                else:
+                    assert_bits(win[i], res["win"], "window products")
+            eng.set_option("site_results", 2)
+            eng.run(targets, ld=ld)
+            for i in range(T):
+                assert_bits(eng.window_ll(i), win[i], "windows, mode 2")
+                assert_bits(eng.site_ll(i), site[i], "site, mode 2")
+            with pytest.raises(E.EngineError, match="AF column"):
+                eng.site_af()
+            eng.set_option("site_results", 0)
+            eng.run(targets, ld=ld)
+            for i in range(T):
+                assert_bits(eng.window_ll(i), win[i], "windows, mode 0")
+            with pytest.raises(E.EngineError, match="no per-site results"):
+                eng.site_ll(0)
+        eng.set_option("site_results", 1)
+        eng.run(targets[:1], ld=True)
+        assert_bits(eng.site_af(), af, "AF column")
+
+
 # --------------------------------------------------------------------------- kernel selection
 def test_kernel_selection_and_fallback(oracle):
     """Auto picks the exponent-counting kernel when the P(D|G) table is the plain binomial

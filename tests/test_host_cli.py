@@ -327,8 +327,8 @@ def test_cli_window_sharding_over_several_contexts(tag, case, devices, tmp_path)
     elif "-D" not in args or slices:         # (-D thins the reads only when the depth is above the target)
         assert len(slices) == n_dev
         total = int(slices[0][-1])
-        first = [int(x[6]) for x in slices]
-        count = [int(x[8]) for x in slices]
+        first = [int(x[7]) for x in slices]          # "## panel slice of device D: rows R0 + N of TOTAL"
+        count = [int(x[9]) for x in slices]
         live = [(a, c) for a, c in zip(first, count) if c]
         # contiguous window ranges: ascending, and only the two rows at a cut may be shared... no row twice
         assert all(a + c <= b for (a, c), (b, _) in zip(live, live[1:]))

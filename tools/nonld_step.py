@@ -16,6 +16,6 @@ for lib in sys.argv[1:]:
     eng.sync()
     ms = (time.perf_counter() - t0) / 200 * 1e3
     eng.set_option("async", 0)
-    k = {n: float(np.mean([eng.run_ms(i)[n] for i in range(16)])) for n in ("site", "window")}
-    print(f"{lib}: non-LD step {ms:.4f} ms  k_site {k['site']:.4f}  k_window_prod {k['window']:.4f}")
+    k = float(np.mean([eng.run_ms(i)["rows"] for i in range(16)]))
+    print(f"{lib}: non-LD step {ms:.4f} ms  k_rows_windows {k:.4f}")
     eng.close()

@@ -21,5 +21,5 @@ for b in (0, 1, 2, 4, 8, 16, 0, 4):
     eng.set_option("site_blocks_per_cu", b)
     rate(30)
     ms = rate()
-    eng.set_option("async", 0); k = {n: float(np.mean([eng.run_ms(i)[n] for i in range(16)])) for n in ("site", "window", "ld")}; eng.set_option("async", 1)
-    print(f"site blocks/CU {b}: {ms:.4f} ms/step  k_site {k['site']:.3f}  k_window_prod {k['window']:.3f}  ld launches {k['ld']:.3f}")
+    eng.set_option("async", 0); k = {n: float(np.mean([eng.run_ms(i)[n] for i in range(16)])) for n in ("rows", "ld")}; eng.set_option("async", 1)
+    print(f"site blocks/CU {b}: {ms:.4f} ms/step  k_rows_windows {k['rows']:.3f}  ld launches {k['ld']:.3f}")
