@@ -55,6 +55,7 @@ struct ibdg_ctx {
         hipEvent_t prep = nullptr;          // main stream: the target operands of the matrix-core kernel are built
         hipEvent_t start = nullptr;         // start_own or the previous run's ld_end
         bool recount = false, ld = false;
+        bool rows_on_main = false;          // non-LD run: the one kernel went to the main stream, stream2 was not used
     } evs[EV_RING];
     int ev_head = 0;
     long runs_done = 0;
@@ -89,7 +90,7 @@ struct ibdg_ctx {
     bool sites_valid = false;           // an upload of sites has succeeded since the last upload of a panel
     std::vector<uint32_t> runs_h;
     // power tables (functions of epsilon only; grown on demand, see grow_pow_tables)
-    std::vector<ibdg::PowEntry> p1_h, p2_h;
+    std::vector<ibdg::PowEntry> p1_h, p2_h, p3_h;      // rho^n, sigma^n, tau^n = (rho / sigma^2)^n (k_ld_mfma)
     std::vector<ibdg::WinRaw> pb_h;
     size_t tab_dev = 0;                 // entries the device copies hold
     size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
@@ -97,7 +98,7 @@ struct ibdg_ctx {
     float up_ms[3] = {0.f, 0.f, 0.f};   // copies, preparation on the device (with its host round trips), whole call
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
-    DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, partial;
+    DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, pow3, partial;
     // many comparison individuals (k_ld_mfma): target operands of a batch of groups, window constants per slot,
     // partial sums per half chunk, background multiplicities without the comparison individual's exclusion
     DevBuf aimg, wc_slot, partial_h, base_w;
@@ -533,21 +534,27 @@ bool grow_pow_tables(ibdg_ctx *c, size_t need)
     const size_t n = std::max(need, std::min<size_t>(old + old / 2 + 256, c->tab_fail_from));
     const long double one_me = (long double)(double)(1 - c->eps);
     const ME rho = me_norm((long double)c->eps / one_me, 0), sigma = me_norm(0.5L / one_me, 0);
+    // tau = rho / sigma^2 = 4 eps (1 - eps): the same long-double eps and 1 - eps as rho and sigma are made of
+    const ME tau = me_norm(4.0L * (long double)c->eps * one_me, 0);
     c->p1_h.resize(n);
     c->p2_h.resize(n);
+    c->p3_h.resize(n);
     c->pb_h.resize(n);
     for (size_t k = old; k < n; ++k) {
-        const ME x = me_powl(rho, k), y = me_powl(sigma, k), z = me_pow(1 - c->eps, k);
-        if (x.e < -2000000000LL || y.e < -2000000000LL || z.e < -2000000000LL) {
+        const ME x = me_powl(rho, k), y = me_powl(sigma, k), z = me_pow(1 - c->eps, k), u = me_powl(tau, k);
+        if (x.e < -2000000000LL / 3 || y.e < -2000000000LL / 3 || z.e < -2000000000LL / 3 || u.e < -2000000000LL / 3 ||
+            u.e > 2000000000LL / 3) {
             c->tab_fail_from = k;
             c->p1_h.resize(k);
             c->p2_h.resize(k);
+            c->p3_h.resize(k);
             c->pb_h.resize(k);
             c->tab_dev = std::min(c->tab_dev, k);
             return need <= k;
         }
         c->p1_h[k].m = (double)x.m; c->p1_h[k].e = (int32_t)x.e; c->p1_h[k].pad = 0;
         c->p2_h[k].m = (double)y.m; c->p2_h[k].e = (int32_t)y.e; c->p2_h[k].pad = 0;
+        c->p3_h[k].m = (double)u.m; c->p3_h[k].e = (int32_t)u.e; c->p3_h[k].pad = 0;
         c->pb_h[k].m = (uint64_t)ldexpl(z.m, 64);        // exact: a 64-bit mantissa in [2^63, 2^64)
         c->pb_h[k].e = (int32_t)z.e;
         c->pb_h[k].pad = 0;
@@ -645,8 +652,9 @@ int build_segments(ibdg_ctx *c)
     if (c->tab_dev < c->p1_h.size()) {     // new entries since the last upload
         const size_t n = c->p1_h.size();
         if (ensure(c, c->pow1, n * sizeof(ibdg::PowEntry)) || ensure(c, c->pow2, n * sizeof(ibdg::PowEntry)) ||
-            ensure(c, c->powb, n * sizeof(ibdg::WinRaw)))
+            ensure(c, c->pow3, n * sizeof(ibdg::PowEntry)) || ensure(c, c->powb, n * sizeof(ibdg::WinRaw)))
             return 1;
+        HIP_TRY(c, hipMemcpyAsync(c->pow3.p, c->p3_h.data(), n * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->pow1.p, c->p1_h.data(), n * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->pow2.p, c->p2_h.data(), n * sizeof(ibdg::PowEntry), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->powb.p, c->pb_h.data(), n * sizeof(ibdg::WinRaw), hipMemcpyHostToDevice, c->stream));
@@ -807,7 +815,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
         release(*b);
@@ -1166,6 +1174,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     ibdg_ctx::EvSet &E = c->evs[ev_slot];
     E.recount = recount;
     E.ld = ld_mode != 0;
+    // a non-LD run is one kernel: it goes to the main stream (no second stream to start, wait for and join)
+    const bool rows_on_main = !ld_mode && !recount;
+    E.rows_on_main = rows_on_main;
     // Two streams: the per-site kernel and the window products (memory-bound, few waves) run on
     // stream2 beside the --LD kernels (VALU-bound) on the main stream.  stream2 starts a run when
     // the main stream does (a wait in stream2's queue costs the main stream nothing; it also orders
@@ -1188,7 +1199,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             HIP_TRY(c, hipEventRecord(E.start_own, c->stream));
             E.start = E.start_own;
         }
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
+        if (!rows_on_main)
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.start, 0));
     }
 
     ibdg::RowsArgs sa;
@@ -1224,7 +1236,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const size_t TGs = IBDG_TG;
         size_t n_gg = 0, T_g = 0;
         // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
-        const size_t group_bytes = (size_t)c->n_win * c->n_chunks * 32 * TGs + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 256;
+        const size_t group_bytes = (size_t)c->n_win * c->n_chunks * 32 * TGs + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
         if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && c->n_pairs < (1u << 23) &&
             group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
@@ -1255,7 +1267,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
             ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
-            ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 256) ||
+            ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 512) ||
             ensure(c, c->partial_h, T_batch * (size_t)c->n_win * c->n_chunks * 32))
             return 1;
         ibdg::PopArgs pa;
@@ -1308,6 +1320,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.wc_slot = (uint4 *)c->wc_slot.p;
             ma.pow_1me = pa.pow_1me;
             ma.pow_eps = pa.pow_eps;
+            ma.pow_tau = (const ibdg::PowEntry *)c->pow3.p;
             ma.tab_len = pa.tab_len;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
@@ -1428,36 +1441,41 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         } else if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
     }
+    if (rows_on_main) {
+        if (join_streams(c)) return 1;           // an earlier run's kernel on stream2 may still write the results
+        ibdg::launch_rows_windows(sa, (unsigned)T, c->stream, 0);
+    }
     if (!dispatch_events)
         HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
 
-    // stream2, queued after the critical path so that the --LD launches reach the device first
-    if (s2_after_prep)
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.prep, 0));
-    HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
-    if (recount) {
-        // beside the --LD kernel: few long-lived waves (opt_recount_blocks per CU), so that the recount does not
-        // take the wave slots the --LD workgroups need -- it is bound by HBM, they by instruction issue
-        ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
-                               c->stream2, ld_mode ? (unsigned)(c->n_cu * c->opt_recount_blocks) : 0u);
-        c->counts_valid = true;
-        HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
+    if (!rows_on_main) {
+        // stream2, queued after the critical path so that the --LD launches reach the device first
+        if (s2_after_prep)
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, E.prep, 0));
+        HIP_TRY(c, hipEventRecord(E.s2_start, c->stream2));
+        if (recount) {
+            // beside the --LD kernel: few long-lived waves (opt_recount_blocks per CU), so that the recount does not
+            // take the wave slots the --LD workgroups need -- it is bound by HBM, they by instruction issue
+            ibdg::launch_alt_count((const uint64_t *)c->panel.p, c->stride, c->n_rows, (uint32_t *)c->alt_count.p,
+                                   c->stream2, ld_mode ? (unsigned)(c->n_cu * c->opt_recount_blocks) : 0u);
+            c->counts_valid = true;
+            HIP_TRY(c, hipEventRecord(E.s2[0], c->stream2));
+        }
+        // the per-row values and the window products, one launch (k_rows_windows).  Beside the exponent-counting --LD
+        // kernel, which holds every wave slot, it gets few long-lived workgroups (opt_site_blocks per CU, shared among
+        // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
+        // (not when the alt counts are recounted in this run: the second stream's chain count -> rows is then the
+        // longer one of the two, and its kernels should be short; and not beside the matrix-core kernel, which leaves
+        // half of the wave slots free)
+        const bool shadow = ld_mode && !recount && !side_fast;
+        unsigned row_blocks = 0;
+        if (shadow && c->opt_site_blocks > 0)
+            row_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
+        ibdg::launch_rows_windows(sa, (unsigned)T, c->stream2, row_blocks);
+        HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
+        c->last_s2 = E.s2[2];
+        c->s2_pending = true;
     }
-    // the per-row values and the window products, one launch (k_rows_windows).  Beside the exponent-counting --LD
-    // kernel, which holds every wave slot, it gets few long-lived workgroups (opt_site_blocks per CU, shared among
-    // the targets): its gathers wait on memory either way, and the --LD workgroups keep their wave slots
-    // (not when the alt counts are recounted in this run: the second stream's chain count -> rows is then the longer
-    // one of the two, and its kernels should be short; and not beside the matrix-core kernel, which leaves half of
-    // the wave slots free)
-    const bool shadow = ld_mode && !recount && !side_fast;
-    unsigned row_blocks = 0;
-    if (shadow && c->opt_site_blocks > 0)
-        row_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
-    HIP_TRY(c, hipEventRecord(E.s2[1], c->stream2));
-    ibdg::launch_rows_windows(sa, (unsigned)T, c->stream2, row_blocks);
-    HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
-    c->last_s2 = E.s2[2];
-    c->s2_pending = true;
     HIP_TRY(c, hipGetLastError());
     c->ev_head = ev_slot;
     ++c->runs_done;
@@ -1519,15 +1537,19 @@ int ibdg_run_ms(ibdg_ctx *c, unsigned back, float out[5])
     if (quiesce(c)) return 1;
     float v, w;
     HIP_TRY(c, hipEventElapsedTime(&v, E.start, E.ld_end));
+    out[1] = out[4] = 0.f;
+    if (E.rows_on_main) {                        // non-LD: one kernel between the two events of the main stream
+        out[0] = out[2] = v;
+        out[3] = 0.f;
+        return 0;
+    }
     HIP_TRY(c, hipEventElapsedTime(&w, E.start, E.s2[2]));
     out[0] = v > w ? v : w;                  // the run ends when both streams are done
     out[3] = E.ld ? v : 0.f;
-    out[1] = 0.f;
     if (E.recount)
         HIP_TRY(c, hipEventElapsedTime(&out[1], E.s2_start, E.s2[0]));
-    HIP_TRY(c, hipEventElapsedTime(&v, E.s2[1], E.s2[2]));
+    HIP_TRY(c, hipEventElapsedTime(&v, E.recount ? E.s2[0] : E.s2_start, E.s2[2]));
     out[2] = v;                              // per-row values and window products are one kernel
-    out[4] = 0.f;
     return 0;
 }
 

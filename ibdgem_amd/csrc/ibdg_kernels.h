@@ -152,8 +152,9 @@ struct MfmaArgs {
     uint32_t n_runs, win_per_group;
     uint32_t max_seg;           // most segments in one run (LDS sizing)
     uint4 *aimg;                // [groups][n_segs][64] target operand of every segment (k_win_target_g)
-    uint4 *wc_slot;             // [groups][n_win][16] per target: 16<t0,cov> 16<t1,cov> 16(AT-<t0,alt>) 16(AT-<t1,alt>)
-    const PowEntry *pow_1me, *pow_eps;
+    uint4 *wc_slot;             // [groups][n_win][16][2] per comparison individual: U_t0, U_t1 mantissas | their exponents
+                                // (U_t = rho^-<t,alt> sigma^<t,cov>)
+    const PowEntry *pow_1me, *pow_eps, *pow_tau;    // rho^n, sigma^n, tau^n = (rho / sigma^2)^n
     uint32_t tab_len;
     const uint32_t *targets;    // [T]
     uint32_t t_base;            // first comparison individual of group 0 of this launch

@@ -13,9 +13,8 @@
 // individuals and one pair of rows that carries the weights themselves, which gives C(x) and A(x) of the
 // header's algebra) against 32 background individuals, 32 768 multiply-adds in the time of ~9 vector
 // instructions, where the counting kernels spend 24 vector instructions per comparison individual on the
-// same tile.  The integers are the same integers, so everything after them -- the table products, the
-// background sums in the fixed tree of wave_sum2, k_ld_finalize -- gives the bits of the other kernels
-// (tests: a batched run equals single runs bit for bit).
+// same tile.  The integers are the same integers as the counting kernels'; what follows them (the window
+// end below) is arranged for many comparison individuals per background individual.
 //
 // Work split: a wave = 32 background individuals (half a chunk of the transposed panel) x one run of
 // windows x one group of IBDG_TG = 15 comparison individuals; 4 waves per workgroup.
@@ -27,12 +26,22 @@
 //     two MFMAs (x0 and x1) accumulate into 2 x 16 registers;  C(x0 & x1) by and + popcount as before.
 //   per window: result register pair i of lane half h holds G(x, t0), G(x, t1) of comparison individual
 //     slot(h, i) for the lane's background individual, so every lane finishes 8 (individual, comparison
-//     individual) pairs without any exchange: four table products each, the weights, and the sums over the 32
-//     lanes of each half by a transposed reduction (reduce8_halves / reduce16_halves: every value through the
-//     tree of wave_sum2).  The two halves of a chunk are added by k_ld_finalize (halves = 1) -- the last
-//     addition of the 64-lane tree.  Nothing in the loops goes through the scalar memory path: the run's
-//     segment records are staged into LDS once per workgroup (a scalar load per segment cost more than the
-//     segment's arithmetic).
+//     individual) pairs without any exchange.  The exponents of a product are (header of ibdg_ld_popcount.hip)
+//         E2 = AT - <t,alt> - A(x) + G(x,t),   E3 = <t,cov> + C(x) - 2 G(x,t),
+//     so with tau = rho / sigma^2 = 4 eps (1-eps) the product factors into three parts,
+//         K' rho^E2 sigma^E3 = [K' rho^(AT - A(x)) sigma^C(x)] . [rho^-<t,alt> sigma^<t,cov>] . tau^G(x,t)
+//                            =            V_x                 .            U_t              . tau^G,
+//     V_x once per (background haplotype, window) in the lane, U_t once per (comparison haplotype, window) from
+//     k_win_slot_g, and ONE table look-up per product (the unfactored form needs two and eight address
+//     computations per comparison individual): Q(x0,t) + Q(x1,t) = mU_t . (V_x0 tau^G0 + V_x1 tau^G1 scaled by
+//     2^eU_t), everything as mantissa and integer exponent until one ldexp per product.  The eight addends of a lane
+//     go to the wave's LDS strip as they are finished, and the sums over the 32 lanes of each half come from
+//     reading the strip transposed (eight values per lane, then two exchange steps): 13 vector instructions
+//     where a reduction in registers took 51.  The two halves of a chunk are added by k_ld_finalize
+//     (halves = 1).  The association of the products and the order of the sums differ from the counting kernels',
+//     so the results agree with theirs (and the oracle's) to ~1e-14, not bit for bit; the bar is 1e-10.
+//     Nothing in the loops goes through the scalar memory path: the run's segment records are staged into
+//     LDS once per workgroup (a scalar load per segment cost more than the segment's arithmetic).
 // Operand / result layout of the instruction: tools/ubench/mfma_i8_layout.hip (checked on the device).
 #include "ibdg_kernels.h"
 #include "ibdg_ld_dev.h"
@@ -97,7 +106,9 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
     }
 }
 
-// (2) of the above: a wave per window, lane l = slot l & 15, segments l >> 4, l >> 4 + 4, ... of the window
+// (2) of the above: a wave per window, lane l = slot l & 15, segments l >> 4, l >> 4 + 4, ... of the window.
+// U_t = rho^-<t,alt> sigma^<t,cov> of the slot's two haplotypes as {mantissa, exponent}: the quotient of two
+// table mantissas (a correctly rounded division) and the difference of their exponents.
 __global__ __launch_bounds__(256) void k_win_slot_g(MfmaArgs a)
 {
     const unsigned grp = blockIdx.y;
@@ -106,9 +117,9 @@ __global__ __launch_bounds__(256) void k_win_slot_g(MfmaArgs a)
     if (w >= a.n_win)
         return;
     const uint32_t l = threadIdx.x & 63, q = l & 15;
-    const uint32_t AT = a.wconst[w].alt_total;
     uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
-    if (q < cnt && q != PSEUDO) {
+    const bool real = q < cnt && q != PSEUDO;
+    if (real) {
         const uint32_t tgt = a.targets[a.t_base + grp * TG + q];
         const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
         const uint32_t s1 = a.wconst[w + 1].seg_begin;
@@ -131,8 +142,19 @@ __global__ __launch_bounds__(256) void k_win_slot_g(MfmaArgs a)
         a0alt += __shfl_xor(a0alt, m);
         a1alt += __shfl_xor(a1alt, m);
     }
-    if (l < 16)
-        a.wc_slot[((size_t)grp * a.n_win + w) * 16 + q] = make_uint4(16 * a0cov, 16 * a1cov, 16 * (AT - a0alt), 16 * (AT - a1alt));
+    if (l < 16) {
+        uint4 um = make_uint4(0, 0, 0, 0), ue = um;       // empty slots: U = 0
+        if (real) {
+            const PowEntry r0 = a.pow_1me[a0alt], r1 = a.pow_1me[a1alt], s0 = a.pow_eps[a0cov], s1 = a.pow_eps[a1cov];
+            const double m0 = s0.m / r0.m, m1 = s1.m / r1.m;
+            um = make_uint4((uint32_t)__double2loint(m0), (uint32_t)__double2hiint(m0), (uint32_t)__double2loint(m1),
+                            (uint32_t)__double2hiint(m1));
+            ue = make_uint4((uint32_t)(s0.e - r0.e), (uint32_t)(s1.e - r1.e), 0, 0);
+        }
+        uint4 *dst = a.wc_slot + (((size_t)grp * a.n_win + w) * 16 + q) * 2;
+        dst[0] = um;
+        dst[1] = ue;
+    }
 }
 
 // the value of lane 32 + (l & 31) in every lane (v_permlane32_swap: the upper half of the first operand and
@@ -161,58 +183,82 @@ __device__ __forceinline__ double swz_get(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Sixteen sums over the 32 lanes of a half at once.  A butterfly per value costs five exchanges and five
-// additions each (80 + 80), every exchange a round trip through the LDS port whose latency this kernel is
-// bound by; here every level hands half of the values to the partner lane and keeps the other half --
-// 8 + 4 + 2 + 1 exchanges, then one butterfly level for the one value left: 16 exchanges and additions in
-// five round trips.  Every value still goes through the tree of the butterfly (level j adds the totals of
-// two adjacent blocks of 2^j lanes, own + partner's), so the sums are the same bits.
-// Lane n ends up with the total of value 8 (n & 1) + 4 (n >> 1 & 1) + 2 (n >> 2 & 1) + (n >> 3 & 1).
-__device__ __forceinline__ double reduce16_halves(const double (&v)[16], uint32_t n)
+constexpr uint32_t SS = 36;          // doubles per row of the reduction strip: 32 lanes + 4 of padding (reads two-way at most)
+
+// One comparison individual of the lane: register pair I of the two accumulators against the slot's U constants.
+// Six LDS reads in one round trip: the slot's two mantissas and two exponents (immediate offsets from the lane's
+// slot base) and the four tau^G entries.  Returns mU0 (q00 + q01) + mU1 (q10 + q11), the reference's
+// ((Q00 + Q01) + Q10) + Q11 (ibdgem.c:716-719, :744-745) up to the association.
+template <int I>
+__device__ __forceinline__ double comp_products(const v16i &acc0, const v16i &acc1, uint32_t slot_base, uint32_t tab_tau,
+                                                double mV0, double mV1, int eV0, int eV1)
 {
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4, b3 = n & 8;
-    double u[8], x[4], y[2];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        u[k] = (b0 ? v[k + 8] : v[k]) + swz_get<1>(b0 ? v[k] : v[k + 8]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        x[k] = (b1 ? u[k + 4] : u[k]) + swz_get<2>(b1 ? u[k] : u[k + 4]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        y[k] = (b2 ? x[k + 2] : x[k]) + swz_get<4>(b2 ? x[k] : x[k + 2]);
-    double z = (b3 ? y[1] : y[0]) + swz_get<8>(b3 ? y[0] : y[1]);
-    z = swz_add<16>(z);
-    return z;
+    constexpr int OFF = 128 * (I >> 1) + 32 * (I & 1);        // slot_of(h, I) * 32 bytes, the 2 h part is in slot_base
+    const uint32_t ad0 = lshl_add<4>((uint32_t)acc0[2 * I], tab_tau), ad1 = lshl_add<4>((uint32_t)acc1[2 * I], tab_tau);
+    const uint32_t ad2 = lshl_add<4>((uint32_t)acc0[2 * I + 1], tab_tau), ad3 = lshl_add<4>((uint32_t)acc1[2 * I + 1], tab_tau);
+    uint4 um, p0, p1, p2, p3;
+    uint2 ue;
+    asm volatile("ds_read_b128 %0, %6 offset:%11\n\t"
+                 "ds_read_b64 %1, %6 offset:%12\n\t"
+                 "ds_read_b128 %2, %7\n\t"
+                 "ds_read_b128 %3, %8\n\t"
+                 "ds_read_b128 %4, %9\n\t"
+                 "ds_read_b128 %5, %10\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(um), "=&v"(ue), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                 : "v"(slot_base), "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3), "n"(OFF), "n"(OFF + 16)
+                 : "memory");
+    const double mU0 = __hiloint2double((int)um.y, (int)um.x), mU1 = __hiloint2double((int)um.w, (int)um.z);
+    const int eU0 = (int)ue.x, eU1 = (int)ue.y;
+    const double q00 = __builtin_ldexp(mV0 * __hiloint2double((int)p0.y, (int)p0.x), eV0 + (int)p0.z + eU0);   // x0, t0
+    const double q01 = __builtin_ldexp(mV1 * __hiloint2double((int)p1.y, (int)p1.x), eV1 + (int)p1.z + eU0);   // x1, t0
+    const double q10 = __builtin_ldexp(mV0 * __hiloint2double((int)p2.y, (int)p2.x), eV0 + (int)p2.z + eU1);   // x0, t1
+    const double q11 = __builtin_ldexp(mV1 * __hiloint2double((int)p3.y, (int)p3.x), eV1 + (int)p3.z + eU1);   // x1, t1
+    return mU0 * (q00 + q01) + mU1 * (q10 + q11);
 }
 
-// The same for eight values: lane n ends up with the total of value 4 (n & 1) + 2 (n >> 1 & 1) + (n >> 2 & 1).
-__device__ __forceinline__ double reduce8_halves(const double (&v)[8], uint32_t n)
+// addend I of the lane into the wave's reduction strip: row (8 h + I), column n
+template <int I>
+__device__ __forceinline__ void strip_put(uint32_t put_addr, double v)
 {
-    const bool b0 = n & 1, b1 = n & 2, b2 = n & 4;
-    double u[4], x[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        u[k] = (b0 ? v[k + 4] : v[k]) + swz_get<1>(b0 ? v[k] : v[k + 4]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        x[k] = (b1 ? u[k + 2] : u[k]) + swz_get<2>(b1 ? u[k] : u[k + 2]);
-    double y = (b2 ? x[1] : x[0]) + swz_get<4>(b2 ? x[0] : x[1]);
-    y = swz_add<8>(y);
-    y = swz_add<16>(y);
-    return y;
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(put_addr), "v"(v), "n"(I * (int)SS * 8) : "memory");
 }
 
-// LDS per workgroup: window constants (16 B + 16 slots x 16 B per window), the two power tables,
-// the run's segment records
-size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
+// Lane L = 4 s + p adds the elements p, p + 4, ..., p + 28 of row s (a wave's LDS operations execute in order: the
+// reads see the writes of strip_put); two exchange steps within the quad finish the row.  Every lane of quad s
+// ends up with the sum of row s = the sum over the 32 lanes of half s >> 3 of their addend s & 7.
+__device__ __forceinline__ double strip_sum(uint32_t get_addr)
 {
-    return (size_t)win_per_group * 17 * 16 + (size_t)tab_len * 32 + (size_t)max_seg * 32;
+    double r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %8 offset:32\n\t"
+                 "ds_read_b64 %2, %8 offset:64\n\t"
+                 "ds_read_b64 %3, %8 offset:96\n\t"
+                 "ds_read_b64 %4, %8 offset:128\n\t"
+                 "ds_read_b64 %5, %8 offset:160\n\t"
+                 "ds_read_b64 %6, %8 offset:192\n\t"
+                 "ds_read_b64 %7, %8 offset:224\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(get_addr)
+                 : "memory");
+    double t = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    t = t + swz_get<1>(t);
+    t = t + swz_get<2>(t);
+    return t;
 }
 
 #ifndef IBDG_MFMA_WAVES
-#define IBDG_MFMA_WAVES 4           /* waves = half chunks per workgroup (8: 3 % slower; 5 or 6 waves per SIMD spill) */
+#define IBDG_MFMA_WAVES 4           /* waves = half chunks per workgroup */
 #endif
+// LDS per workgroup: window constants (16 B + 16 slots x 32 B per window), the three power tables,
+// the run's segment records, a reduction strip per wave
+size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
+{
+    return (size_t)win_per_group * 33 * 16 + (size_t)tab_len * 48 + (size_t)max_seg * 32 +
+           (size_t)IBDG_MFMA_WAVES * 16 * SS * 8;
+}
+
 #ifndef IBDG_MFMA_WAVES_PER_EU
 #define IBDG_MFMA_WAVES_PER_EU 4
 #endif
@@ -230,29 +276,25 @@ void k_ld_mfma(MfmaArgs a)
     if (seg1 == seg0)
         return;
 
-    uint4 *wcc = reinterpret_cast<uint4 *>(smem);                  // [win_per_group] eK, 16 AT + rho table, sigma table
-    uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][16] per slot
-    uint4 *tab = wcs + (size_t)a.win_per_group * 16;                // rho^n then sigma^n
-    uint4 *rec = tab + 2 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
-    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16;
+    uint4 *wcc = reinterpret_cast<uint4 *>(smem);                  // [win_per_group] eK, 16 AT + rho table, sigma table, segment end
+    uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][16 slots][2] U mantissas | U exponents
+    uint4 *tab = wcs + (size_t)a.win_per_group * 32;                // rho^n, sigma^n, tau^n
+    uint4 *rec = tab + 3 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
+    double *strip = reinterpret_cast<double *>(rec + 2 * (size_t)a.max_seg) + (size_t)wave * 16 * SS;   // this wave's
+    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16, tab3 = tab2 + a.tab_len * 16;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
         wcc[i] = make_uint4((uint32_t)W.eK, 16 * W.alt_total + tab1, tab2, a.wconst[w0 + i + 1].seg_begin);
     }
     {
-        const uint4 *src = a.wc_slot + ((size_t)grp * a.n_win + w0) * 16;
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 16; i += blockDim.x) {
-            uint4 v = src[i];
-            v.x += tab2;
-            v.y += tab2;
-            v.z += tab1;
-            v.w += tab1;
-            wcs[i] = v;
-        }
+        const uint4 *src = a.wc_slot + ((size_t)grp * a.n_win + w0) * 32;
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 32; i += blockDim.x)
+            wcs[i] = src[i];
     }
-    for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < 3 * a.tab_len; i += blockDim.x)
         tab[i] = i < a.tab_len ? reinterpret_cast<const uint4 *>(a.pow_1me)[i]
-                               : reinterpret_cast<const uint4 *>(a.pow_eps)[i - a.tab_len];
+                               : (i < 2 * a.tab_len ? reinterpret_cast<const uint4 *>(a.pow_eps)[i - a.tab_len]
+                                                    : reinterpret_cast<const uint4 *>(a.pow_tau)[i - 2 * a.tab_len]);
     // the run's segments: nothing in the loops below goes through the scalar path (a scalar load per segment
     // and its wait cost more than the segment's arithmetic)
     for (uint32_t i = threadIdx.x; i < seg1 - seg0; i += blockDim.x) {
@@ -280,21 +322,17 @@ void k_ld_mfma(MfmaArgs a)
     const uint4 *xt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64 + 32 * (hc & 1) + n;   // + pair * 64
     const uint4 *ai = a.aimg + (size_t)grp * a.n_segs * 64 + lane;                                              // + segment * 64
     const uint32_t sh = 4 * h;
-    uint32_t m32 = (uint32_t)-32;
-    asm volatile("" : "+v"(m32));
 
-    // where the lane's total of reduce16_halves goes: value 8 (n & 1) + 4 (n >> 1 & 1) + 2 (n >> 2 & 1) + (n >> 3 & 1) is
-    // s0 / s1 (odd) of register pair value >> 1; lanes 0..15 of each half store
-    const uint32_t val = 8 * (n & 1) + 4 * ((n >> 1) & 1) + 2 * ((n >> 2) & 1) + ((n >> 3) & 1);
-    // (eight-value path: value 4 (n & 1) + 2 (n >> 1 & 1) + (n >> 2 & 1) = register pair; lanes 0..7 store both sums)
-    const uint32_t val8 = 4 * (n & 1) + 2 * ((n >> 1) & 1) + ((n >> 2) & 1), st8_q = slot_of(h, val8);
-    const bool st8_ok = n < 8 && st8_q < cnt && st8_q != PSEUDO;
-    const size_t st8_row = (((size_t)(grp * TG + st8_q) * a.n_win) * n_half + hc) * 2;
+    // the reduction strip: lane (h, n) puts its addend I at row 8 h + I, column n; lane L = 4 s + p reads row s
+    const uint32_t put_addr = (uint32_t)(uintptr_t)(lds_void *)strip + (8 * h * SS + n) * 8;
+    const uint32_t get_addr = (uint32_t)(uintptr_t)(lds_void *)strip + ((lane >> 2) * SS + (lane & 3)) * 8;
+    // row s = lane >> 2 belongs to half s >> 3 = h and register pair s & 7: lane p = 0 of the quad stores it
+    const uint32_t st_q = slot_of(h, (lane >> 2) & 7);
+    const bool st_ok = (lane & 3) == 0 && st_q < cnt && st_q != PSEUDO;
+    const size_t st_row = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2;                       // window 0
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
     const uint32_t n_iter = 2 * ((cnt + 3) / 4);                   // register pairs that hold comparison individuals
-    const uint32_t st_q = slot_of(h, val >> 1);
-    const bool st_ok = n < 16 && st_q < cnt && st_q != PSEUDO;
-    const size_t st_row = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2 + (val & 1);   // window 0
+    const uint32_t wcs_lane = (uint32_t)(uintptr_t)(lds_void *)wcs + 64 * h;     // + 512 per window: slots 2 h, 2 h + 1, ...
 
     uint32_t s = seg0;
     // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested PF
@@ -355,77 +393,65 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t C0 = from_upper_half((uint32_t)acc0[14]), a0 = from_upper_half((uint32_t)acc0[15]);
         const uint32_t C1 = from_upper_half((uint32_t)acc1[14]), a1 = from_upper_half((uint32_t)acc1[15]);
         const int eK = (int)kc.x;
-        double P2;
+        double wP2, mV0, mV1;
+        int eV0, eV1;
         {
-            // pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH, E2 = AT - a0 - a1 + CH
-            uint4 p1, p2;
-            lds_read2(p1, p2, lshl_add<4>(CH - (a0 + a1), kc.y), lshl_add<4>(mad24<-2>(CH, C0 + C1), kc.z));
-            P2 = ld_value(eK, p1, p2);
+            // pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH, E2 = AT - a0 - a1 + CH;
+            // V_x = K' rho^(AT - A(x)) sigma^C(x) with the lane's background multiplicity folded into its mantissa
+            uint4 p1, p2, r0, s0, r1, s1;
+            const uint32_t ad1 = lshl_add<4>(CH - (a0 + a1), kc.y), ad2 = lshl_add<4>(mad24<-2>(CH, C0 + C1), kc.z);
+            const uint32_t ad3 = lshl_add<4>(0u - a0, kc.y), ad4 = lshl_add<4>(C0, kc.z);
+            const uint32_t ad5 = lshl_add<4>(0u - a1, kc.y), ad6 = lshl_add<4>(C1, kc.z);
+            asm volatile("ds_read_b128 %0, %6\n\t"
+                         "ds_read_b128 %1, %7\n\t"
+                         "ds_read_b128 %2, %8\n\t"
+                         "ds_read_b128 %3, %9\n\t"
+                         "ds_read_b128 %4, %10\n\t"
+                         "ds_read_b128 %5, %11\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(p1), "=&v"(p2), "=&v"(r0), "=&v"(s0), "=&v"(r1), "=&v"(s1)
+                         : "v"(ad1), "v"(ad2), "v"(ad3), "v"(ad4), "v"(ad5), "v"(ad6)
+                         : "memory");
+            wP2 = wgt * ld_value(eK, p1, p2);                  // :743
+            mV0 = wgt * (__hiloint2double((int)r0.y, (int)r0.x) * __hiloint2double((int)s0.y, (int)s0.x));
+            mV1 = wgt * (__hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)s1.y, (int)s1.x));
+            eV0 = eK + (int)r0.z + (int)s0.z;
+            eV1 = eK + (int)r1.z + (int)s1.z;
         }
-        const uint32_t a0m = 0u - 16u * a0, a1m = 0u - 16u * a1, C0s = 16u * C0, C1s = 16u * C1;
-        // (the slots' constants through the scalar path instead of LDS, both halves' and a select: 12 % slower)
-        const uint32_t slot_addr = (uint32_t)(uintptr_t)(lds_void *)wcs + ((w - w0) * 16 + 2 * h) * 16;
-        // ((Q00 + Q01) + Q10) + Q11 of comparison individual slot_of(h, i) (ibdgem.c:716-719, :744-745)
-        auto four_products = [&](uint32_t i) -> double {
-            uint32_t G00 = (uint32_t)acc0[2 * i], G10 = (uint32_t)acc0[2 * i + 1];
-            uint32_t G01 = (uint32_t)acc1[2 * i], G11 = (uint32_t)acc1[2 * i + 1];
-            if (i == 7) {                       // the upper half's last pair is the weights' own rows
-                G00 = h ? 0u : G00;
-                G10 = h ? 0u : G10;
-                G01 = h ? 0u : G01;
-                G11 = h ? 0u : G11;
-            }
-            const uint4 kt = lds_read_b128(slot_addr + (4 * (i >> 1) + (i & 1)) * 16);      // slot_of(h, i)
-            const uint32_t kc0 = kt.x, kc1 = kt.y, kb0 = kt.z, kb1 = kt.w;
-            // pDg[At+hx]: E3 = <t,cov> + Cx - 2 G(x,t), E2 = AT - <t,alt> - ax + G(x,t)
-            // (-16 a and 16 C are taken once per window: the sums below are plain additions, which issue at twice
-            // the rate of the shift-and-add forms)
-            uint32_t ad[8];
-            ad[0] = lshl_add<4>(G00, kb0 + a0m);   ad[1] = mad24r(G00, m32, kc0 + C0s);
-            ad[2] = lshl_add<4>(G01, kb0 + a1m);   ad[3] = mad24r(G01, m32, kc0 + C1s);
-            ad[4] = lshl_add<4>(G10, kb1 + a0m);   ad[5] = mad24r(G10, m32, kc1 + C0s);
-            ad[6] = lshl_add<4>(G11, kb1 + a1m);   ad[7] = mad24r(G11, m32, kc1 + C1s);
-            uint4 pw[8];
-            // (tried: two of the eight through the vector memory path, 30 % slower; plain C++ LDS loads that hipcc
-            // may schedule across comparison individuals instead of this statement with its own wait, 7 % slower)
-            lds_read_pow8(pw, ad);
-            const double Q00 = ld_value(eK, pw[0], pw[1]);
-            const double Q01 = ld_value(eK, pw[2], pw[3]);
-            const double Q10 = ld_value(eK, pw[4], pw[5]);
-            const double Q11 = ld_value(eK, pw[6], pw[7]);
-            return ((Q00 + Q01) + Q10) + Q11;
-        };
-        double s1[8];                                       // the IBD1 addends of the lane's eight comparison individuals
-        // (a short group occupies the first register pairs only: slots 4j .. 4j+3 are pairs 2j, 2j+1 of the two halves)
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i)
-            s1[i] = i < n_iter ? ((excl >> i) & 1 ? 0.0 : wgt) * four_products(i) : 0.0;          // :744-745
-        const double wP2 = wgt * P2;                        // :743
-        // The 32 individuals of the half chunk are summed in the tree of wave_sum2 (neighbours first).
+        const uint32_t slot_base = wcs_lane + (w - w0) * 512;
+        // the IBD1 addends of the lane's eight comparison individuals (:744-745) go to the strip as they are finished
+        // (a short group occupies the first register pairs only: slots 4j .. 4j+3 are pairs 2j, 2j+1 of the two halves;
+        // the upper half's last pair are the weights' own rows, which nobody reads back)
+#define IBDG_COMP(I)                                                                                         \
+        if (I < n_iter) {                                                                                    \
+            double v = comp_products<I>(acc0, acc1, slot_base, tab3, mV0, mV1, eV0, eV1);                    \
+            if (any_excl && ((excl >> I) & 1))                                                               \
+                v = 0.0;              /* no individual is in its own background (ibdgem.c:714) */           \
+            strip_put<I>(put_addr, v);                                                                       \
+        }
+        IBDG_COMP(0) IBDG_COMP(1) IBDG_COMP(2) IBDG_COMP(3) IBDG_COMP(4) IBDG_COMP(5) IBDG_COMP(6) IBDG_COMP(7)
+#undef IBDG_COMP
+        const double t1 = strip_sum(get_addr);
+        double t0;
         if (!any_excl) {
             // No lane of the wave is one of the group's comparison individuals (all but a few waves): the IBD0
-            // addends are the same for the eight of them -- one butterfly for that sum, the transposed reduction
-            // for the eight IBD1 sums only.
+            // addends are the same for all of them -- one butterfly over the half.
             double s0 = wP2;
             s0 = s0 + swz_get<1>(s0);
             s0 = s0 + swz_get<2>(s0);
             s0 = swz_add<4>(s0);
             s0 = swz_add<8>(s0);
             s0 = swz_add<16>(s0);
-            const double t1 = reduce8_halves(s1, n);
-            if (st8_ok)
-                *reinterpret_cast<double2 *>(a.partial + st8_row + (size_t)w * n_half * 2) = make_double2(s0, t1);
+            t0 = s0;
         } else {
-            double sv[16];
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) {
-                sv[2 * i] = (excl >> i) & 1 ? 0.0 : wP2;
-                sv[2 * i + 1] = s1[i];
-            }
-            const double tot = reduce16_halves(sv, n);
-            if (st_ok)
-                a.partial[st_row + (size_t)w * n_half * 2] = tot;
+            // the IBD0 addend of a lane counts for all comparison individuals but itself: a second turn of the strip
+#define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> I) & 1 ? 0.0 : wP2);
+            IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
+#undef IBDG_PUT0
+            t0 = strip_sum(get_addr);
         }
+        if (st_ok)
+            *reinterpret_cast<double2 *>(a.partial + st_row + (size_t)w * n_half * 2) = make_double2(t0, t1);
     }
 }
 

@@ -197,7 +197,9 @@ def test_config5_500_comparison_individuals_in_one_launch(chr1, oracle):
     batched = {i: (eng.window_ll(i), eng.site_ll(i)) for i in picks}
     for i in picks:
         eng.run([int(targets[i])], ld=True, pu_id=int(targets[3]))
-        assert (bits(eng.window_ll(0)) == bits(batched[i][0])).all(), f"target slot {i}: windows"
+        one = eng.window_ll(0)
+        assert (bits(one[:, 2]) == bits(batched[i][0][:, 2])).all(), f"target slot {i}: LIBD2"
+        ld_close(batched[i][0][:, :2], one[:, :2])          # factored window end: within the bar, not the same bits
         assert (bits(eng.site_ll(0)) == bits(batched[i][1])).all(), f"target slot {i}: sites"
     # the oracle on every window of two of the 500 (slot 3 is also the pileup's own sample, -N)
     for i in (3, 499):
