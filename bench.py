@@ -771,8 +771,48 @@ def main():
             eng.run(many_t, ld=True)
             ms = eng.last_run_ms()
             best = ms if best is None or ms["total"] < best["total"] else best
-        many = {"comparison_individuals": len(many_t), "run_ms": best["total"], "ms_per_individual": best["total"] / len(many_t),
-                "site_individual_pairs_per_s": n_cov * len(many_t) / (best["total"] * 1e-3),
+        T = len(many_t)
+        b_site_T = algorithmic_bytes_per_site(args.ids, T)          # N/4 + 4 + T x 24.24 B per windowed site
+        achieved_T = b_site_T * n_cov / (best["ld"] * 1e-3) / 1e9
+        # the same run with no per-row results kept (option site_results 0: the host program's --summary-only)
+        eng.set_option("site_results", 0)
+        eng.run(many_t, ld=True)
+        best0 = None
+        for _ in range(3):
+            eng.run(many_t, ld=True)
+            ms = eng.last_run_ms()
+            best0 = ms if best0 is None or ms["total"] < best0["total"] else best0
+        eng.set_option("site_results", 1)
+        b_site_T0 = args.ids / 4.0 + 4.0 + T * 0.24                  # ... without the 24 B per row and individual
+        pmc = None
+        pdir = os.path.join(REPO, "profiles")
+        for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+            if fn.endswith("_mfma_pmc.json"):
+                with open(os.path.join(pdir, fn)) as fh:
+                    k = json.load(fh).get("kernels", {}).get("ibdg::k_ld_mfma")
+                if k:
+                    pmc = {"profile": fn, "VALUBusy_pct": k.get("VALUBusy"), "LdsUtil_pct": k.get("LdsUtil"),
+                           "MfmaUtil_pct": k.get("MfmaUtil"), "valu_instructions_per_launch": k.get("SQ_INSTS_VALU"),
+                           "lds_instructions_per_launch": k.get("SQ_INSTS_LDS")}
+        many = {"comparison_individuals": T, "run_ms": best["total"], "ms_per_individual": best["total"] / T,
+                "site_individual_pairs_per_s": n_cov * T / (best["total"] * 1e-3),
+                "ld_launches_ms": best["ld"], "rows_kernel_ms": best["rows"],
+                "roofline": {"bound": "hbm", "kernel": "k_ld_mfma (groups of 15)", "bytes_per_site": b_site_T,
+                             "sites_per_launch": n_cov, "kernel_ms": best["ld"], "achieved": achieved_T, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved_T / HBM_PEAK_GBS,
+                             "busy_shares_from_profile": pmc,
+                             "note": "bytes_per_site = N/4 + 4 + T x 24.24 (SURVEY.md s8(d): the panel row once per launch, 24 B "
+                                     "of per-row output per individual); kernel_ms = the --LD launches of the run (k_win_target_g, "
+                                     "k_win_slot_g, k_ld_mfma, k_ld_finalize for all groups) from the engine's events.  This path is "
+                                     "bound by vector-ALU issue and the LDS port in its window ends (four table products per "
+                                     "background individual, comparison individual and window), far from the HBM roofline: the "
+                                     "busy shares are those of the committed counter profile"},
+                "without_per_row_results": {"run_ms": best0["total"], "ms_per_individual": best0["total"] / T,
+                                            "bytes_per_site": b_site_T0,
+                                            "hbm_frac": b_site_T0 * n_cov / (best0["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "device_memory_for_results_bytes": int(T * eng.n_windows * 24),
+                                            "note": "option site_results 0: no T x rows x 24 B array, no per-row stores; LIBD2 of "
+                                                    "the windows from the IBD2 pick of every row (k_rows_windows<false>)"},
                 "note": "one ibdg_run over that many comparison individuals against the resident panel (device time, best of 3): "
                         "groups of 15 through k_ld_mfma -- the sums that depend on the comparison individual as integer matrix "
                         "products (DESIGN.md s4.2); per-site values and window products of all of them included"}

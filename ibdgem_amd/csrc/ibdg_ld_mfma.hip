@@ -49,15 +49,14 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 namespace ibdg {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr uint32_t TG = IBDG_TG;     // comparison individuals per group
-#ifndef IBDG_MFMA_PREFETCH
-#define IBDG_MFMA_PREFETCH 2
-#endif
 constexpr uint32_t PSEUDO = 15;      // the slot whose two rows are the weights: row 30 = cov, row 31 = alt
 
 // Result register pair i (registers 2i, 2i+1) of lane half h holds rows (2i & 3) + 8 (2i >> 2) + 4 h (+1) of
@@ -185,29 +184,35 @@ __device__ __forceinline__ double swz_get(double v)
 
 constexpr uint32_t SS = 36;          // doubles per row of the reduction strip: 32 lanes + 4 of padding (reads two-way at most)
 
-// One comparison individual of the lane: register pair I of the two accumulators against the slot's U constants.
-// Six LDS reads in one round trip: the slot's two mantissas and two exponents (immediate offsets from the lane's
-// slot base) and the four tau^G entries.  Returns mU0 (q00 + q01) + mU1 (q10 + q11), the reference's
-// ((Q00 + Q01) + Q10) + Q11 (ibdgem.c:716-719, :744-745) up to the association.
-template <int I>
-__device__ __forceinline__ double comp_products(const v16i &acc0, const v16i &acc1, uint32_t slot_base, uint32_t tab_tau,
-                                                double mV0, double mV1, int eV0, int eV1)
+// (a << 4) + b with b in a scalar register (the tau table's LDS address is the same for the whole workgroup)
+__device__ __forceinline__ uint32_t lshl4_add_s(uint32_t a, uint32_t b)
 {
-    constexpr int OFF = 128 * (I >> 1) + 32 * (I & 1);        // slot_of(h, I) * 32 bytes, the 2 h part is in slot_base
-    const uint32_t ad0 = lshl_add<4>((uint32_t)acc0[2 * I], tab_tau), ad1 = lshl_add<4>((uint32_t)acc1[2 * I], tab_tau);
-    const uint32_t ad2 = lshl_add<4>((uint32_t)acc0[2 * I + 1], tab_tau), ad3 = lshl_add<4>((uint32_t)acc1[2 * I + 1], tab_tau);
-    uint4 um, p0, p1, p2, p3;
-    uint2 ue;
-    asm volatile("ds_read_b128 %0, %6 offset:%11\n\t"
-                 "ds_read_b64 %1, %6 offset:%12\n\t"
-                 "ds_read_b128 %2, %7\n\t"
-                 "ds_read_b128 %3, %8\n\t"
-                 "ds_read_b128 %4, %9\n\t"
-                 "ds_read_b128 %5, %10\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(um), "=&v"(ue), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
-                 : "v"(slot_base), "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3), "n"(OFF), "n"(OFF + 16)
-                 : "memory");
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(d) : "v"(a), "s"(b));
+    return d;
+}
+
+__device__ __forceinline__ void reg_swap(uint32_t &a, uint32_t &b)
+{
+    asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// the two operand slots change places
+__device__ __forceinline__ void slots_swap(uint2 &x0, uint4 &a0, uint2 &x1, uint4 &a1)
+{
+    reg_swap(x0.x, x1.x);
+    reg_swap(x0.y, x1.y);
+    reg_swap(a0.x, a1.x);
+    reg_swap(a0.y, a1.y);
+    reg_swap(a0.z, a1.z);
+    reg_swap(a0.w, a1.w);
+}
+
+// mU0 (q00 + q01) + mU1 (q10 + q11): the reference's ((Q00 + Q01) + Q10) + Q11 (ibdgem.c:716-719, :744-745) up to
+// the association, from the slot's U constants and the four tau^G entries
+__device__ __forceinline__ double comp_value(const uint4 &um, const uint2 &ue, const uint4 &p0, const uint4 &p1, const uint4 &p2,
+                                             const uint4 &p3, double mV0, double mV1, int eV0, int eV1)
+{
     const double mU0 = __hiloint2double((int)um.y, (int)um.x), mU1 = __hiloint2double((int)um.w, (int)um.z);
     const int eU0 = (int)ue.x, eU1 = (int)ue.y;
     const double q00 = __builtin_ldexp(mV0 * __hiloint2double((int)p0.y, (int)p0.x), eV0 + (int)p0.z + eU0);   // x0, t0
@@ -215,6 +220,44 @@ __device__ __forceinline__ double comp_products(const v16i &acc0, const v16i &ac
     const double q10 = __builtin_ldexp(mV0 * __hiloint2double((int)p2.y, (int)p2.x), eV0 + (int)p2.z + eU1);   // x0, t1
     const double q11 = __builtin_ldexp(mV1 * __hiloint2double((int)p3.y, (int)p3.x), eV1 + (int)p3.z + eU1);   // x1, t1
     return mU0 * (q00 + q01) + mU1 * (q10 + q11);
+}
+
+// Two comparison individuals of the lane (register pairs I and I + 1 of the two accumulators) per LDS round trip:
+// twelve reads in one statement -- per individual the slot's two mantissas and two exponents (immediate offsets
+// from the lane's slot base) and four tau^G entries.  At four waves per SIMD a round trip is not hidden by other
+// waves; one per individual (eight per window) cost 11 % more than one per two.
+template <int I>
+__device__ __forceinline__ void comp_pair(const v16i &acc0, const v16i &acc1, uint32_t slot_base, uint32_t tab_tau, double mV0,
+                                          double mV1, int eV0, int eV1, double &ra, double &rb)
+{
+    constexpr int OFA = 128 * (I >> 1) + 32 * (I & 1);        // slot_of(h, I) * 32 bytes, the 2 h part is in slot_base
+    constexpr int OFB = 128 * ((I + 1) >> 1) + 32 * ((I + 1) & 1);
+    const uint32_t a0 = lshl4_add_s((uint32_t)acc0[2 * I], tab_tau), a1 = lshl4_add_s((uint32_t)acc1[2 * I], tab_tau);
+    const uint32_t a2 = lshl4_add_s((uint32_t)acc0[2 * I + 1], tab_tau), a3 = lshl4_add_s((uint32_t)acc1[2 * I + 1], tab_tau);
+    const uint32_t b0 = lshl4_add_s((uint32_t)acc0[2 * I + 2], tab_tau), b1 = lshl4_add_s((uint32_t)acc1[2 * I + 2], tab_tau);
+    const uint32_t b2 = lshl4_add_s((uint32_t)acc0[2 * I + 3], tab_tau), b3 = lshl4_add_s((uint32_t)acc1[2 * I + 3], tab_tau);
+    uint4 uma, pa0, pa1, pa2, pa3, umb, pb0, pb1, pb2, pb3;
+    uint2 uea, ueb;
+    asm volatile("ds_read_b128 %0, %12 offset:%21\n\t"
+                 "ds_read_b64 %1, %12 offset:%22\n\t"
+                 "ds_read_b128 %2, %13\n\t"
+                 "ds_read_b128 %3, %14\n\t"
+                 "ds_read_b128 %4, %15\n\t"
+                 "ds_read_b128 %5, %16\n\t"
+                 "ds_read_b128 %6, %12 offset:%23\n\t"
+                 "ds_read_b64 %7, %12 offset:%24\n\t"
+                 "ds_read_b128 %8, %17\n\t"
+                 "ds_read_b128 %9, %18\n\t"
+                 "ds_read_b128 %10, %19\n\t"
+                 "ds_read_b128 %11, %20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(uma), "=&v"(uea), "=&v"(pa0), "=&v"(pa1), "=&v"(pa2), "=&v"(pa3), "=&v"(umb), "=&v"(ueb), "=&v"(pb0),
+                   "=&v"(pb1), "=&v"(pb2), "=&v"(pb3)
+                 : "v"(slot_base), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(OFA), "n"(OFA + 16),
+                   "n"(OFB), "n"(OFB + 16)
+                 : "memory");
+    ra = comp_value(uma, uea, pa0, pa1, pa2, pa3, mV0, mV1, eV0, eV1);
+    rb = comp_value(umb, ueb, pb0, pb1, pb2, pb3, mV0, mV1, eV0, eV1);
 }
 
 // addend I of the lane into the wave's reduction strip: row (8 h + I), column n
@@ -249,7 +292,8 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 }
 
 #ifndef IBDG_MFMA_WAVES
-#define IBDG_MFMA_WAVES 4           /* waves = half chunks per workgroup */
+#define IBDG_MFMA_WAVES 8           /* waves = half chunks per workgroup: 8 share one copy of the tables (4: the strips'
+                                       LDS leaves room for 3 waves per SIMD only, 12 % slower) */
 #endif
 // LDS per workgroup: window constants (16 B + 16 slots x 32 B per window), the three power tables,
 // the run's segment records, a reduction strip per wave
@@ -335,41 +379,34 @@ void k_ld_mfma(MfmaArgs a)
     const uint32_t wcs_lane = (uint32_t)(uintptr_t)(lds_void *)wcs + 64 * h;     // + 512 per window: slots 2 h, 2 h + 1, ...
 
     uint32_t s = seg0;
-    // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested PF
-    // segments ahead, into a queue of registers: one segment of this kernel is a few hundred cycles of work,
-    // a load from L2 or HBM takes a multiple of that.
-    constexpr uint32_t PF = IBDG_MFMA_PREFETCH;
-    uint2 xq[PF];
-    uint4 aq[PF];
-#pragma unroll
-    for (uint32_t d = 0; d < PF; ++d) {
-        xq[d] = make_uint2(0, 0);
-        aq[d] = make_uint4(0, 0, 0, 0);
-        if (seg0 + d < seg1) {
-            const uint32_t tile = __builtin_amdgcn_readfirstlane(rec[2 * d].x) & 0xffffffu;
-            xq[d] = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
-            aq[d] = ai[(size_t)(seg0 + d) * 64];
-        }
-    }
+    // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested two
+    // segments ahead, into two register slots used in turn (a queue that shifts costs six moves per segment):
+    // one segment of this kernel is a few hundred cycles of work, a load from L2 or HBM takes a multiple of that
+    // (one ahead: 0.40 ms per individual against 0.36; four: 0.40; six: 0.49 -- registers).
+    uint2 xq0 = make_uint2(0, 0), xq1 = xq0;
+    uint4 aq0 = make_uint4(0, 0, 0, 0), aq1 = aq0;
+    auto fetch = [&](uint32_t seg, uint2 &xq, uint4 &aq) {
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(rec[2 * (seg - seg0)].x) & 0xffffffu;
+        xq = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
+        aq = ai[(size_t)seg * 64];
+    };
+    fetch(seg0, xq0, aq0);
+    if (seg0 + 1 < seg1)
+        fetch(seg0 + 1, xq1, aq1);
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t w = w0; w < w1; ++w) {
         const uint4 kc = wcc[w - w0];
         const uint32_t se = __builtin_amdgcn_readfirstlane(kc.w);
-        v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-        uint32_t CH = 0;
-        for (; s < se; ++s) {
-            const uint2 x = xq[0];
-            const v4i A = {(int)aq[0].x, (int)aq[0].y, (int)aq[0].z, (int)aq[0].w};
+        v16i acc0, acc1;
+        uint32_t CH;
+        // one segment from operand slot (xq, aq), which is refilled for segment s + 2; the first segment of a window
+        // starts the sums (zero as the matrix instruction's addend: no 32 registers to clear per window)
+        auto segment = [&](uint2 &xq, uint4 &aq, auto first) {
+            const uint2 x = xq;
+            const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
             const uint4 r0 = rec[2 * (s - seg0)];
-#pragma unroll
-            for (uint32_t d = 0; d + 1 < PF; ++d) {
-                xq[d] = xq[d + 1];
-                aq[d] = aq[d + 1];
-            }
-            if (s + PF < seg1) {
-                const uint32_t tile = __builtin_amdgcn_readfirstlane(rec[2 * (s + PF - seg0)].x) & 0xffffffu;
-                xq[PF - 1] = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
-                aq[PF - 1] = ai[(size_t)(s + PF) * 64];
-            }
+            if (s + 2 < seg1)
+                fetch(s + 2, xq, aq);
             // B operand: byte j of dword d of lane half kb = the individual's bit of row 4 kb + d + 8 j -- one shift
             // and one mask per dword, no table
             const uint32_t b0 = x.x >> sh, b1 = x.y >> sh;
@@ -377,16 +414,50 @@ void k_ld_mfma(MfmaArgs a)
                             (int)((b0 >> 3) & 0x01010101u)};
             const v4i B1 = {(int)(b1 & 0x01010101u), (int)((b1 >> 1) & 0x01010101u), (int)((b1 >> 2) & 0x01010101u),
                             (int)((b1 >> 3) & 0x01010101u)};
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
             const uint32_t hom = x.x & x.y;
-            CH += (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
+            uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
             const uint32_t ncov = __builtin_amdgcn_readfirstlane(r0.x) >> 24;
             if (ncov > 3) {                      // deep rows (cov >= 8): max_cov < 128, seven planes at most
                 const uint4 r1 = rec[2 * (s - seg0) + 1];
-                CH += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
+                ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
                       ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
             }
+            if constexpr (decltype(first)::value) {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, zero16, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, zero16, 0, 0, 0);
+                CH = ch;
+            } else {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
+                CH += ch;
+            }
+        };
+        // Segments take the two operand slots in turn, slot 0 first in every window: two per turn of the loop, and
+        // after an odd number of segments the slots change places (six register moves per such window instead of
+        // six per segment for a queue that shifts).
+        if (s < se) {
+            segment(xq0, aq0, std::true_type());
+            ++s;
+            if (s < se) {
+                segment(xq1, aq1, std::false_type());
+                ++s;
+                while (s + 1 < se) {
+                    segment(xq0, aq0, std::false_type());
+                    ++s;
+                    segment(xq1, aq1, std::false_type());
+                    ++s;
+                }
+                if (s < se) {
+                    segment(xq0, aq0, std::false_type());
+                    ++s;
+                    slots_swap(xq0, aq0, xq1, aq1);
+                }
+            } else {
+                slots_swap(xq0, aq0, xq1, aq1);
+            }
+        } else {                                  // (every window has a covered row, hence a segment)
+            acc0 = acc1 = zero16;
+            CH = 0;
         }
 
         // ---- the window's end: every lane finishes its individual against 8 comparison individuals
@@ -419,39 +490,51 @@ void k_ld_mfma(MfmaArgs a)
             eV1 = eK + (int)r1.z + (int)s1.z;
         }
         const uint32_t slot_base = wcs_lane + (w - w0) * 512;
-        // the IBD1 addends of the lane's eight comparison individuals (:744-745) go to the strip as they are finished
+        // The IBD1 addends of the lane's eight comparison individuals (:744-745) go to the strip as they are finished
         // (a short group occupies the first register pairs only: slots 4j .. 4j+3 are pairs 2j, 2j+1 of the two halves;
-        // the upper half's last pair are the weights' own rows, which nobody reads back)
-#define IBDG_COMP(I)                                                                                         \
-        if (I < n_iter) {                                                                                    \
-            double v = comp_products<I>(acc0, acc1, slot_base, tab3, mV0, mV1, eV0, eV1);                    \
-            if (any_excl && ((excl >> I) & 1))                                                               \
-                v = 0.0;              /* no individual is in its own background (ibdgem.c:714) */           \
-            strip_put<I>(put_addr, v);                                                                       \
-        }
-        IBDG_COMP(0) IBDG_COMP(1) IBDG_COMP(2) IBDG_COMP(3) IBDG_COMP(4) IBDG_COMP(5) IBDG_COMP(6) IBDG_COMP(7)
-#undef IBDG_COMP
-        const double t1 = strip_sum(get_addr);
-        double t0;
-        if (!any_excl) {
-            // No lane of the wave is one of the group's comparison individuals (all but a few waves): the IBD0
-            // addends are the same for all of them -- one butterfly over the half.
-            double s0 = wP2;
-            s0 = s0 + swz_get<1>(s0);
-            s0 = s0 + swz_get<2>(s0);
-            s0 = swz_add<4>(s0);
-            s0 = swz_add<8>(s0);
-            s0 = swz_add<16>(s0);
-            t0 = s0;
-        } else {
-            // the IBD0 addend of a lane counts for all comparison individuals but itself: a second turn of the strip
+        // the upper half's last pair are the weights' own rows, whose slot has U = 0).  In the few waves that hold one
+        // of the group's comparison individuals, that lane's addends for itself are left out: no individual is in its
+        // own background (ibdgem.c:714).
+        auto window_end = [&](auto with_excl) {
+            constexpr bool EX = decltype(with_excl)::value;
+#define IBDG_COMP2(I)                                                                                        \
+            if (I < n_iter) {                                                                                \
+                double va, vb;                                                                               \
+                comp_pair<I>(acc0, acc1, slot_base, tab3, mV0, mV1, eV0, eV1, va, vb);                       \
+                if (EX) {                                                                                    \
+                    va = (excl >> I) & 1 ? 0.0 : va;                                                         \
+                    vb = (excl >> (I + 1)) & 1 ? 0.0 : vb;                                                   \
+                }                                                                                            \
+                strip_put<I>(put_addr, va);                                                                  \
+                strip_put<I + 1>(put_addr, vb);                                                              \
+            }
+            IBDG_COMP2(0) IBDG_COMP2(2) IBDG_COMP2(4) IBDG_COMP2(6)
+#undef IBDG_COMP2
+            const double t1 = strip_sum(get_addr);
+            double t0;
+            if (!EX) {
+                // the IBD0 addends are the same for all comparison individuals: one butterfly over the half
+                double s0 = wP2;
+                s0 = s0 + swz_get<1>(s0);
+                s0 = s0 + swz_get<2>(s0);
+                s0 = swz_add<4>(s0);
+                s0 = swz_add<8>(s0);
+                s0 = swz_add<16>(s0);
+                t0 = s0;
+            } else {
+                // the IBD0 addend of a lane counts for all comparison individuals but itself: a second turn of the strip
 #define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> I) & 1 ? 0.0 : wP2);
-            IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
+                IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
 #undef IBDG_PUT0
-            t0 = strip_sum(get_addr);
-        }
-        if (st_ok)
-            *reinterpret_cast<double2 *>(a.partial + st_row + (size_t)w * n_half * 2) = make_double2(t0, t1);
+                t0 = strip_sum(get_addr);
+            }
+            if (st_ok)
+                *reinterpret_cast<double2 *>(a.partial + st_row + (size_t)w * n_half * 2) = make_double2(t0, t1);
+        };
+        if (any_excl)
+            window_end(std::true_type());
+        else
+            window_end(std::false_type());
     }
 }
 
