@@ -28,6 +28,7 @@
  */
 #define _GNU_SOURCE
 #include <ctype.h>
+#include <float.h>
 #include <getopt.h>
 #include <limits.h>
 #include <math.h>
@@ -162,7 +163,7 @@ static int read_names(const char *fn, names_t *out)
         chomp1(line);
         if (out->n == cap) {
             cap = cap ? cap * 2 : 256;
-            out->names = realloc(out->names, cap * sizeof *out->names);
+            out->names = ls_xrealloc(out->names, cap * sizeof *out->names);
         }
         out->names[out->n++] = strdup(line);
     }
@@ -258,7 +259,7 @@ static int read_af_file(const char *fn, const char *chr)
             continue;
         if (af_n == cap) {
             cap = cap ? cap * 2 : 4096;
-            af_tab = realloc(af_tab, cap * sizeof *af_tab);
+            af_tab = ls_xrealloc(af_tab, cap * sizeof *af_tab);
         }
         af_tab[af_n++] = r;
     }
@@ -301,7 +302,7 @@ static int read_pos_file(const char *fn, const char *chr)
             continue;
         if (pos_n == cap) {
             cap = cap ? cap * 2 : 4096;
-            pos_tab = realloc(pos_tab, cap * sizeof *pos_tab);
+            pos_tab = ls_xrealloc(pos_tab, cap * sizeof *pos_tab);
         }
         pos_tab[pos_n++] = p;
     }
@@ -349,7 +350,7 @@ static uint32_t arena_add(const char *s)
         arena_cap = arena_cap ? arena_cap * 2 : (1 << 20);
         while (arena_len + l > arena_cap)
             arena_cap *= 2;
-        arena = realloc(arena, arena_cap);
+        arena = ls_xrealloc(arena, arena_cap);
     }
     memcpy(arena + arena_len, s, l);
     arena_len += l;
@@ -381,7 +382,7 @@ static uint32_t part_arena_add(legend_part *t, const char *s)
         t->arena_cap = t->arena_cap ? t->arena_cap * 2 : (1 << 20);
         while (t->arena_len + l > t->arena_cap)
             t->arena_cap *= 2;
-        t->arena = realloc(t->arena, t->arena_cap);
+        t->arena = ls_xrealloc(t->arena, t->arena_cap);
     }
     memcpy(t->arena + t->arena_len, s, l);
     t->arena_len += l;
@@ -392,7 +393,7 @@ static void part_add_legend_line(legend_part *t, const char *l)
 {
     if (t->n == t->cap) {
         t->cap = t->cap ? t->cap * 2 : (1 << 16);
-        t->rows = realloc(t->rows, t->cap * sizeof *t->rows);
+        t->rows = ls_xrealloc(t->rows, t->cap * sizeof *t->rows);
     }
     row_t *r = &t->rows[t->n++];
     memset(r, 0, sizeof *r);
@@ -443,7 +444,7 @@ static void *legend_parse(void *arg)
         const size_t len = nl ? (size_t)(nl - (j->base + p)) + 1 : j->b - p;
         if (len + 1 > cap) {
             cap = (len + 1) * 2;
-            buf = realloc(buf, cap);
+            buf = ls_xrealloc(buf, cap);
         }
         memcpy(buf, j->base + p, len);
         buf[len] = 0;
@@ -515,7 +516,7 @@ static void *read_legend(void *arg)
             rg[t].first = total;
             total += rg[t].lines;
         }
-        rows = realloc(rows, (total ? total : 1) * sizeof *rows);
+        rows = ls_xrealloc(rows, (total ? total : 1) * sizeof *rows);
         team_run(legend_parse, rg, T);
         size_t atotal = arena_len;
         for (int t = 0; t < T; ++t) {
@@ -524,7 +525,7 @@ static void *read_legend(void *arg)
         }
         if (atotal > arena_cap) {
             arena_cap = atotal;
-            arena = realloc(arena, arena_cap);
+            arena = ls_xrealloc(arena, arena_cap);
         }
         arena_len = atotal;
         team_run(legend_place, rg, T);
@@ -645,7 +646,7 @@ static int read_genotypes_vcf(const char *vcf_fn, names_t *ids)
         for (char *tok = strtok(p, "\t"); tok; tok = strtok(NULL, "\t")) {
             if (ids->n == cap) {
                 cap = cap ? cap * 2 : 256;
-                ids->names = realloc(ids->names, cap * sizeof *ids->names);
+                ids->names = ls_xrealloc(ids->names, cap * sizeof *ids->names);
             }
             ids->names[ids->n++] = strdup(tok);
         }
@@ -661,8 +662,8 @@ static int read_genotypes_vcf(const char *vcf_fn, names_t *ids)
     while ((line = ls_next(vcf, NULL))) {
         if (n_rows == cap) {
             cap = cap ? cap * 2 : (1 << 16);
-            rows = realloc(rows, cap * sizeof *rows);
-            packed = realloc(packed, cap * row_words * 8);
+            rows = ls_xrealloc(rows, cap * sizeof *rows);
+            packed = ls_xrealloc(packed, cap * row_words * 8);
         }
         row_t *r = &rows[n_rows];
         memset(r, 0, sizeof *r);
@@ -792,6 +793,8 @@ static unsigned cull(unsigned count, double cull_p)
  *   %e: a * 10^(6-E) in long double (64-bit mantissa; relative error < 2^-60 after the table product);
  *       when the result lies within 1e-6 of a rounding boundary or of a power of ten, sprintf decides.
  * `ibdgem --fmt-check N` compares them with sprintf on N random doubles (tests/test_host_cli.py). */
+/* put_e6's guard band (relative error of q below 2^-60) is argued for the 64-bit mantissa of the x87 long double */
+_Static_assert(LDBL_MANT_DIG >= 64, "put_e6 needs a long double with a 64-bit mantissa (x86-64); elsewhere use sprintf");
 static long double pow10_tab[700];           /* 10^(i-350) */
 static void fmt_init(void)
 {

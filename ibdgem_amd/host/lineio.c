@@ -136,3 +136,14 @@ size_t ls_mt_min_bytes(void)
     const char *e = getenv("IBDGEM_MT_MIN_BYTES");
     return e && *e ? (size_t)strtoull(e, NULL, 10) : (size_t)1 << 20;
 }
+
+void *ls_xrealloc(void *p, size_t bytes)
+{
+    void *q = realloc(p, bytes ? bytes : 1);
+    if (!q) {
+        static const char msg[] = "[::] ERROR: out of memory while reading the input files.\n";
+        if (write(2, msg, sizeof msg - 1) < 0) { /* nothing left to do about it */ }
+        _exit(1);
+    }
+    return q;
+}

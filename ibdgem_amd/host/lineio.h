@@ -26,4 +26,10 @@ void ls_split_lines(const char *base, size_t size, size_t from, int parts, size_
 /* files smaller than this are read line by line (1 MiB; IBDGEM_MT_MIN_BYTES in the environment overrides it,
  * which is how the tests send their small files through the threaded readers) */
 size_t ls_mt_min_bytes(void);
+
+/* realloc / malloc for the readers' growing tables, which run on worker threads with nobody to return an error to:
+ * on failure a message and _exit(1) -- not exit(): other threads may be inside the GPU runtime, whose exit handlers
+ * must not run under them. */
+void *ls_xrealloc(void *p, size_t bytes);
+#define ls_xmalloc(bytes) ls_xrealloc(NULL, (bytes))
 #endif

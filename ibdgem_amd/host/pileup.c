@@ -149,7 +149,7 @@ static void part_add_line(pu_part *t, const char *line, const char *chr, FILE *e
     char cb[256];
     if (t->n == t->cap) {
         t->cap = t->cap ? t->cap * 2 : (1 << 16);
-        t->lines = realloc(t->lines, t->cap * sizeof *t->lines);
+        t->lines = ls_xrealloc(t->lines, t->cap * sizeof *t->lines);
     }
     pu_line *l = &t->lines[t->n];
     const int st = pileup_parse_line_to(line, l, cb, err);
@@ -169,7 +169,7 @@ static void part_add_line(pu_part *t, const char *line, const char *chr, FILE *e
             if (strcmp(t->chr_names[ci], cb) == 0)
                 break;
     if (ci == t->n_chr) {
-        t->chr_names = realloc(t->chr_names, (t->n_chr + 1) * sizeof *t->chr_names);
+        t->chr_names = ls_xrealloc(t->chr_names, (t->n_chr + 1) * sizeof *t->chr_names);
         t->chr_names[t->n_chr++] = strdup(cb);
     }
     l->chr = (uint32_t)ci;
@@ -231,7 +231,7 @@ static void *pu_worker(void *arg)
         const size_t len = nl ? (size_t)(nl - (j->base + p)) + 1 : j->b - p;    /* with its '\n', like ls_next */
         if (len + 1 > cap) {
             cap = (len + 1) * 2;
-            buf = realloc(buf, cap);
+            buf = ls_xrealloc(buf, cap);
         }
         memcpy(buf, j->base + p, len);
         buf[len] = 0;
@@ -276,7 +276,7 @@ pileup_t *pileup_read_mt(const char *fn, const char *chr, int threads)
             pthread_join(th[t], NULL);
         total += jobs[t].part.n;
     }
-    pu->lines = malloc((total ? total : 1) * sizeof *pu->lines);
+    pu->lines = ls_xmalloc((total ? total : 1) * sizeof *pu->lines);
     for (int t = 0; t < threads; ++t) {
         pu_job *j = &jobs[t];
         if (j->msg_len)
@@ -284,14 +284,14 @@ pileup_t *pileup_read_mt(const char *fn, const char *chr, int threads)
         free(j->msg);
         /* chromosome names in order of first appearance over the whole file; lines renumbered to them */
         uint32_t map[256];
-        uint32_t *mp = j->part.n_chr <= 256 ? map : malloc(j->part.n_chr * sizeof *mp);
+        uint32_t *mp = j->part.n_chr <= 256 ? map : ls_xmalloc(j->part.n_chr * sizeof *mp);
         for (size_t c = 0; c < j->part.n_chr; ++c) {
             size_t g = 0;
             for (; g < pu->n_chr; ++g)
                 if (strcmp(pu->chr_names[g], j->part.chr_names[c]) == 0)
                     break;
             if (g == pu->n_chr) {
-                pu->chr_names = realloc(pu->chr_names, (pu->n_chr + 1) * sizeof *pu->chr_names);
+                pu->chr_names = ls_xrealloc(pu->chr_names, (pu->n_chr + 1) * sizeof *pu->chr_names);
                 pu->chr_names[pu->n_chr++] = j->part.chr_names[c];
             } else {
                 free(j->part.chr_names[c]);

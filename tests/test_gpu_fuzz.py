@@ -40,8 +40,8 @@ def test_host_program_against_the_reference_binary_on_random_inputs(threaded):
                     reason="the reference binary (oracle/_ref/ibdgem) is not in this tree")
 def test_host_program_with_many_comparison_individuals_against_the_reference_binary():
     """8-40 comparison individuals per case: the host program batches them and the engine takes them through its
-    matrix-core kernel (k_ld_mfma); every output file of every individual byte for byte (a seed without the
-    seventh-digit ties of 2-row windows)."""
+    matrix-core kernel (k_ld_mfma); every output file of every individual byte for byte, seventh-digit ties of
+    --LD values in windows of two or three rows aside (counted by the tool; a handful per thousand files)."""
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_cli_full.py"), "60", "42", "--many-targets"],
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
