@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -81,7 +82,10 @@ struct ibdg_ctx {
     DevBuf rec_all, rec_cov, cov_site, fo;
     DevBuf in_row, in_ref, in_alt;      // device copies of the caller's arrays (ibdg_upload_sites)
     DevBuf scan_tmp, info_dev, wraw, nck_dev, powb, win_first, win_last;
-    ibdg::PrepInfo *info_h = nullptr;   // pinned
+    ibdg::PrepInfo *info_h = nullptr;   // host-mapped mirror of the device's PrepInfo, filled in by the preparation kernels
+    uint32_t prep_seq = 0;              // hand-overs so far (info_h->seq == prep_seq: the latest one has arrived)
+    uint32_t prep_epoch = 0;            // of the single-pass scans (two per upload)
+    size_t seg_room = 0;                // segments the array was cleared for by stage A
     bool have_fo = false;
     size_t n_sites = 0;
     uint32_t n_cov = 0, window = 0, n_win = 0;
@@ -96,6 +100,7 @@ struct ibdg_ctx {
     size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
     hipEvent_t ev_up[3] = {};           // before the host-to-device copies, after them, after the last prep kernel
     float up_ms[3] = {0.f, 0.f, 0.f};   // copies, preparation on the device (with its host round trips), whole call
+    bool up_ms_pending = false;         // the first two are still to be read from the events
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
     DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, pow3, partial;
@@ -154,6 +159,7 @@ struct ibdg_ctx {
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 and AF kept for ibdg_get_site_*; 2: LIBD0/1/2 only; 0: neither --
                                      // no T x n_sites x 24 B of HBM, no per-site stores (window results only)
     int res_site_mode = 0;           // the mode the last run's results were produced under
+    bool prep_dirty = false;         // the device's PrepInfo may hold the leavings of an upload that did not finish
     long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
     // page-locked staging for large panels from pageable memory (staged_upload)
     static constexpr int STAGE_WORKERS = 8;
@@ -562,11 +568,26 @@ bool grow_pow_tables(ibdg_ctx *c, size_t need)
     return true;
 }
 
-// Copy the device's PrepInfo to the pinned host copy and wait for it.
-int read_info(ibdg_ctx *c)
+// Wait until the preparation kernels have handed hand-over number `seq` of PrepInfo to the host's mirror: a poll of
+// one word in host memory, which the last workgroup of the stage writes -- no copy to queue, no stream to drain
+// (each of those is a round trip of 10-15 us; an upload has two).  The stream is asked now and then whether it
+// has died under us.
+int wait_info(ibdg_ctx *c, uint32_t seq)
 {
-    HIP_TRY(c, hipMemcpyAsync(c->info_h, c->info_dev.p, sizeof(ibdg::PrepInfo), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const volatile uint32_t *flag = &c->info_h->seq;
+    for (unsigned spins = 1; *flag != seq; ++spins) {
+        if ((spins & 0xfff) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipErrorNotReady) {
+                if (*flag == seq)
+                    break;
+                if (e == hipSuccess)
+                    return fail(c, "[::] ERROR in ibdg_upload_sites: the site preparation finished without reporting");
+                return fail(c, "[::] ERROR in ibdg_upload_sites: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return 0;
 }
 
@@ -580,13 +601,13 @@ int build_segments(ibdg_ctx *c)
         return 0;
     const ibdg::PrepInfo &I = *c->info_h;
     // segments <= windows + tiles spanned when the rows are in file order (otherwise the device stops
-    // writing at the capacity and the exponent-counting kernel is not used)
+    // writing at the capacity and the exponent-counting kernel is not used); never more than stage A cleared
     uint64_t seg_cap = c->n_cov;
     if (I.last_row >= I.first_row)
         seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((I.last_row >> 5) - (I.first_row >> 5)) + 1);
-    if (ensure(c, c->segs, seg_cap * sizeof(ibdg::Seg)) || ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
-        ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)) ||
-        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(c->n_sites, 1)) * 4))
+    seg_cap = std::min<uint64_t>(seg_cap, c->seg_room);
+    if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
+        ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
         return 1;
     if (!c->nck_dev.p) {
         if (ensure(c, c->nck_dev, c->nck_h.size() * 8)) return 1;
@@ -603,8 +624,12 @@ int build_segments(ibdg_ctx *c)
     sa.seg_cap = (uint32_t)seg_cap;
     sa.wconst = (ibdg::WinConst *)c->wconst.p;
     sa.raw = (ibdg::WinRaw *)c->wraw.p;
-    sa.block_tmp = (uint32_t *)c->scan_tmp.p;
+    sa.chain_state = (unsigned long long *)c->scan_tmp.p;
+    sa.epoch = ++c->prep_epoch;
     sa.info = (ibdg::PrepInfo *)c->info_dev.p;
+    sa.ctl = (ibdg::PrepCtl *)((char *)c->info_dev.p + sizeof(ibdg::PrepInfo));
+    sa.mirror = c->info_h;
+    c->prep_dirty = true;
     ibdg::launch_prep_segments(sa, c->stream);
     HIP_TRY(c, hipGetLastError());
 
@@ -625,13 +650,13 @@ int build_segments(ibdg_ctx *c)
         c->n_runs = (uint32_t)c->runs_h.size() - 1;
         if (ensure(c, c->runs, c->runs_h.size() * 4))
             return 1;
-        // runs_h is a member: it outlives the copy (the next wait is read_info below)
+        // runs_h is a member: it outlives the copy (the next wait is wait_info below)
         HIP_TRY(c, hipMemcpyAsync(c->runs.p, c->runs_h.data(), c->runs_h.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(&((ibdg::PrepInfo *)c->info_dev.p)->max_seg, 0, 8, c->stream));   // max_seg, adv_overflow
-        ibdg::launch_prep_seg_flags(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, c->stream);
+        ibdg::launch_prep_seg_flags(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, ++c->prep_seq, c->stream);
         HIP_TRY(c, hipGetLastError());
-        if (read_info(c))
+        if (wait_info(c, c->prep_seq))
             return 1;
+        c->prep_dirty = false;
         if (I.out_of_order || I.n_segs > seg_cap)
             return 0;                      // not in file order: only the strict kernel applies
         if ((size_t)I.max_seg * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1)
@@ -779,8 +804,10 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     }
     for (hipEvent_t &ev : c->ev_up)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipHostMalloc((void **)&c->info_h, sizeof(ibdg::PrepInfo), hipHostMallocDefault)) != hipSuccess)
+    // (coherent: the kernels' stores must reach the host while the stream is still busy, not at its next drain)
+    if ((e = hipHostMalloc((void **)&c->info_h, sizeof(ibdg::PrepInfo), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return bail("hipHostMalloc", e);
+    memset(c->info_h, 0, sizeof(ibdg::PrepInfo));
     {
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
@@ -906,29 +933,64 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     c->pop_sites_ok = false;
     c->win_bounds_valid = false;
     c->have_fo = false;
+    // segments of stage B: at most one per site, and in file order at most windows + tiles of the panel
+    const size_t seg_room = std::min<size_t>(n_sites, (n_sites + window - 1) / window + (c->n_rows + 31) / 32 + 1);
+    const bool fresh_info = !c->info_dev.p;
+    const size_t chain_cap_before = c->scan_tmp.cap;
     if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
-        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
-        ensure(c, c->info_dev, sizeof(ibdg::PrepInfo)))
+        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 8) ||
+        ensure(c, c->info_dev, sizeof(ibdg::PrepInfo) + sizeof(ibdg::PrepCtl)) ||
+        (c->pop_lut_ok && ensure(c, c->segs, seg_room * sizeof(ibdg::Seg))))
         return 1;
-    memset(c->info_h, 0, sizeof(ibdg::PrepInfo));
-    c->info_h->err_row_site = c->info_h->err_cov_site = 0xffffffffu;
-    HIP_TRY(c, hipMemcpyAsync(c->info_dev.p, c->info_h, sizeof(ibdg::PrepInfo), hipMemcpyHostToDevice, c->stream));
-    ibdg::PrepSiteArgs pa;
-    pa.row_index = d_row;
-    pa.n_ref = d_ref;
-    pa.n_alt = d_alt;
-    pa.n_sites = n_sites;
-    pa.n_rows = c->n_rows;
-    pa.max_cov = c->max_cov;
-    pa.rec_all = (uint2 *)c->rec_all.p;
-    pa.rec_cov = (uint2 *)c->rec_cov.p;
-    pa.cov_site = (uint32_t *)c->cov_site.p;
-    pa.block_tmp = (uint32_t *)c->scan_tmp.p;
-    pa.info = (ibdg::PrepInfo *)c->info_dev.p;
-    ibdg::launch_prep_sites(pa, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    if (read_info(c))
-        return 1;
+    if (fresh_info || c->prep_dirty) {
+        // the device's PrepInfo and the kernels' bookkeeping start clean; afterwards every upload leaves them so
+        // (not one that stopped at a validation error or a failed call: prep_dirty)
+        struct { ibdg::PrepInfo i; ibdg::PrepCtl c; } init;
+        memset(&init, 0, sizeof init);
+        init.i.err_row_site = init.i.err_cov_site = init.i.first_row = 0xffffffffu;
+        HIP_TRY(c, hipMemcpyAsync(c->info_dev.p, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // `init` is a local
+        c->prep_dirty = false;
+    }
+    if (c->scan_tmp.cap != chain_cap_before || c->prep_epoch > 0x3ffffff0u) {
+        // the scans' words are told apart by their epoch, never cleared -- except when they are new memory (whatever
+        // it holds could pass for a word of this launch) or, a thousand million uploads on, when the epochs start over
+        HIP_TRY(c, hipMemsetAsync(c->scan_tmp.p, 0, c->scan_tmp.cap, c->stream));
+        if (c->prep_epoch > 0x3ffffff0u)
+            c->prep_epoch = 0;
+    }
+    c->seg_room = c->pop_lut_ok ? seg_room : 0;
+    if (n_sites) {
+        c->prep_dirty = true;
+        ibdg::PrepSiteArgs pa;
+        pa.row_index = d_row;
+        pa.n_ref = d_ref;
+        pa.n_alt = d_alt;
+        pa.n_sites = n_sites;
+        pa.n_rows = c->n_rows;
+        pa.max_cov = c->max_cov;
+        pa.rec_all = (uint2 *)c->rec_all.p;
+        pa.rec_cov = (uint2 *)c->rec_cov.p;
+        pa.cov_site = (uint32_t *)c->cov_site.p;
+        pa.chain_state = (unsigned long long *)c->scan_tmp.p;
+        pa.epoch = ++c->prep_epoch;
+        pa.info = (ibdg::PrepInfo *)c->info_dev.p;
+        pa.ctl = (ibdg::PrepCtl *)((char *)c->info_dev.p + sizeof(ibdg::PrepInfo));
+        pa.mirror = c->info_h;
+        pa.seq = ++c->prep_seq;
+        pa.clear = c->pop_lut_ok ? c->segs.p : nullptr;
+        pa.clear_bytes = c->pop_lut_ok ? seg_room * sizeof(ibdg::Seg) : 0;
+        ibdg::launch_prep_sites(pa, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        if (wait_info(c, c->prep_seq))
+            return 1;
+        c->prep_dirty = false;                  // the stage's last workgroup has left everything clean
+    } else {
+        c->prep_dirty = false;
+        memset(c->info_h, 0, sizeof(ibdg::PrepInfo));
+        c->info_h->err_row_site = c->info_h->err_cov_site = c->info_h->first_row = 0xffffffffu;
+        c->info_h->seq = c->prep_seq;
+    }
     const ibdg::PrepInfo &I = *c->info_h;
     if (I.err_row_site != 0xffffffffu || I.err_cov_site != 0xffffffffu) {
         // the first offending site in file order, its row checked before its counts (as a loop over the sites would)
@@ -991,16 +1053,16 @@ static double wall_ms(std::chrono::steady_clock::time_point t0)
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// After the last kernel of an upload: wait, then keep the three clocks of ibdg_upload_ms.
+// After the last kernel of an upload.  The call does not wait for it: everything the host needed it has polled
+// for, the caller's arrays have been read, and whatever uses the prepared sites next is queued behind that kernel
+// (K' of the windows) on the same stream.  The event clocks are read when somebody asks (ibdg_upload_ms).
 static int upload_sites_finish(ibdg_ctx *c, int rc, std::chrono::steady_clock::time_point t0)
 {
     if (rc)
         return rc;
     c->sites_valid = true;
     HIP_TRY(c, hipEventRecord(c->ev_up[2], c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipEventElapsedTime(&c->up_ms[0], c->ev_up[0], c->ev_up[1]));
-    HIP_TRY(c, hipEventElapsedTime(&c->up_ms[1], c->ev_up[1], c->ev_up[2]));
+    c->up_ms_pending = true;
     c->up_ms[2] = (float)wall_ms(t0);
     return 0;
 }
@@ -1046,6 +1108,12 @@ int ibdg_upload_sites_dev(ibdg_ctx *c, const void *dev_row_index, const void *de
 int ibdg_upload_ms(ibdg_ctx *c, float out[3])
 {
     if (!c || !out) return 1;
+    if (c->up_ms_pending) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_up[2]));
+        HIP_TRY(c, hipEventElapsedTime(&c->up_ms[0], c->ev_up[0], c->ev_up[1]));
+        HIP_TRY(c, hipEventElapsedTime(&c->up_ms[1], c->ev_up[1], c->ev_up[2]));
+        c->up_ms_pending = false;
+    }
     for (int i = 0; i < 3; ++i) out[i] = c->up_ms[i];
     return 0;
 }
