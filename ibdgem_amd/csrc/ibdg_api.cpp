@@ -84,7 +84,6 @@ struct ibdg_ctx {
     DevBuf scan_tmp, info_dev, wraw, nck_dev, powb, win_first, win_last;
     ibdg::PrepInfo *info_h = nullptr;   // host-mapped mirror of the device's PrepInfo, filled in by the preparation kernels
     uint32_t prep_seq = 0;              // hand-overs so far (info_h->seq == prep_seq: the latest one has arrived)
-    uint32_t prep_epoch = 0;            // of the single-pass scans (two per upload)
     size_t seg_room = 0;                // segments the array was cleared for by stage A
     bool have_fo = false;
     size_t n_sites = 0;
@@ -99,6 +98,7 @@ struct ibdg_ctx {
     size_t tab_dev = 0;                 // entries the device copies hold
     size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
     hipEvent_t ev_up[3] = {};           // before the host-to-device copies, after them, after the last prep kernel
+    hipEvent_t ev_prep2 = nullptr;      // stream2: the per-window constants of an upload are there
     float up_ms[3] = {0.f, 0.f, 0.f};   // copies, preparation on the device (with its host round trips), whole call
     bool up_ms_pending = false;         // the first two are still to be read from the events
 
@@ -603,15 +603,17 @@ int build_segments(ibdg_ctx *c)
     // segments <= windows + tiles spanned when the rows are in file order (otherwise the device stops
     // writing at the capacity and the exponent-counting kernel is not used); never more than stage A cleared
     uint64_t seg_cap = c->n_cov;
-    if (I.last_row >= I.first_row)
-        seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((I.last_row >> 5) - (I.first_row >> 5)) + 1);
+    const uint32_t first_row = I.first_row, last_row = I.last_row;     // of stage A: the mirror is overwritten by stage B's hand-over
+    if (last_row >= first_row)
+        seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((last_row >> 5) - (first_row >> 5)) + 1);
     seg_cap = std::min<uint64_t>(seg_cap, c->seg_room);
     if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
         ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
         return 1;
     if (!c->nck_dev.p) {
         if (ensure(c, c->nck_dev, c->nck_h.size() * 8)) return 1;
-        HIP_TRY(c, hipMemcpyAsync(c->nck_dev.p, c->nck_h.data(), c->nck_h.size() * 8, hipMemcpyHostToDevice, c->stream));
+        // (a blocking copy, once per context: the kernel that reads the table runs on the second stream)
+        HIP_TRY(c, hipMemcpy(c->nck_dev.p, c->nck_h.data(), c->nck_h.size() * 8, hipMemcpyHostToDevice));
     }
     ibdg::PrepSegArgs sa;
     sa.rec_cov = (const uint2 *)c->rec_cov.p;
@@ -624,14 +626,15 @@ int build_segments(ibdg_ctx *c)
     sa.seg_cap = (uint32_t)seg_cap;
     sa.wconst = (ibdg::WinConst *)c->wconst.p;
     sa.raw = (ibdg::WinRaw *)c->wraw.p;
-    sa.chain_state = (unsigned long long *)c->scan_tmp.p;
-    sa.epoch = ++c->prep_epoch;
+    sa.block_tmp = (uint32_t *)c->scan_tmp.p;
     sa.info = (ibdg::PrepInfo *)c->info_dev.p;
-    sa.ctl = (ibdg::PrepCtl *)((char *)c->info_dev.p + sizeof(ibdg::PrepInfo));
     sa.mirror = c->info_h;
     c->prep_dirty = true;
-    ibdg::launch_prep_segments(sa, c->stream);
+    // (stream2 is idle: ibdg_upload_sites drained both streams before it began; stage A has been waited for)
+    ibdg::launch_prep_segments(sa, c->stream, c->stream2);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_prep2, c->stream2));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep2, 0));      // before the control words' hand-over (ct_max) and K'
 
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
@@ -695,7 +698,7 @@ int build_segments(ibdg_ctx *c)
     // and last row (~175 issue cycles per tile and chunk) while the strict kernel touches covered rows
     // only (~49 cycles per row and chunk): below ~1 covered row in 9 the strict kernel is the faster one.
     {
-        const uint64_t span = (uint64_t)I.last_row - I.first_row + 1;
+        const uint64_t span = (uint64_t)last_row - first_row + 1;
         c->pop_dense_enough = (uint64_t)c->n_cov * 9 >= span;
     }
     return 0;
@@ -804,6 +807,7 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     }
     for (hipEvent_t &ev : c->ev_up)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_prep2, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // (coherent: the kernels' stores must reach the host while the stream is still busy, not at its next drain)
     if ((e = hipHostMalloc((void **)&c->info_h, sizeof(ibdg::PrepInfo), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return bail("hipHostMalloc", e);
@@ -849,6 +853,8 @@ void ibdg_destroy(ibdg_ctx *c)
     for (hipEvent_t ev : c->ev_up)
         if (ev)
             (void)hipEventDestroy(ev);
+    if (c->ev_prep2)
+        (void)hipEventDestroy(c->ev_prep2);
     for (int b = 0; b < 2 * ibdg_ctx::STAGE_WORKERS; ++b) {
         if (c->stage_ev[b])
             (void)hipEventDestroy(c->stage_ev[b]);
@@ -936,28 +942,20 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     // segments of stage B: at most one per site, and in file order at most windows + tiles of the panel
     const size_t seg_room = std::min<size_t>(n_sites, (n_sites + window - 1) / window + (c->n_rows + 31) / 32 + 1);
     const bool fresh_info = !c->info_dev.p;
-    const size_t chain_cap_before = c->scan_tmp.cap;
     if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
-        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 8) ||
-        ensure(c, c->info_dev, sizeof(ibdg::PrepInfo) + sizeof(ibdg::PrepCtl)) ||
+        ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
+        ensure(c, c->info_dev, sizeof(ibdg::PrepInfo)) ||
         (c->pop_lut_ok && ensure(c, c->segs, seg_room * sizeof(ibdg::Seg))))
         return 1;
     if (fresh_info || c->prep_dirty) {
-        // the device's PrepInfo and the kernels' bookkeeping start clean; afterwards every upload leaves them so
-        // (not one that stopped at a validation error or a failed call: prep_dirty)
-        struct { ibdg::PrepInfo i; ibdg::PrepCtl c; } init;
+        // the device's PrepInfo starts clean; afterwards every upload leaves it so (k_prep_mirror) -- unless it
+        // stopped half way: prep_dirty
+        ibdg::PrepInfo init;
         memset(&init, 0, sizeof init);
-        init.i.err_row_site = init.i.err_cov_site = init.i.first_row = 0xffffffffu;
+        init.err_row_site = init.err_cov_site = init.first_row = 0xffffffffu;
         HIP_TRY(c, hipMemcpyAsync(c->info_dev.p, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));          // `init` is a local
         c->prep_dirty = false;
-    }
-    if (c->scan_tmp.cap != chain_cap_before || c->prep_epoch > 0x3ffffff0u) {
-        // the scans' words are told apart by their epoch, never cleared -- except when they are new memory (whatever
-        // it holds could pass for a word of this launch) or, a thousand million uploads on, when the epochs start over
-        HIP_TRY(c, hipMemsetAsync(c->scan_tmp.p, 0, c->scan_tmp.cap, c->stream));
-        if (c->prep_epoch > 0x3ffffff0u)
-            c->prep_epoch = 0;
     }
     c->seg_room = c->pop_lut_ok ? seg_room : 0;
     if (n_sites) {
@@ -972,10 +970,8 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
         pa.rec_all = (uint2 *)c->rec_all.p;
         pa.rec_cov = (uint2 *)c->rec_cov.p;
         pa.cov_site = (uint32_t *)c->cov_site.p;
-        pa.chain_state = (unsigned long long *)c->scan_tmp.p;
-        pa.epoch = ++c->prep_epoch;
+        pa.block_tmp = (uint32_t *)c->scan_tmp.p;
         pa.info = (ibdg::PrepInfo *)c->info_dev.p;
-        pa.ctl = (ibdg::PrepCtl *)((char *)c->info_dev.p + sizeof(ibdg::PrepInfo));
         pa.mirror = c->info_h;
         pa.seq = ++c->prep_seq;
         pa.clear = c->pop_lut_ok ? c->segs.p : nullptr;

@@ -196,14 +196,6 @@ struct PrepInfo {
     uint32_t pad;
 };
 
-// device-side bookkeeping of the preparation kernels (zero at context creation; every launch leaves it zero)
-struct PrepCtl {
-    uint32_t ticket;         // next tile of a single-pass scan
-    uint32_t done_a;         // workgroups of k_prep_sites that have finished
-    uint32_t done_f;         // ... of k_prep_seg_flags
-    uint32_t pad;
-};
-
 // a number in the x87 extended format, normalised: value = m / 2^64 * 2^e, m in [2^63, 2^64)
 struct WinRaw {
     uint64_t m;
@@ -218,11 +210,9 @@ struct PrepSiteArgs {
     uint32_t max_cov;
     uint2 *rec_all, *rec_cov;
     uint32_t *cov_site;
-    unsigned long long *chain_state;   // prep_scan_blocks(n_sites) words of the single-pass scan (never cleared: epochs)
-    uint32_t epoch;             // of this launch, 1 .. 2^30-1, never reused while chain_state lives
+    uint32_t *block_tmp;        // prep_scan_blocks(n_sites) words
     PrepInfo *info;             // device
-    PrepCtl *ctl;               // device
-    PrepInfo *mirror;           // host-mapped copy the last workgroup fills in, then mirror->seq = seq
+    PrepInfo *mirror;           // host-mapped copy a one-wave kernel fills in at the end of the stage, then mirror->seq = seq
     uint32_t seq;
     void *clear;                // the segment array, cleared here for stage B (16-byte units)
     size_t clear_bytes;
@@ -236,18 +226,18 @@ struct PrepSegArgs {
     uint32_t seg_cap;           // segments beyond it are counted but not written (rows out of file order only)
     WinConst *wconst;           // [n_win + 1]
     WinRaw *raw;                // [n_win] K = prod C(cov, n_ref) per window
-    unsigned long long *chain_state;   // as in PrepSiteArgs
-    uint32_t epoch;
+    uint32_t *block_tmp;        // prep_scan_blocks(n_cov) words
     PrepInfo *info;
-    PrepCtl *ctl;
     PrepInfo *mirror;
 };
 
 size_t prep_scan_blocks(size_t n);
 // stage A: rec_all, rec_cov, cov_site, info->{n_cov, err_*, first_row, last_row}; the mirror gets them with seq
 void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st);
-// stage B: segment masks, per-window reads / alt reads / K, info->{n_segs, ct_max, out_of_order}
-void launch_prep_segments(const PrepSegArgs &a, hipStream_t st);
+// stage B: segment masks (on st), per-window reads / alt reads / K (on st2, which must be idle and see stage A's
+// results: the caller has waited for stage A), info->{n_segs, ct_max, out_of_order}.  The caller makes st wait for st2
+// before it queues anything that reads the per-window constants.
+void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2);
 // control words for a given run structure, info->{max_seg, adv_overflow}; the mirror gets all of stage B with seq
 void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, uint32_t seq,
                            hipStream_t st);

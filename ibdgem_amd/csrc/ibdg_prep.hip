@@ -4,18 +4,18 @@
 // zero-coverage rows (src/ibdgem.c:657-663), cutting windows of `window` covered rows
 // (:562-570, :723-730) and looking up the binomial coefficient of every row (src/ibd-math.c:55)
 // -- is done here once per ibdg_upload_sites for all rows at once:
-//   stage A  covered-row flags -> exclusive scan -> site records, covered-row list      (k_prep_sites)
-//   stage B  (window, 32-row tile) segment starts -> scan -> segment masks              (k_prep_segs)
-//            per-window constants (k_prep_win_const), control words of the exponent-counting
-//            --LD kernel (k_prep_seg_flags; ibdg_ld_popcount.hip), K' (k_prep_win_kp)
-// Both scans are single-pass: a workgroup takes the next tile of 1024 elements by ticket, counts its
-// flags, publishes the count, adds up its predecessors' published counts (a wave looks back 64 tiles at
-// a time until it meets one whose running total is known: "decoupled look-back"), publishes its own
-// running total and scatters -- one read of the input instead of the three launches and two reads of a
-// count / scan / scatter triple.  Tickets are handed out in start order, so every tile a workgroup
-// waits for belongs to a workgroup that is already running.  What the host needs between the stages
-// (PrepInfo: a few words) is written to a host-mapped mirror by whichever workgroup of a stage
-// finishes last; the host polls its sequence number instead of queueing a copy and waiting for the stream.
+//   stage A  covered-row flags -> exclusive scan -> site records, covered-row list
+//   stage B  (window, 32-row tile) segment starts -> scan -> segment masks, per-window constants,
+//            control words of the exponent-counting --LD kernel (ibdg_ld_popcount.hip)
+// Both scans are the plain three-kernel kind (per-block totals, one block scans the totals, the
+// blocks redo their flags and scatter): 6-12 bytes per row, a few microseconds per kernel.  (A
+// single-pass scan -- tiles chained by decoupled look-back -- was built and measured: 124 us where the three
+// kernels of stage A take 27.  The workgroups of a launch sit on eight XCDs, so the chain's words must
+// be read with agent-scope loads that go past the L2s, and any counter all workgroups share -- a ticket,
+// a "who is last" count -- costs ~12 ns per atomic on its one address: 3907 tiles make that 47 us.)
+// What the host needs between the stages (PrepInfo: a few words) is written to a host-mapped mirror by a
+// one-wave kernel at the end of each stage; the host polls the mirror's sequence number instead of
+// queueing a copy and draining the stream (a round trip of 10-15 us each).
 //
 // K = prod C(cov, n_ref) over a window is taken in the x87 extended format the host used to
 // take it in (64-bit mantissa, round to nearest even after every factor, in row order), done in
@@ -50,108 +50,66 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total)
     return x - v;
 }
 
-// ---- single-pass scan across workgroups -------------------------------------------------------
-// One 64-bit word per tile: status (2 bits: 1 = the tile's own count, 2 = the running total up to and
-// including the tile), the epoch of the launch (30 bits: words of earlier launches read as "nothing yet",
-// so the array is never cleared), the value (32 bits).  Agent-scope atomics: the workgroups of a launch
-// sit on eight XCDs with an L2 each.
-struct ScanChain {
-    unsigned long long *state;      // [tiles]
-    uint32_t *ticket;               // next tile to hand out (reset by the last tile)
-    uint32_t epoch;                 // 1 .. 2^30-1
-};
-
-__device__ __forceinline__ unsigned long long chain_word(uint32_t status, uint32_t epoch, uint32_t value)
+// ---- the block-level part both stages share ---------------------------------------------------
+// A block owns PREP_BLOCK consecutive elements; thread t looks at elements base + i*256 + t, so
+// every access is coalesced.  flag_of(e) says whether element e is kept.
+// count: number of kept elements of the block.
+template <class F>
+__device__ __forceinline__ uint32_t block_count(size_t base, size_t n, F flag_of)
 {
-    return ((unsigned long long)status << 62) | ((unsigned long long)epoch << 32) | value;
-}
-
-// The tile this workgroup works on (tickets in start order) -- all threads get the same answer.
-__device__ __forceinline__ uint32_t chain_take_tile(const ScanChain &ch)
-{
-    __shared__ uint32_t s_tile;
-    if (threadIdx.x == 0)
-        s_tile = atomicAdd(ch.ticket, 1u);
-    __syncthreads();
-    return s_tile;
-}
-
-// count = kept elements of this tile (the same in every thread).  Returns the number of kept elements in all
-// earlier tiles.  Block-wide call; wave 0 does the look-back.
-__device__ __forceinline__ uint32_t chain_exclusive(const ScanChain &ch, uint32_t tile, uint32_t count)
-{
-    __shared__ uint32_t s_excl;
-    const unsigned lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) {
-        if (lane == 0)
-            __hip_atomic_store(&ch.state[tile], chain_word(tile == 0 ? 2u : 1u, ch.epoch, count), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (tile > 0) {
-            long long base = (long long)tile - 1;        // lane l looks at tile base - l
-            for (;;) {
-                const long long idx = base - (long long)lane;
-                unsigned long long st = chain_word(2u, ch.epoch, 0u);        // before the first tile: total 0
-                if (idx >= 0)
-                    st = __hip_atomic_load(&ch.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t status = (uint32_t)(st >> 62), ep = (uint32_t)(st >> 32) & 0x3fffffffu;
-                const bool ready = status != 0 && ep == ch.epoch;
-                if (__ballot(ready) != ~0ull) {
-                    __builtin_amdgcn_s_sleep(1);                              // a predecessor has not published yet
-                    continue;
-                }
-                const uint64_t totals = __ballot(status == 2u);
-                const unsigned first = totals ? (unsigned)__builtin_ctzll(totals) : 63u;
-                uint32_t v = lane <= first ? (uint32_t)st : 0u;
+    __shared__ uint32_t wave_cnt[PREP_THREADS / 64];
+    uint32_t cnt = 0;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
-                    v += __shfl_xor(v, off);
-                excl += v;
-                if (totals)
-                    break;
-                base -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&ch.state[tile], chain_word(2u, ch.epoch, excl + count), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const bool f = e < n && flag_of(e);
+        cnt += (uint32_t)__popcll(__ballot(f));           // the same number in every lane of the wave
+    }
+    if ((threadIdx.x & 63) == 0)
+        wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < PREP_THREADS / 64; ++w)
+        tot += wave_cnt[w];
+    return tot;
+}
+
+// scatter: calls emit(e, k) for every kept element e of the block, k = its rank among all kept
+// elements (block_off = kept elements before this block), and other(e) for every element.
+template <class F, class E>
+__device__ __forceinline__ void block_scatter(size_t base, size_t n, uint32_t block_off, F flag_of, E emit)
+{
+    constexpr int NW = PREP_THREADS / 64;
+    __shared__ uint32_t pre[PREP_ITEMS * NW];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ballots[PREP_ITEMS];
+#pragma unroll
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        const bool f = e < n && flag_of(e);
+        ballots[i] = __ballot(f);
         if (lane == 0)
-            s_excl = excl;
+            pre[i * NW + wave] = (uint32_t)__popcll(ballots[i]);
     }
     __syncthreads();
-    return s_excl;
-}
-
-// Called by every workgroup of a launch when its work is done: true (in all threads) for the one that is last.
-// Its reads see everything the others wrote before they called.
-__device__ __forceinline__ bool chain_last_done(uint32_t *done, uint32_t n_blocks)
-{
-    __shared__ uint32_t s_last;
+    if (wave == 0) {                                   // at most 64 entries: one wave scans them
+        static_assert(PREP_ITEMS * NW <= 64, "one wave scans the per-(row, wave) totals");
+        uint32_t tot;
+        const uint32_t v = lane < PREP_ITEMS * NW ? pre[lane] : 0u;
+        const uint32_t x = wave_excl_scan(v, &tot);
+        if (lane < PREP_ITEMS * NW)
+            pre[lane] = x;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const uint32_t k = atomicAdd(done, 1u);
-        s_last = k + 1 == n_blocks;
-        if (s_last) {
-            *done = 0;                 // for the next launch
-            __threadfence();
+#pragma unroll
+    for (int i = 0; i < PREP_ITEMS; ++i) {
+        const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
+        if (e < n && ((ballots[i] >> lane) & 1)) {
+            const uint32_t below = (uint32_t)__popcll(ballots[i] & ((1ull << lane) - 1));
+            emit(e, block_off + pre[i * NW + wave] + below);
         }
     }
-    __syncthreads();
-    return s_last != 0;
-}
-
-// The host's copy of PrepInfo: all words, then the sequence number (host-mapped, fine-grained memory).
-__device__ __forceinline__ void mirror_info(const PrepInfo *info, PrepInfo *mirror, uint32_t seq)
-{
-    const volatile uint32_t *src = reinterpret_cast<const volatile uint32_t *>(info);
-    volatile uint32_t *dst = reinterpret_cast<volatile uint32_t *>(mirror);
-    constexpr int N = (int)(offsetof(PrepInfo, seq) / 4);
-    for (int i = 0; i < N; ++i)
-        dst[i] = __hip_atomic_load(const_cast<const uint32_t *>(&src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    mirror->seq = seq;
-    __threadfence_system();
 }
 
 // ---- stage A: rows -> records ----------------------------------------------------------------
@@ -163,110 +121,127 @@ struct SiteIn {
     uint32_t max_cov;
 };
 
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_site_count(SiteIn in, uint32_t *__restrict__ block_cnt,
+                                                                  PrepInfo *__restrict__ info)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    const uint32_t tot = block_count(base, in.n_sites, [&](size_t s) {
+        const unsigned r = in.n_ref[s], a = in.n_alt[s];
+        if (r + a > in.max_cov)
+            atomicMin(&info->err_cov_site, (uint32_t)s);
+        if (in.row_index && in.row_index[s] >= in.n_rows)
+            atomicMin(&info->err_row_site, (uint32_t)s);
+        return r + a >= 1;
+    });
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = tot;
+}
+
+// One block: exclusive scan of cnt[0..n) in place, the grand total to *total.
+__global__ __launch_bounds__(1024) void k_prep_scan(uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ total,
+                                                   WinConst *__restrict__ behind_last)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? cnt[i] : 0;
+        uint32_t wt;
+        const uint32_t x = wave_excl_scan(v, &wt);
+        if (lane == 0)
+            wave_tot[wave] = wt;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (unsigned w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        if (i < n)
+            cnt[i] = off + x;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry_s = off + x + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *total = carry_s;
+        if (behind_last) {             // the entry behind the last window carries seg_begin = n_segs
+            behind_last->mK = 0.0;
+            behind_last->eK = 0;
+            behind_last->cov_total = behind_last->alt_total = 0;
+            behind_last->seg_begin = carry_s;
+        }
+    }
+}
+
+// The host's copy of PrepInfo: all words, then the sequence number (host-mapped, fine-grained memory).  One wave,
+// queued behind the last kernel of a stage; stage 0 (after the site records): what the host has now is cleared for
+// the next upload, and so is what stage B accumulates into; stage 1 (after the control words): what a rerun with
+// another run structure accumulates again.
+__global__ __launch_bounds__(64) void k_prep_mirror(PrepInfo *__restrict__ info, PrepInfo *__restrict__ mirror, uint32_t seq,
+                                                    int stage)
+{
+    if (threadIdx.x != 0)
+        return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(info);
+    volatile uint32_t *dst = reinterpret_cast<volatile uint32_t *>(mirror);
+    constexpr int N = (int)(offsetof(PrepInfo, seq) / 4);
+    for (int i = 0; i < N; ++i)
+        dst[i] = src[i];
+    __threadfence_system();
+    mirror->seq = seq;
+    __threadfence_system();
+    if (stage == 0) {
+        info->err_row_site = info->err_cov_site = 0xffffffffu;
+        info->first_row = 0xffffffffu;
+        info->last_row = 0;
+        info->out_of_order = info->n_segs = info->ct_max = info->max_seg = info->adv_overflow = 0;
+    } else {
+        info->max_seg = info->adv_overflow = 0;
+    }
+}
+
 struct SiteOut {
     uint2 *rec_all;         // [n_sites] {row, lut byte offset}
     uint2 *rec_cov;         // [n_cov] the same for covered rows
     uint32_t *cov_site;     // [n_cov] site index of every covered row
 };
 
-// A tile = PREP_BLOCK consecutive sites; thread t looks at sites base + i*256 + t, so every access is coalesced.
-// Besides its tile's records the workgroup clears its share of the segment array (the masks of stage B are
-// built with atomicOr) and takes part in the validation: the smallest offending site of either kind.
-__global__ __launch_bounds__(PREP_THREADS) void k_prep_sites(SiteIn in, SiteOut out, ScanChain ch, uint32_t n_tiles,
-                                                            PrepInfo *__restrict__ info, PrepCtl *__restrict__ ctl,
-                                                            PrepInfo *__restrict__ mirror, uint32_t seq,
-                                                            uint4 *__restrict__ clear, size_t clear_units)
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, const uint32_t *__restrict__ block_off,
+                                                                    SiteOut out, PrepInfo *__restrict__ info,
+                                                                    uint4 *__restrict__ clear, size_t clear_units)
 {
-    constexpr int NW = PREP_THREADS / 64;
-    __shared__ uint32_t pre[PREP_ITEMS * NW];
-    const uint32_t tile = chain_take_tile(ch);
-    const size_t base = (size_t)tile * PREP_BLOCK;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
     const uint32_t d = in.max_cov + 1;
-    uint64_t ballots[PREP_ITEMS];
-    uint2 rec[PREP_ITEMS];
-    uint32_t err_row = 0xffffffffu, err_cov = 0xffffffffu, row_min = 0xffffffffu, row_max = 0;
-#pragma unroll
-    for (int i = 0; i < PREP_ITEMS; ++i) {
-        const size_t s = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        bool f = false;
-        rec[i] = make_uint2(0, 0);
-        if (s < in.n_sites) {
-            const unsigned r = in.n_ref[s], a = in.n_alt[s];
-            rec[i].x = in.row_index ? in.row_index[s] : (uint32_t)s;
-            rec[i].y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
-            if (r + a > in.max_cov)
-                err_cov = err_cov < (uint32_t)s ? err_cov : (uint32_t)s;
-            if (in.row_index && rec[i].x >= in.n_rows)
-                err_row = err_row < (uint32_t)s ? err_row : (uint32_t)s;
-            out.rec_all[s] = rec[i];           // every row gets its record (an out-of-range pair is reported and never used)
-            f = r + a >= 1;
-            if (f) {
-                row_min = row_min < rec[i].x ? row_min : rec[i].x;
-                row_max = row_max > rec[i].x ? row_max : rec[i].x;
-            }
-        }
-        ballots[i] = __ballot(f);
-        if (lane == 0)
-            pre[i * NW + wave] = (uint32_t)__popcll(ballots[i]);
-    }
-    __syncthreads();
-    uint32_t count = 0;
-    if (wave == 0) {                                   // at most 64 entries: one wave scans them
-        static_assert(PREP_ITEMS * NW <= 64, "one wave scans the per-(row, wave) totals");
-        const uint32_t v = lane < PREP_ITEMS * NW ? pre[lane] : 0u;
-        const uint32_t x = wave_excl_scan(v, &count);
-        if (lane < PREP_ITEMS * NW)
-            pre[lane] = x;
-    }
-    __shared__ uint32_t s_count;
-    if (threadIdx.x == 0)
-        s_count = count;
-    __syncthreads();
-    count = s_count;
-    const uint32_t block_off = chain_exclusive(ch, tile, count);
-#pragma unroll
-    for (int i = 0; i < PREP_ITEMS; ++i) {
-        const size_t s = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        if (s < in.n_sites && ((ballots[i] >> lane) & 1)) {
-            const uint32_t j = block_off + pre[i * NW + wave] + (uint32_t)__popcll(ballots[i] & ((1ull << lane) - 1));
-            out.rec_cov[j] = rec[i];
-            out.cov_site[j] = (uint32_t)s;
-        }
-    }
-    // the wave's extremes, one atomic each per wave that has something to say
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t a = __shfl_xor(err_row, off), b = __shfl_xor(err_cov, off), m = __shfl_xor(row_min, off),
-                       x = __shfl_xor(row_max, off);
-        err_row = err_row < a ? err_row : a;
-        err_cov = err_cov < b ? err_cov : b;
-        row_min = row_min < m ? row_min : m;
-        row_max = row_max > x ? row_max : x;
-    }
-    if (lane == 0) {
-        if (err_row != 0xffffffffu) atomicMin(&info->err_row_site, err_row);
-        if (err_cov != 0xffffffffu) atomicMin(&info->err_cov_site, err_cov);
-        if (row_min != 0xffffffffu) {
-            atomicMin(&info->first_row, row_min);
-            atomicMax(&info->last_row, row_max);
-        }
-    }
-    if (tile + 1 == n_tiles && threadIdx.x == 0) {
-        info->n_cov = block_off + count;
-        *ch.ticket = 0;                                // every ticket of this launch has been taken
-    }
-    // this workgroup's share of the segment array
-    for (size_t u = (size_t)tile * PREP_THREADS + threadIdx.x; u < clear_units; u += (size_t)n_tiles * PREP_THREADS)
+    // this workgroup's share of the segment array (stage B builds the masks with atomicOr)
+    for (size_t u = (size_t)blockIdx.x * PREP_THREADS + threadIdx.x; u < clear_units; u += (size_t)gridDim.x * PREP_THREADS)
         clear[u] = make_uint4(0, 0, 0, 0);
-    if (chain_last_done(&ctl->done_a, n_tiles) && threadIdx.x == 0) {
-        mirror_info(info, mirror, seq);
-        // what the host has now is cleared for the next upload; so is what stage B accumulates into
-        info->err_row_site = info->err_cov_site = 0xffffffffu;
-        info->first_row = 0xffffffffu;
-        info->last_row = 0;
-        info->out_of_order = info->n_segs = info->ct_max = info->max_seg = info->adv_overflow = 0;
-    }
+    block_scatter(
+        base, in.n_sites, block_off[blockIdx.x],
+        [&](size_t s) {
+            const unsigned r = in.n_ref[s], a = in.n_alt[s];
+            // every row gets its record (an out-of-range pair is reported by the host and never used)
+            uint2 rc;
+            rc.x = in.row_index ? in.row_index[s] : (uint32_t)s;
+            rc.y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
+            out.rec_all[s] = rc;
+            // the panel rows the sites span (in file order: what the covered rows span at most)
+            if (s == 0)
+                info->first_row = rc.x;
+            if (s + 1 == in.n_sites)
+                info->last_row = rc.x;
+            return r + a >= 1;
+        },
+        [&](size_t s, uint32_t j) {
+            const unsigned r = in.n_ref[s], a = in.n_alt[s];
+            uint2 rc;
+            rc.x = in.row_index ? in.row_index[s] : (uint32_t)s;
+            rc.y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
+            out.rec_cov[j] = rc;
+            out.cov_site[j] = (uint32_t)s;
+        });
 }
 
 // ---- stage B: covered rows -> segments --------------------------------------------------------
@@ -286,6 +261,19 @@ __device__ __forceinline__ bool seg_start(const SegIn &in, size_t j)
     return (in.rec_cov[j].x >> 5) != (in.rec_cov[j - 1].x >> 5);
 }
 
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint32_t *__restrict__ block_cnt,
+                                                                 PrepInfo *__restrict__ info)
+{
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
+    const uint32_t tot = block_count(base, in.n_cov, [&](size_t j) {
+        if (j > 0 && in.rec_cov[j].x <= in.rec_cov[j - 1].x)
+            info->out_of_order = 1;                    // not in file order: only the strict kernel applies
+        return seg_start(in, j);
+    });
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = tot;
+}
+
 // Segment masks, row-parallel: every covered row is a lane.  The lanes of a wave (64 consecutive covered
 // rows) OR their bits into a wave-private LDS table of [piece][weight plane] words -- a piece = the rows of
 // one segment that fall into this wave's 64, so at most 64 pieces -- with ds_or (LDS atomics; a segment's
@@ -293,31 +281,23 @@ __device__ __forceinline__ bool seg_start(const SegIn &in, size_t j)
 // adds the piece's non-zero words to the segment in memory with atomicOr: a segment cut by a wave boundary
 // is simply two pieces.  segs[] is zeroed beforehand.  The first row of a segment writes tile and window,
 // its last row the end-of-window mark.
-__global__ __launch_bounds__(PREP_THREADS) void k_prep_segs(SegIn in, ScanChain ch, uint32_t n_tiles,
-                                                            Seg *__restrict__ segs, uint32_t seg_cap,
-                                                            WinConst *__restrict__ wconst, uint32_t n_win,
-                                                            PrepInfo *__restrict__ info)
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const uint32_t *__restrict__ block_off,
+                                                                 Seg *__restrict__ segs, uint32_t seg_cap,
+                                                                 WinConst *__restrict__ wconst)
 {
     constexpr int NW = PREP_THREADS / 64;
     __shared__ uint32_t pre[PREP_ITEMS * NW];
-    __shared__ uint32_t s_count;
     __shared__ __attribute__((aligned(16))) uint32_t tbl[NW][64][16];
-    const uint32_t tile = chain_take_tile(ch);
-    const size_t base = (size_t)tile * PREP_BLOCK;
+    const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pass 1: segment starts per (item, wave) -> exclusive prefix; the tile's total goes down the chain
-    bool disorder = false;
+    // pass 1: segment starts per (item, wave) -> exclusive prefix (the same ranks k_prep_seg_count counted)
 #pragma unroll 4
     for (int i = 0; i < PREP_ITEMS; ++i) {
         const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        if (j > 0 && j < in.n_cov && in.rec_cov[j].x <= in.rec_cov[j - 1].x)
-            disorder = true;                           // not in file order: only the strict kernel applies
         const uint64_t b = __ballot(j < in.n_cov && seg_start(in, j));
         if (lane == 0)
             pre[i * NW + wave] = (uint32_t)__popcll(b);
     }
-    if (__any(disorder) && lane == 0)
-        info->out_of_order = 1;
     __syncthreads();
     if (wave == 0) {
         uint32_t tot;
@@ -325,20 +305,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_segs(SegIn in, ScanChain 
         const uint32_t x = wave_excl_scan(v, &tot);
         if (lane < PREP_ITEMS * NW)
             pre[lane] = x;
-        if (lane == 0)
-            s_count = tot;
     }
     __syncthreads();
-    const uint32_t count = s_count;
-    const uint32_t boff = chain_exclusive(ch, tile, count);
-    if (tile + 1 == n_tiles && threadIdx.x == 0) {
-        info->n_segs = boff + count;
-        wconst[n_win].mK = 0.0;                        // the entry behind the last window carries seg_begin = n_segs
-        wconst[n_win].eK = 0;
-        wconst[n_win].cov_total = wconst[n_win].alt_total = 0;
-        wconst[n_win].seg_begin = boff + count;
-        *ch.ticket = 0;
-    }
+    const uint32_t boff = block_off[blockIdx.x];
     uint4 *my_row = reinterpret_cast<uint4 *>(&tbl[wave][lane][0]);
 #pragma unroll 1
     for (int i = 0; i < PREP_ITEMS; ++i) {
@@ -435,14 +404,16 @@ __device__ __forceinline__ X87 x87_mul(X87 a, uint64_t bm, int32_t be)
     return r;
 }
 
-// One thread per window: reads, alt reads and K = prod C(cov, n_ref) of its rows in row order
+// One thread per window: reads, alt reads and K = prod C(cov, n_ref) of its rows in row order -- a chain of roundings,
+// 43 us of latency for 35 000 windows whatever fetches the rows (a workgroup staging them through LDS: 68 us), so it
+// runs on the second stream beside the segment kernels, which need none of it
 // (src/ibd-math.c:55 factors of every P(D|G) of the window).
 __global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win, const unsigned long long *__restrict__ nck,
                                                       WinConst *__restrict__ wconst, WinRaw *__restrict__ raw,
                                                       PrepInfo *__restrict__ info)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_win)
+    if (w >= n_win)                    // (the entry behind the last window, seg_begin = n_segs, is the scan's)
         return;
     const uint64_t b = (uint64_t)w * in.window;
     const uint64_t e64 = b + in.window;
@@ -503,10 +474,11 @@ __global__ __launch_bounds__(256) void k_prep_win_kp(uint32_t n_win, const WinRa
 
 // One thread per segment: the control word of the --LD kernel (ibdg::Seg::flags), which depends on
 // the run structure; one thread per run: the largest number of segments in a run.
-__device__ __forceinline__ void seg_flags_one(uint32_t i, Seg *__restrict__ segs, const WinConst *__restrict__ wconst,
-                                              const uint32_t *__restrict__ run_begin, uint32_t n_runs, uint32_t ring,
-                                              uint32_t seg_cap, PrepInfo *__restrict__ info)
+__global__ __launch_bounds__(256) void k_prep_seg_flags(Seg *__restrict__ segs, const WinConst *__restrict__ wconst,
+                                                        const uint32_t *__restrict__ run_begin, uint32_t n_runs,
+                                                        uint32_t ring, uint32_t seg_cap, PrepInfo *__restrict__ info)
 {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_segs = info->n_segs;
     if (i < n_runs)
         atomicMax(&info->max_seg, wconst[run_begin[i + 1]].seg_begin - wconst[run_begin[i]].seg_begin);
@@ -545,20 +517,6 @@ __device__ __forceinline__ void seg_flags_one(uint32_t i, Seg *__restrict__ segs
                (nc << 16) | (na << 24);
 }
 
-// The last kernel of stage B: whichever workgroup finishes last hands PrepInfo to the host's mirror and clears what a
-// rerun with another run structure accumulates again.
-__global__ __launch_bounds__(256) void k_prep_seg_flags(Seg *__restrict__ segs, const WinConst *__restrict__ wconst,
-                                                        const uint32_t *__restrict__ run_begin, uint32_t n_runs,
-                                                        uint32_t ring, uint32_t seg_cap, PrepInfo *__restrict__ info,
-                                                        PrepCtl *__restrict__ ctl, PrepInfo *__restrict__ mirror, uint32_t seq)
-{
-    seg_flags_one(blockIdx.x * blockDim.x + threadIdx.x, segs, wconst, run_begin, n_runs, ring, seg_cap, info);
-    if (chain_last_done(&ctl->done_f, gridDim.x) && threadIdx.x == 0) {
-        mirror_info(info, mirror, seq);
-        info->max_seg = info->adv_overflow = 0;
-    }
-}
-
 // first / last site of every window (ibdg_get_windows)
 __global__ __launch_bounds__(256) void k_prep_win_bounds(const uint32_t *__restrict__ cov_site, uint32_t n_cov,
                                                          uint32_t window, uint32_t n_win, uint32_t *__restrict__ first,
@@ -594,16 +552,15 @@ void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st)
     out.rec_all = a.rec_all;
     out.rec_cov = a.rec_cov;
     out.cov_site = a.cov_site;
-    ScanChain ch;
-    ch.state = a.chain_state;
-    ch.ticket = &a.ctl->ticket;
-    ch.epoch = a.epoch;
     const unsigned nb = blocks_for(a.n_sites);
-    hipLaunchKernelGGL(k_prep_sites, dim3(nb), dim3(PREP_THREADS), 0, st, in, out, ch, nb, a.info, a.ctl, a.mirror, a.seq,
+    hipLaunchKernelGGL(k_prep_site_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_cov, (WinConst *)nullptr);
+    hipLaunchKernelGGL(k_prep_site_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, out, a.info,
                        reinterpret_cast<uint4 *>(a.clear), a.clear_bytes / 16);
+    hipLaunchKernelGGL(k_prep_mirror, dim3(1), dim3(64), 0, st, a.info, a.mirror, a.seq, 0);
 }
 
-void launch_prep_segments(const PrepSegArgs &a, hipStream_t st)
+void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2)
 {
     if (a.n_cov == 0)
         return;
@@ -612,25 +569,24 @@ void launch_prep_segments(const PrepSegArgs &a, hipStream_t st)
     in.n_cov = a.n_cov;
     in.window = a.window;
     in.d = a.max_cov + 1;
-    ScanChain ch;
-    ch.state = a.chain_state;
-    ch.ticket = &a.ctl->ticket;
-    ch.epoch = a.epoch;
     const unsigned nb = blocks_for(a.n_cov);
-    hipLaunchKernelGGL(k_prep_segs, dim3(nb), dim3(PREP_THREADS), 0, st, in, ch, nb, a.segs, a.seg_cap, a.wconst, a.n_win,
+    // the per-window constants on the second stream, beside the three segment kernels
+    hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 63) / 64), dim3(64), 0, st2, in, a.n_win, a.nck, a.wconst, a.raw,
                        a.info);
-    hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 63) / 64), dim3(64), 0, st, in, a.n_win, a.nck, a.wconst, a.raw,
-                       a.info);
+    hipLaunchKernelGGL(k_prep_seg_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs, a.wconst + a.n_win);
+    hipLaunchKernelGGL(k_prep_seg_build, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.segs, a.seg_cap,
+                       a.wconst);
 }
 
 void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, uint32_t seq,
                            hipStream_t st)
 {
-    uint32_t n = a.seg_cap > n_runs ? a.seg_cap : n_runs;
-    if (n == 0)
-        n = 1;                                         // the mirror is written by this kernel's last workgroup
-    hipLaunchKernelGGL(k_prep_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, a.segs, a.wconst, run_begin, n_runs,
-                       ring, a.seg_cap, a.info, a.ctl, a.mirror, seq);
+    const uint32_t n = a.seg_cap > n_runs ? a.seg_cap : n_runs;
+    if (n)
+        hipLaunchKernelGGL(k_prep_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, a.segs, a.wconst, run_begin, n_runs,
+                           ring, a.seg_cap, a.info);
+    hipLaunchKernelGGL(k_prep_mirror, dim3(1), dim3(64), 0, st, a.info, a.mirror, seq, 1);
 }
 
 void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st)

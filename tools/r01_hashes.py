@@ -44,6 +44,12 @@ def digests(lib_path=None):
         alle, n_ref, n_alt = make_case(rows, n_ids, depth, max_cov, seed)
         with ibdgem_amd.Engine(0, eps, max_cov, lib_path=lib_path) as eng:
             eng.set_option("ld_variant", 2)
+            try:
+                # the exponent-counting kernels are what round 1 had and what these digests pin; five or more comparison
+                # individuals would otherwise take the matrix-core kernel, whose factored products round differently
+                eng.set_option("mfma_targets", 0)
+            except ibdgem_amd.EngineError:
+                pass                              # (the round-1 library has no such option)
             eng.upload_panel(pack_alleles_fast(alle), n_ids)
             eng.upload_sites(np.arange(rows, dtype=np.uint32), n_ref, n_alt, window)
             eng.run(targets, ld=True)
