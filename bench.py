@@ -279,8 +279,12 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
                 eng.upload_sites(idx, n_ref, n_alt, window)
             eng.run(targets, ld=True)
             eng.window_ll(0, out=win_pin.array)
+        # (option "async": ibdg_run returns once its kernels are queued and ibdg_get_window_ll is what waits -- one host
+        # wait for the comparison instead of two)
+        eng.set_option("async", 1)
         once()
         ms = best_of(5, once)
+        eng.set_option("async", 0)
         eng.set_option("count_in_run", 0)
         return ms
     full = clock(True, True)
