@@ -644,6 +644,12 @@ def main():
     eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
     first_upload_ms = (time.perf_counter() - t_up) * 1e3
     n_cov = int(((n_ref.astype(np.int32) + n_alt) > 0).sum())
+    # (window, 32-row tile) segments of this rank's rows: the unit of work of the --LD kernels' inner loop
+    cov_rows = np.flatnonzero((n_ref.astype(np.int32) + n_alt) > 0)
+    seg_start = (np.arange(len(cov_rows)) % args.window == 0)
+    seg_start[1:] |= (cov_rows[1:] >> 5) != (cov_rows[:-1] >> 5)
+    n_segments = int(seg_start.sum())
+    del cov_rows, seg_start
     targets = [args.target]
 
     def barrier():
@@ -861,6 +867,7 @@ def main():
             "config": {"workload": f"--LD, {L} SNP rows (synthetic chr1), {args.ids}-individual phased panel, "
                                    f"window {args.window}, 1 comparison individual (BASELINE.json configs[3])",
                        "rows": int(rows_total), "windowed_sites": int(cov_total), "n_ids": args.ids,
+                       "windows_rank0": int(eng.n_windows), "segments_rank0": n_segments,
                        "window": args.window, "targets": len(targets), "epsilon": 0.02, "max_cov": 20,
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",

@@ -1,7 +1,7 @@
 """profiles/<round>_ld_pmc.json from the per-kernel counter averages tools/pmc_ld.sh leaves in
 gpurun_out/<tag>_pmc.json (the file bench.py reads for `roofline.valu`):
 
-    python tools/pmc_ld_summary.py gpurun_out/r02pmc_pmc.json profiles/r02_ld_pmc.json
+    python tools/pmc_ld_summary.py gpurun_out/r03pmc_pmc.json profiles/r03_ld_pmc.json <windows> <segments>
 
 Derived quantities: instructions per (window, chunk of 64 individuals), the split of wave time, the VALU
 issue cycles per SIMD against the kernel's own cycle count.  Cycles per VALU instruction: the (mask, count)
@@ -13,7 +13,8 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-n_win, n_chunks, n_segs = 34579, 40, int(sys.argv[3]) if len(sys.argv) > 3 else 158392
+# windows and segments of the workload: `config.windows_rank0` / `config.segments_rank0` of the bench line
+n_win, n_chunks, n_segs = int(sys.argv[3]), 40, int(sys.argv[4])
 raw = json.load(open(src))
 name = [k for k in raw if "k_ld_popcount<" in k][0]
 k = raw[name]
