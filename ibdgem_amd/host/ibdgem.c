@@ -1030,43 +1030,51 @@ static void *fmt_rows(void *arg)
     return NULL;
 }
 
+/* Rounds of 2^18 rows (bounds the text held in memory); the team formats round k+1 into a second set of buffers
+ * while this thread writes round k -- a third of the phase was the copy into the page cache with the team idle. */
 static int write_rows_parallel(FILE *tab, fmt_job proto, size_t n, int threads)
 {
-    const size_t batch = (size_t)1 << 18;              /* rows per round: bounds the text held in memory */
-    fmt_job jobs[64];
+    const size_t batch = (size_t)1 << 18;
+    static fmt_job jobs[2][64];
     pthread_t tid[64];
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
-    for (int t = 0; t < threads; ++t) {
-        jobs[t] = proto;
-        jobs[t].buf = NULL;
-        jobs[t].cap = 0;
-    }
-    int rc = 0;
-    for (size_t r0 = 0; r0 < n && !rc; r0 += batch) {
-        const size_t r1 = r0 + batch < n ? r0 + batch : n, m = r1 - r0;
-        const int team = m < 4096 ? 1 : threads;
-        int started[64] = {0};
-        for (int t = 0; t < team; ++t) {
-            jobs[t].a = r0 + m * (size_t)t / (size_t)team;
-            jobs[t].b = r0 + m * (size_t)(t + 1) / (size_t)team;
-            jobs[t].len = 0;
+    for (int k = 0; k < 2; ++k)
+        for (int t = 0; t < threads; ++t) {
+            jobs[k][t] = proto;
+            jobs[k][t].buf = NULL;
+            jobs[k][t].cap = 0;
         }
-        for (int t = 0; t + 1 < team; ++t)
-            started[t] = pthread_create(&tid[t], NULL, fmt_rows, &jobs[t]) == 0;
-        for (int t = 0; t < team; ++t)
-            if (!started[t])
-                fmt_rows(&jobs[t]);
-        for (int t = 0; t + 1 < team; ++t)
-            if (started[t])
-                pthread_join(tid[t], NULL);
-        for (int t = 0; t < team; ++t) {
-            if (jobs[t].failed || fwrite(jobs[t].buf, 1, jobs[t].len, tab) != jobs[t].len)
+    int rc = 0, prev_team = 0, cur = 0;
+    for (size_t r0 = 0; (r0 < n || prev_team) && !rc; r0 += batch, cur ^= 1) {
+        int team = 0, started[64] = {0};
+        if (r0 < n) {
+            const size_t r1 = r0 + batch < n ? r0 + batch : n, m = r1 - r0;
+            team = m < 4096 ? 1 : threads;
+            for (int t = 0; t < team; ++t) {
+                jobs[cur][t].a = r0 + m * (size_t)t / (size_t)team;
+                jobs[cur][t].b = r0 + m * (size_t)(t + 1) / (size_t)team;
+                jobs[cur][t].len = 0;
+                started[t] = team > 1 && pthread_create(&tid[t], NULL, fmt_rows, &jobs[cur][t]) == 0;
+            }
+        }
+        /* the previous round's text goes out while the team works */
+        for (int t = 0; t < prev_team; ++t) {
+            fmt_job *j = &jobs[cur ^ 1][t];
+            if (j->failed || fwrite(j->buf, 1, j->len, tab) != j->len)
                 rc = 1;
         }
+        for (int t = 0; t < team; ++t) {
+            if (started[t])
+                pthread_join(tid[t], NULL);
+            else
+                fmt_rows(&jobs[cur][t]);
+        }
+        prev_team = team;
     }
-    for (int t = 0; t < threads; ++t)
-        free(jobs[t].buf);
+    for (int k = 0; k < 2; ++k)
+        for (int t = 0; t < threads; ++t)
+            free(jobs[k][t].buf);
     return rc;
 }
 
