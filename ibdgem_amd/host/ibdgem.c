@@ -1222,6 +1222,28 @@ static void phase(const char *name)
         const char *e = getenv("IBDGEM_TIMING");
         timing_on = e && *e && *e != '0';
         timing_last = now_s();
+        if (timing_on) {
+            /* what the loader and the libraries' initialisers took before main: now (since boot) minus the start
+             * time of the process (field 22 of /proc/self/stat, in clock ticks since boot) */
+            FILE *f = fopen("/proc/self/stat", "r");
+            char buf[1024];
+            if (f && fgets(buf, sizeof buf, f)) {
+                const char *p = strrchr(buf, ')');
+                unsigned long long ticks = 0;
+                int field = 2;
+                for (p = p ? p + 1 : buf; *p && field < 22; ++p)
+                    if (*p == ' ')
+                        ++field;
+                if (sscanf(p, "%llu", &ticks) == 1) {
+                    struct timespec ts;
+                    clock_gettime(CLOCK_BOOTTIME, &ts);
+                    const double since = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec - (double)ticks / (double)sysconf(_SC_CLK_TCK);
+                    fprintf(stderr, "## time process start to main %.4f\n", since > 0 ? since : 0.0);
+                }
+            }
+            if (f)
+                fclose(f);
+        }
         return;
     }
     if (!timing_on)
