@@ -21,4 +21,7 @@ bash tools/pmc_any.sh ${tag}mfma "tools/multi_target.py 4000000 15" "LdsUtil Mfm
 # 4. the site preparation, per kernel
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prep_stats -- "$PY" tools/prep_times.py > gpurun_out/${tag}_prep_times.txt 2>&1 &&
 cp gpurun_out/${tag}_prep_stats/*/*kernel_stats.csv gpurun_out/${tag}_prep_kernel_stats.csv
-echo "profiles rc=$?"
+rc=$?
+# only the summaries travel back (the raw traces are tens of megabytes per pass)
+find gpurun_out -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+echo "profiles rc=$rc"
