@@ -1763,7 +1763,10 @@ int main(int argc, char **argv)
     /* ---- per comparison individual (:522-773) ------------------------------------------ */
     /* the arrays that cross the engine's boundary live in page-locked memory when a device is in use
      * (ibdg_host_alloc: copies at link speed, 45+ GB/s instead of ~17 through a staging buffer) */
-    const int pin = !no_engine;
+    /* Round 2 page-locked these arrays (ibdg_host_alloc).  Measured since: locking 128 MB costs 0.1 s, giving it
+     * back at exit 0.2 s, and the copies it was meant to speed up (24 MB in, 96 MB out per comparison) run at the same
+     * 56 GB/s from ordinary memory (bench.py results_to_host) -- so they are ordinary memory now. */
+    const int pin = 0;
     uint32_t *s_row = io_alloc((n_cand ? n_cand : 1) * 4, pin), *s_cand = malloc((n_cand ? n_cand : 1) * 4);
     uint8_t *s_nr = io_alloc(n_cand ? n_cand : 1, pin), *s_na = io_alloc(n_cand ? n_cand : 1, pin);
     double *s_fo = has_A ? malloc((n_cand ? n_cand : 1) * 8) : NULL;
@@ -1772,7 +1775,7 @@ int main(int argc, char **argv)
     double *site_ll = io_alloc(n_site_out * 24, pin);
     if (!s_row || !s_cand || !s_nr || !s_na || !site_ll)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
-    phase("page-locked result arrays");
+    phase("result arrays");
     uint32_t *s_row_dev = NULL;     /* slice_mode: the site list's rows counted from each device's first row */
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
@@ -1854,7 +1857,7 @@ int main(int argc, char **argv)
             if (slice_mode && ti == 0) {
                 /* every device gets the panel rows from its first site's row to its last site's row, and its
                  * sites are numbered within that slice */
-                s_row_dev = io_alloc((n ? n : 1) * 4, 1);
+                s_row_dev = io_alloc((n ? n : 1) * 4, pin);
                 if (!s_row_dev)
                     DIE("[::] ERROR: out of memory for %zu rows.\n", n);
                 for (int d = 0; d < n_eng; ++d) {
