@@ -46,19 +46,25 @@ def synth_host(seed, L, N):
     rng = np.random.default_rng(seed)
     f = np.clip(rng.beta(0.3, 1.0, size=L), 1e-3, 0.999)
     alle = np.empty((L, 2 * N), dtype=np.uint8)
-    for a in range(0, L, 20000):
-        b = min(L, a + 20000)
+    step = max(1000, 40_000_000 // (2 * N))            # ~320 MB of random doubles per turn
+    for a in range(0, L, step):
+        b = min(L, a + step)
         alle[a:b] = rng.random((b - a, 2 * N)) < f[a:b, None]
     cov = np.minimum(rng.poisson(2.0, size=L), 20)
     n_alt = rng.binomial(cov, f)
     return alle, (cov - n_alt).astype(np.uint8), n_alt.astype(np.uint8)
 
 
-def test_config1_nonld_100k_rows(oracle):
-    L, N = 100_000, 64
+@pytest.mark.parametrize("N", [64, 2504])
+def test_config1_nonld_100k_rows(oracle, N):
+    """BASELINE.json configs[1]: non-LD, ~100k rows, one comparison individual; SURVEY s8 sizes it at the 2504-individual
+    panel (the panel's width only enters through the AF column and the comparison individual's two bits)."""
+    L = 100_000
     alle, nr, na = synth_host(1, L, N)
     with E.Engine() as eng:
-        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        packed = np.concatenate([E.pack_alleles_fast(alle[a:a + 10_000]) for a in range(0, L, 10_000)])
+        eng.upload_panel(packed, N)
+        del packed
         eng.upload_sites(np.arange(L), nr, na, 100)
         eng.run([11], ld=False)
         res = oracle.compare(alle, nr, na, 11, window=100, ld=False)
