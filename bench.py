@@ -768,21 +768,9 @@ def main():
                   "kernel_hbm_frac": nl_bytes * n_rows / (nl_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "note": "non-LD comparison (per-row LIBD0/1/2 + window products, BASELINE.json configs[1] at this row count), "
                           "queued steps, host wall clock; one kernel (k_rows_windows: a wave per window computes its rows' "
-                          "values, stores them and multiplies them up -- nothing is read back); hbm_frac on the step clock, "
-                          "kernel_hbm_frac on the kernel's own events"}
-        # the same without the AF column kept on the device (the host program derives it from its own alt counts)
-        eng.set_option("site_results", 2)
-        eng.set_option("async", 1)
-        for _ in range(50):
-            eng.run(targets, ld=False)
-        eng.sync()
-        t0 = time.perf_counter()
-        for _ in range(200):
-            eng.run(targets, ld=False)
-        eng.sync()
-        non_ld["ms_per_step_without_af_column"] = (time.perf_counter() - t0) / 200 * 1e3
-        eng.set_option("async", 0)
-        eng.set_option("site_results", 1)
+                          "values, stores them and multiplies them up -- nothing is read back; the AF column is made by "
+                          "ibdg_get_site_af when asked for, not by the run); hbm_frac on the step clock, kernel_hbm_frac on "
+                          "the kernel's own events"}
     # BASELINE.json configs[4]'s shape on this rank's rows (not `value`): many comparison individuals in ONE ibdg_run
     many = None
     if world == 1 and not args.no_many:

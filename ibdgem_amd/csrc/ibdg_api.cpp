@@ -156,8 +156,8 @@ struct ibdg_ctx {
     long opt_site_blocks = 4;        // 256-thread workgroups per CU of k_site inside an --LD run (0 = a thread per site)
     long opt_recount_blocks = 4;     // single-wave workgroups per CU of k_alt_count when it runs inside an --LD run
                                      // (0 = the full grid; 4 measured best: tools/recount_sweep.py)
-    long opt_site_results = 1;       // 1: per-site LIBD0/1/2 and AF kept for ibdg_get_site_*; 2: LIBD0/1/2 only; 0: neither --
-                                     // no T x n_sites x 24 B of HBM, no per-site stores (window results only)
+    long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
+                                     // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under
     bool prep_dirty = false;         // the device's PrepInfo may hold the leavings of an upload that did not finish
     long opt_staged_upload = 1;      // panels of 256 MB and more from pageable memory go through the staging team
@@ -1172,9 +1172,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     HIP_TRY(c, hipSetDevice(c->device));
 
     const size_t lanes = (size_t)c->n_groups * c->cpw * 64;
-    const bool want_ll = c->opt_site_results != 0, want_af = c->opt_site_results == 1;
-    if (ensure(c, c->targets, T * 4) || (want_af && ensure(c, c->af, c->n_sites * 8)) ||
-        (want_ll && ensure(c, c->site_ll, T * c->n_sites * 24)) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
+    const bool want_ll = c->opt_site_results != 0;
+    if (ensure(c, c->targets, T * 4) || (want_ll && ensure(c, c->site_ll, T * c->n_sites * 24)) ||
+        ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
     // targets / background weights change rarely between calls (a loop over windows sizes, repeated
     // timing steps): their device copies are rebuilt only when the inputs differ
@@ -1285,7 +1285,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.window = c->window;
     sa.n_win = c->n_win;
     sa.ld_mode = ld_mode ? 1 : 0;
-    sa.af = want_af ? (double *)c->af.p : nullptr;
+    sa.af = nullptr;
     sa.site_ll = want_ll ? (double *)c->site_ll.p : nullptr;
     sa.win_ll = (double *)c->win_ll.p;
 
@@ -1565,7 +1565,20 @@ int ibdg_get_site_af(ibdg_ctx *c, double *af)
 {
     if (!c) return 1;
     if (!c->have_results) return fail(c, "[::] ERROR in ibdg_get_site_af: no results (call ibdg_run)");
-    if (c->res_site_mode != 1) return fail(c, "[::] ERROR in ibdg_get_site_af: the run kept no AF column (option site_results)");
+    if (!c->counts_valid) return fail(c, "[::] ERROR in ibdg_get_site_af: alt counts not computed yet");
+    // made when asked for: it depends on the panel row (or the -A value) only, and no run needs it
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (ensure(c, c->af, c->n_sites * 8)) return 1;
+    if (join_streams(c)) return 1;
+    ibdg::RowsArgs ra = {};
+    ra.rec_all = (const uint2 *)c->rec_all.p;
+    ra.n_sites = c->n_sites;
+    ra.n_ids = c->n_ids;
+    ra.alt_count = (const uint32_t *)c->alt_count.p;
+    ra.fo = c->have_fo ? (const double *)c->fo.p : nullptr;
+    ra.af = (double *)c->af.p;
+    ibdg::launch_site_af(ra, c->stream);
+    HIP_TRY(c, hipGetLastError());
     return fetch(c, af, c->af.p, c->n_sites * 8);
 }
 
@@ -1658,7 +1671,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
     if (!strcmp(name, "site_results")) {
-        if (value < 0 || value > 2) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0, 1 or 2");
+        if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0 or 1");
         c->opt_site_results = value; return 0;
     }
     if (!strcmp(name, "site_blocks_per_cu")) {

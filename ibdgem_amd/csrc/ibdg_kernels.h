@@ -26,7 +26,7 @@ struct RowsArgs {
     uint32_t window;
     uint32_t n_win;
     int ld_mode;                // 1: of the window products only LIBD2 is written
-    double *af;                 // [n_sites], or NULL: not wanted
+    double *af;                 // [n_sites]: written by k_site_af only (ibdg_get_site_af)
     double *site_ll;            // [T][n_sites][3], or NULL: per-site results not wanted
     double *win_ll;             // [T][n_win][3]
 };
@@ -253,6 +253,8 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
 // max_blocks: 0 = a wave per window (four per workgroup); otherwise at most that many workgroups per target, which
 // walk the windows grid-stride (few long-lived waves: for running beside the --LD kernel)
 void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
+// af[s] of every site (k_site_af)
+void launch_site_af(const RowsArgs &a, hipStream_t st);
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st);
 
 }  // namespace ibdg

@@ -214,8 +214,6 @@ __global__ __launch_bounds__(256) void k_rows_windows(RowsArgs a)
                     if (ibd1 == 0.0)
                         ibd1 = 2.2250738585072014e-308;
                     if (live[u]) {
-                        if (a.af && t == 0)
-                            a.af[s] = f[u];
                         if (a.site_ll) {
                             double *d = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
                             d[0] = ibd0;
@@ -459,6 +457,30 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
                        alt_count);
 }
 
+// The AF column (tab column 6): the alt-allele fraction of a row's panel row, src/ibd-parse.c:98, or the -A override
+// (src/ibdgem.c:609-614).  It does not depend on the comparison individual and the host has it from the alt counts
+// anyway, so it is produced when somebody asks (ibdg_get_site_af), not stored by every run.
+__global__ __launch_bounds__(256) void k_site_af(RowsArgs a)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sites)
+        return;
+    double f = (double)a.alt_count[a.rec_all[s].x] / (double)(int)(2u * a.n_ids);
+    if (a.fo) {
+        const double o = a.fo[3 * s];
+        if (o == o)
+            f = o;
+    }
+    a.af[s] = f;
+}
+
+void launch_site_af(const RowsArgs &a, hipStream_t st)
+{
+    if (a.n_sites == 0)
+        return;
+    hipLaunchKernelGGL(k_site_af, dim3((unsigned)((a.n_sites + 255) / 256)), dim3(256), 0, st, a);
+}
+
 void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks)
 {
     if (a.n_sites == 0 || n_targets == 0)
@@ -469,7 +491,7 @@ void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, 
         blocks = max_blocks;
     dim3 grid((unsigned)blocks, n_targets);
     // everything but LIBD2 of the windows unwanted (--LD, no per-site results): the one-value form
-    if (a.ld_mode && !a.site_ll && !a.af)
+    if (a.ld_mode && !a.site_ll)
         hipLaunchKernelGGL(k_rows_windows<false>, grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(k_rows_windows<true>, grid, dim3(256), 0, st, a);

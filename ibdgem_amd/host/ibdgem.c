@@ -1390,7 +1390,7 @@ static void *upload_run(void *arg)
     j->failed = 1;
     /* the per-site table needs LIBD0/1/2 of every row (its AF column the host has itself); --summary-only needs
      * nothing per row: the engine then neither keeps nor computes per-row results beyond the IBD2 pick */
-    if (ibdg_set_option(j->eng, "site_results", opt_summary_only ? 0 : 2))
+    if (ibdg_set_option(j->eng, "site_results", opt_summary_only ? 0 : 1))
         return NULL;
     if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
         return NULL;

@@ -158,7 +158,8 @@ int ibdg_get_windows(ibdg_ctx *ctx, uint32_t *first, uint32_t *last, uint32_t *n
 int ibdg_run(ibdg_ctx *ctx, const uint32_t *targets, size_t n_targets, const uint8_t *bg_count,
              int pu_id, int ld_mode);
 
-/* AF column: alt-allele fraction per uploaded site (or the -A override). */
+/* AF column: alt-allele fraction per uploaded site (or the -A override): alt count / (2 n_ids), src/ibd-parse.c:98.
+ * Computed by this call (it depends on the panel row only), after an ibdg_run. */
 int ibdg_get_site_af(ibdg_ctx *ctx, double *af);
 /* LIBD0, LIBD1, LIBD2 per site of target t: out[n_sites][3] (tab columns 12-14). */
 int ibdg_get_site_ll(ibdg_ctx *ctx, size_t t, double *out);
@@ -203,10 +204,10 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it; beside the --LD kernel the recount runs with "recount_blocks_per_cu"
  * single-wave workgroups per CU, default 4, 0 = its full grid); "site_results" (what ibdg_run keeps per row: 1, the default,
- * LIBD0/1/2 of every row and comparison individual and the AF column, for ibdg_get_site_ll / ibdg_get_site_af; 2 the same
- * without the AF column; 0 nothing -- no n_targets x n_sites x 24 bytes of device memory, no per-row stores, and in --LD
- * mode only the IBD2 pick of a row is computed at all: for callers that want the window table only, e.g. hundreds of
- * comparison individuals in one call; the two getters then fail); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
+ * LIBD0/1/2 of every row and comparison individual for ibdg_get_site_ll; 0 nothing -- no n_targets x n_sites x 24 bytes
+ * of device memory, no per-row stores, and in --LD mode only the IBD2 pick of a row is computed at all: for callers that
+ * want the window table only, e.g. hundreds of comparison individuals in one call; ibdg_get_site_ll then fails.  The AF
+ * column never costs a run anything: ibdg_get_site_af computes it when called); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
  * ordinary host memory goes to the device through page-locked staging buffers filled by a team of host
  * threads instead of the runtime's pageable-memory path); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference

@@ -443,9 +443,9 @@ def test_all_sites_zero_coverage():
 
 @pytest.mark.parametrize("N,L,W,T", [(70, 900, 100, 1), (150, 2500, 37, 3), (300, 700, 2, 6), (64, 300, 257, 2)])
 def test_site_results_option_changes_no_window_bit(oracle, N, L, W, T):
-    """Option "site_results": 0 keeps (and in --LD mode computes) nothing per row, 2 keeps LIBD0/1/2 without the AF
-    column.  The window table must be the same bits in every mode, --LD or not, and equal the oracle's; rows
-    without reads between and around the windows must not disturb the products (reference src/ibdgem.c:657-667)."""
+    """Option "site_results": 0 keeps (and in --LD mode computes) nothing per row.  The window table must be the same
+    bits in both modes, --LD or not, and equal the oracle's; rows without reads between and around the windows must
+    not disturb the products (reference src/ibdgem.c:657-667)."""
     alle, nr, na = synth(77 + N, L, N)
     nr[:5] = na[:5] = 0                      # rows without reads before the first window ...
     nr[-7:] = na[-7:] = 0                    # ... and behind the last
@@ -467,19 +467,13 @@ def test_site_results_option_changes_no_window_bit(oracle, N, L, W, T):
                     assert_ld_close(win[i][:, :2], res["win"][:, :2], "LD window")
                 else:
                     assert_bits(win[i], res["win"], "window products")
-            eng.set_option("site_results", 2)
-            eng.run(targets, ld=ld)
-            for i in range(T):
-                assert_bits(eng.window_ll(i), win[i], "windows, mode 2")
-                assert_bits(eng.site_ll(i), site[i], "site, mode 2")
-            with pytest.raises(E.EngineError, match="AF column"):
-                eng.site_af()
             eng.set_option("site_results", 0)
             eng.run(targets, ld=ld)
             for i in range(T):
                 assert_bits(eng.window_ll(i), win[i], "windows, mode 0")
             with pytest.raises(E.EngineError, match="no per-site results"):
                 eng.site_ll(0)
+            assert_bits(eng.site_af(), af, "AF column (made on demand, whatever the run kept)")
         eng.set_option("site_results", 1)
         eng.run(targets[:1], ld=True)
         assert_bits(eng.site_af(), af, "AF column")
