@@ -164,6 +164,8 @@ struct ibdg_ctx {
     // page-locked staging for large panels from pageable memory (staged_upload)
     static constexpr int STAGE_WORKERS = 8;
     static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+    long opt_stage_workers = STAGE_WORKERS;   // host threads of the staging team (two 8 MB page-locked buffers each): a caller with
+                                              // several contexts uploading at once gives each a share of the cores
     void *stage[2 * STAGE_WORKERS] = {};
     hipEvent_t stage_ev[2 * STAGE_WORKERS] = {};
 };
@@ -435,7 +437,7 @@ void stage_worker(StageJob *j)
 
 int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t dw)
 {
-    int T = (int)std::min<unsigned>(ibdg_ctx::STAGE_WORKERS, std::max(1u, std::thread::hardware_concurrency()));
+    int T = (int)std::min<unsigned>((unsigned)c->opt_stage_workers, std::max(1u, std::thread::hardware_concurrency()));
     const size_t rows_per_piece = std::max<size_t>(1, ibdg_ctx::STAGE_BYTES / rw);
     for (int b = 0; b < 2 * T; ++b) {
         if (!c->stage[b])
@@ -1670,6 +1672,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
+    if (!strcmp(name, "stage_workers")) {
+        if (value < 1 || value > ibdg_ctx::STAGE_WORKERS) return fail(c, "[::] ERROR in ibdg_set_option: stage_workers must be 1..%d", ibdg_ctx::STAGE_WORKERS);
+        c->opt_stage_workers = value; return 0;
+    }
     if (!strcmp(name, "site_results")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0 or 1");
         c->opt_site_results = value; return 0;

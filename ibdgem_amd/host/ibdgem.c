@@ -1379,6 +1379,7 @@ typedef struct {
     const uint32_t *bg_idx;      /* --reference-order: the -B list in file order */
     size_t bg_n;
     int ref_order, has_B;
+    int n_uploads;               /* uploads running at the same time */
     int failed;
     pthread_t th;
     int started;
@@ -1391,6 +1392,10 @@ static void *upload_run(void *arg)
     /* the per-site table needs LIBD0/1/2 of every row (its AF column the host has itself); --summary-only needs
      * nothing per row: the engine then neither keeps nor computes per-row results beyond the IBD2 pick */
     if (ibdg_set_option(j->eng, "site_results", opt_summary_only ? 0 : 1))
+        return NULL;
+    /* the uploads of all devices run side by side: each staging team gets its share of the host's threads (and locks
+     * as much less memory: two 8 MB buffers per thread) */
+    if (j->n_uploads > 1 && ibdg_set_option(j->eng, "stage_workers", j->n_uploads >= 8 ? 1 : 8 / j->n_uploads))
         return NULL;
     if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
         return NULL;
@@ -1716,6 +1721,7 @@ int main(int argc, char **argv)
             memset(&ups[d], 0, sizeof ups[d]);
             ups[d].eng = engs[d]; ups[d].r0 = 0; ups[d].n = n_rows; ups[d].n_ids = n_ids;
             ups[d].ref_order = opt_ref_order; ups[d].has_B = has_B; ups[d].bg_idx = bg.idx; ups[d].bg_n = bg.n;
+            ups[d].n_uploads = n_eng;
         }
         if (!slice_mode) {
             /* whole panel to every device, all copies at once, under the filter chain below */

@@ -207,7 +207,8 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * LIBD0/1/2 of every row and comparison individual for ibdg_get_site_ll; 0 nothing -- no n_targets x n_sites x 24 bytes
  * of device memory, no per-row stores, and in --LD mode only the IBD2 pick of a row is computed at all: for callers that
  * want the window table only, e.g. hundreds of comparison individuals in one call; ibdg_get_site_ll then fails.  The AF
- * column never costs a run anything: ibdg_get_site_af computes it when called); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
+ * column never costs a run anything: ibdg_get_site_af computes it when called); "stage_workers" (1..8, default 8: host threads of that staging team -- a caller
+ * whose contexts upload at the same time gives each its share); "staged_upload" (0/1, default 1: a panel of 256 MB or more in
  * ordinary host memory goes to the device through page-locked staging buffers filled by a team of host
  * threads instead of the runtime's pageable-memory path); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference
