@@ -17,8 +17,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     bench.write_panel_cache(os.path.join(d, "p.cache"), words, 2504, st)
     base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o", "--summary-only"]
     os.makedirs(os.path.join(d, "o"))
-    for rep in range(3):
-        t0 = time.perf_counter()
-        r = subprocess.run(base, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1"), capture_output=True, text=True)
-        dt = time.perf_counter() - t0
-        print(f"{dt:.3f} s", " | ".join(l[8:] for l in r.stderr.splitlines() if l.startswith("## time")))
+    for label, extra_env in (("default (_exit once the files are closed)", {}), ("IBDGEM_KEEP_TEARDOWN=1 (ibdg_destroy, orderly exit)", {"IBDGEM_KEEP_TEARDOWN": "1"})):
+        print(label)
+        for rep in range(4):
+            t0 = time.perf_counter()
+            r = subprocess.run(base, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1", **extra_env), capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            ph = [l[8:] for l in r.stderr.splitlines() if l.startswith("## time")]
+            covered = sum(float(x.rsplit(" ", 1)[1]) for x in ph)
+            print(f"  {dt:.3f} s wall, {covered:.3f} s in phases, {dt - covered:.3f} s outside |", " | ".join(ph))
