@@ -258,6 +258,18 @@ def test_no_device_summary_only_and_threads(tmp_path):
         assert _read(str(tmp_path / "a" / n)) == _read(str(tmp_path / "b" / n))
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REPO, "oracle", "_ref", "ibdgem")),
+                    reason="the reference binary (oracle/_ref/ibdgem) is not in this tree")
+def test_no_device_runs_against_the_reference_binary_on_random_inputs():
+    """The device-less non-LD run on random panels, pileups and flags (-v -D -M -F -f -w -e -c -p -A -N ...): every
+    output file of the host program byte for byte the reference binary's (tools/fuzz_cli_full.py --no-device)."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_cli_full.py"), "80", "7", "--no-device"], cwd=REPO,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "full CLI fuzz: 80 cases" in r.stdout and "0 failures" in r.stdout.splitlines()[-1], r.stdout[-2000:]
+
+
 # ------------------------------------------------------------------------------------------- GPU
 def _run_full(args, cwd, out):
     res = subprocess.run([_exe()] + args + ["-O", str(out)], cwd=cwd, capture_output=True, text=True)

@@ -5,7 +5,7 @@ host program against the reference: every output file byte for byte after the co
 tolerated kind of difference, counted and printed: --LD values of a summary file off by ONE unit in their
 seventh printed digit (decimal ties, see last_digit_tie below).
 
-    python tools/fuzz_cli_full.py [n_cases] [seed] [--reference-order] [--many-targets]
+    python tools/fuzz_cli_full.py [n_cases] [seed] [--reference-order] [--many-targets] [--no-device]
 
 With --reference-order the host is run in its reference-order mode, in which the --LD columns are
 bit-identical to the reference's, so that not even decimal ties can differ.  With --many-targets the
@@ -24,6 +24,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 EXTRA = ["--reference-order"] if "--reference-order" in sys.argv[3:] else []
 MANY = "--many-targets" in sys.argv[3:]
+# --no-device: the host program on a machine without a HIP device (none visible): non-LD cases only, the per-row values
+# and window products from the library's host twins (BASELINE configs[0]); runs anywhere
+NODEV = "--no-device" in sys.argv[3:]
+ENV = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="") if NODEV else None
 bad = 0
 compared = rows_compared = ties = 0
 
@@ -109,7 +113,7 @@ for case in range(n_cases):
             with open(os.path.join(d, "bg.txt"), "w") as fh:
                 fh.write("".join(n + "\n" for n in random.choices(names, k=random.randint(1, N))))
             args += ["-B", "bg.txt"]
-        if random.random() < 0.67: args = ["--LD"] + args
+        if random.random() < 0.67 and not NODEV: args = ["--LD"] + args
         targets = random.sample(names, random.randint(8, N) if MANY else random.randint(1, min(3, N)))
         args += ["-s", ",".join(targets)]
         sq = args[args.index("-N") + 1] if "-N" in args else "UNKWN"
@@ -117,7 +121,7 @@ for case in range(n_cases):
         os.makedirs(out)
         os.makedirs(out2)
         r = subprocess.run([REF, *args, "-O", out], cwd=d, capture_output=True, text=True)
-        o = subprocess.run([EXE, *args, *EXTRA, "-O", out2], cwd=d, capture_output=True, text=True)
+        o = subprocess.run([EXE, *args, *EXTRA, "-O", out2], cwd=d, capture_output=True, text=True, env=ENV)
         try:
             assert r.returncode == o.returncode, (r.returncode, o.returncode, r.stderr[-200:], o.stderr[-200:])
             if r.returncode == 0:
