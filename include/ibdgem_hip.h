@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 2
+#define IBDG_ABI_VERSION 3   /* 3: options site_results, stage_workers; ibdg_get_site_af computes on demand; ibdg_last_run_ms out[4] is 0 */
 
 typedef struct ibdg_ctx ibdg_ctx;
 
@@ -173,7 +173,7 @@ int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out
 /* Device time of the last ibdg_run, from HIP events on the engine's streams:
  * out[0] total (first launch to last completion), out[1] alt-count kernel
  * (0 if not run), out[2] the kernel of the per-row values and window products,
- * out[3] the --LD launches, out[4] 0 (ms; until ABI 2 the window products were
+ * out[3] the --LD launches, out[4] 0 (ms; up to ABI 2 the window products were
  * a kernel of their own).  The per-row kernel runs on a second stream beside
  * the --LD kernels, so the parts overlap and need not add up to the total. */
 int ibdg_last_run_ms(ibdg_ctx *ctx, float out[5]);
