@@ -232,7 +232,7 @@ def best_of(n, fn):
     return best
 
 
-def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targets, n_cov):
+def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targets, n_cov, eng2=None):
     """What one more comparison costs around its kernels, at the full size of this rank's rows.
 
     upload_sites: ibdg_upload_sites with the caller's arrays in pageable memory (numpy), in page-locked
@@ -300,6 +300,43 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
     ec["alt_counts_amortised_ms"] = am
     ec["alt_counts_amortised_sites_per_s"] = n_cov / (am * 1e-3)
     ec["from_pageable_host_arrays_ms"] = clock(True, False)
+    if eng2 is not None:
+        # comparisons in a stream: two contexts on this GPU (each with the panel) take turns, so the preparation of
+        # comparison i+1 is on the device under the --LD kernel of comparison i and the host waits once per comparison
+        # (for the window table of the one before).  Same calls as above, alt counts amortised; per comparison.
+        win_pin2 = ibdgem_amd.PinnedArray((n_win, 3), np.float64)
+        clock(False, True)
+        single = win_pin.array.copy()
+        engs, outs = [eng, eng2], [win_pin, win_pin2]
+        for e in engs:
+            e.set_option("async", 1)
+
+        def submit(e):
+            e.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), n, window)
+            e.run(targets, ld=True)
+
+        def stream_of(k):
+            submit(engs[0])
+            t0 = time.perf_counter()
+            for i in range(1, k + 1):
+                submit(engs[i & 1])
+                engs[(i - 1) & 1].window_ll(0, out=outs[(i - 1) & 1].array)
+            dt = (time.perf_counter() - t0) / k
+            engs[k & 1].window_ll(0, out=outs[k & 1].array)
+            return dt * 1e3
+        stream_of(6)
+        alt = min(stream_of(40) for _ in range(3))
+        for e in engs:
+            e.set_option("async", 0)
+        ec["two_contexts_alternating_ms"] = alt
+        ec["two_contexts_alternating_sites_per_s"] = n_cov / (alt * 1e-3)
+        ec["two_contexts_alternating_bits_equal_single"] = bool(
+            np.array_equal(single, win_pin.array) and np.array_equal(single, win_pin2.array))
+        ec["two_contexts_alternating_note"] = (
+            "40 comparisons through two ibdg contexts on one GPU taking turns (upload_sites_dev + run of i+1 queued before the "
+            "window table of i is fetched); host wall clock per comparison, best of 3; a throughput, where `ms` above is the "
+            "latency of one comparison")
+        win_pin2.close()
     # per-site results (96 MB at 4M rows): pageable vs page-locked destination
     eng.run(targets, ld=True)
     site_pin = ibdgem_amd.PinnedArray((n, 3), np.float64)
@@ -642,6 +679,17 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
+    eng2 = None
+    if world == 1 and not args.no_many and not args.timed_only:
+        # a second context with the same panel, for engine_clock.two_contexts_alternating_ms (idle until then)
+        eng2 = ibdgem_amd.Engine(local, 0.02, 20)
+        for name, val in (("ld_variant", args.variant), ("chunks_per_wave", args.cpw), ("waves_per_block", args.waves)):
+            if val is not None:
+                eng2.set_option(name, val)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            eng2.set_option(k, int(v))
+        eng2.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
     sample_rows = min(args.cpu_sample_rows, panel.shape[0])
     sample_words = panel[:sample_rows].cpu().numpy().view(np.uint64) if rank == 0 else None
     words_all = None
@@ -745,7 +793,10 @@ def main():
     eng.set_option("async", 0)
     eng.set_option("dispatch_events", 0)
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
-    up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov)
+    up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov, eng2)
+    if eng2 is not None:
+        eng2.close()
+        eng2 = None
     up["first_call_ms"] = first_upload_ms
     # BASELINE.json configs[1]'s shape on this rank's rows (not `value`): the non-LD step (per-site values + window products)
     non_ld = None

@@ -790,12 +790,16 @@ static unsigned cull(unsigned count, double cull_p)
  * spends its host time.  These produce the very characters printf produces -- printf rounds the exact
  * binary value to nearest, ties to even -- and hand the rare case they cannot decide to sprintf:
  *   %lf of 0 <= f < 2^40: f * 10^6 exactly in 128-bit integer arithmetic (a double is m * 2^e);
- *   %e: a * 10^(6-E) in long double (64-bit mantissa; relative error < 2^-60 after the table product);
- *       when the result lies within 1e-6 of a rounding boundary or of a power of ten, sprintf decides.
+ *   %e: a * 10^(6-E) as a 64 x 64 -> 128-bit integer product with a table of powers of ten (64-bit mantissas,
+ *       made in long double); when the result lies within 1e-6 of a rounding boundary or 1e-5 of a power of
+ *       ten, sprintf decides.  (Until round 3 the product was taken in long double itself: 62 ns per number
+ *       in x87 code against 20 now -- frexp, floor and the control-word dance of the conversion were the time.)
  * `ibdgem --fmt-check N` compares them with sprintf on N random doubles (tests/test_host_cli.py). */
-/* put_e6's guard band (relative error of q below 2^-60) is argued for the 64-bit mantissa of the x87 long double */
+/* put_e6's table of powers of ten is made in long double and split into 64-bit mantissas */
 _Static_assert(LDBL_MANT_DIG >= 64, "put_e6 needs a long double with a 64-bit mantissa (x86-64); elsewhere use sprintf");
 static long double pow10_tab[700];           /* 10^(i-350) */
+static uint64_t p10_m[700];                  /* the same as integers: pow10_tab[i] = p10_m[i] * 2^p10_e[i], top bit of p10_m set */
+static int16_t p10_e[700];
 static void fmt_init(void)
 {
     static int done;
@@ -805,6 +809,12 @@ static void fmt_init(void)
     for (int i = 1; i <= 349; ++i) {
         pow10_tab[350 + i] = pow10_tab[350 + i - 1] * 10.0L;      /* exact up to 10^27, 1 rounding per step after */
         pow10_tab[350 - i] = 1.0L / pow10_tab[350 + i];
+    }
+    for (int i = 1; i < 700; ++i) {
+        int e;
+        const long double m = frexpl(pow10_tab[i], &e);           /* [0.5, 1) */
+        p10_m[i] = (uint64_t)ldexpl(m, 64);                       /* exact: the mantissa has 64 bits */
+        p10_e[i] = (int16_t)(e - 64);
     }
     done = 1;
 }
@@ -834,19 +844,17 @@ static char *put_lf6(char *d, double f)
 {
     if (!(f >= 0.0) || f >= 1099511627776.0 || (f == 0.0 && signbit(f)))
         return d + sprintf(d, "%lf", f);
-    int e;
-    const double m = frexp(f, &e);                         /* f = m * 2^e, 0.5 <= m < 1 */
-    const uint64_t mi = (uint64_t)ldexp(m, 53);            /* f = mi * 2^(e-53) exactly */
-    unsigned __int128 p = (unsigned __int128)mi * 1000000u;   /* < 2^73 */
-    const int sh = 53 - e;                                 /* f * 10^6 = p / 2^sh; e <= 40 -> sh >= 13 */
-    unsigned __int128 q;
-    if (f == 0.0) {
-        q = 0;
-    } else if (sh >= 127) {
-        q = 0;                                             /* below 2^-54 * 10^6: rounds to 0 (no tie: p < 2^73) */
-    } else {
-        q = p >> sh;
-        const unsigned __int128 rem = p - (q << sh), half = (unsigned __int128)1 << (sh - 1);
+    uint64_t bits;
+    memcpy(&bits, &f, 8);
+    const unsigned ex = (unsigned)(bits >> 52);            /* sign bit is clear */
+    const int sh = 1075 - (int)ex;                         /* f = mi * 2^-sh exactly; f < 2^40 -> sh >= 13 */
+    uint64_t q = 0;
+    if (ex != 0 && sh < 127) {                             /* zero, subnormals and everything below 2^-54 * 10^6 round to 0 */
+        const uint64_t mi = (bits & (((uint64_t)1 << 52) - 1)) | ((uint64_t)1 << 52);
+        const unsigned __int128 p = (unsigned __int128)mi * 1000000u;   /* f * 10^6 = p / 2^sh; p < 2^73 */
+        const unsigned __int128 q128 = p >> sh;            /* < 2^60 */
+        const unsigned __int128 rem = p - (q128 << sh), half = (unsigned __int128)1 << (sh - 1);
+        q = (uint64_t)q128;
         if (rem > half || (rem == half && (q & 1)))
             q += 1;
     }
@@ -861,37 +869,71 @@ static char *put_lf6(char *d, double f)
     return d + 6;
 }
 
-/* "%e" (six decimals, exponent of at least two digits) */
+/* "%e" (six decimals, exponent of at least two digits).  v = mv * 2^ev with a 64-bit mv; q = v * 10^(6-E) as the
+ * 128-bit product of mv and the table's 64-bit mantissa: its integer part is the seven digits, the next 64 bits
+ * the fraction that decides the rounding.  The table entry is within 2^-56 of the power of ten (a rounding per
+ * step of fmt_init), so q is off by less than 1e7 * 2^-56 < 2e-10: a fraction within 1e-6 of one half, or a q
+ * within 1e-5 of a power of ten, goes to sprintf -- except for 1e-21 <= v < 1e7, where the power of ten is exact
+ * and so is the product (most likelihoods; and exactly the values the guard band would catch most often: 1.0,
+ * 0.5, 0.25 of rows without reads were 37 % of a table's numbers and all went to sprintf). */
 static char *put_e6(char *d, double v)
 {
     if (!isfinite(v))
         return d + sprintf(d, "%e", v);
-    if (signbit(v)) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    if (bits >> 63) {
         *d++ = '-';
+        bits &= ~((uint64_t)1 << 63);
         v = -v;
     }
-    if (v == 0.0) {
+    if (bits == 0) {
         memcpy(d, "0.000000e+00", 12);
         return d + 12;
     }
-    int e2;
-    (void)frexp(v, &e2);
-    int E = (int)floor((e2 - 1) * 0.30102999566398120);    /* floor(log10(2^(e2-1))) <= floor(log10 v) */
-    if (E < -340 || E > 320)
+    const int ex = (int)(bits >> 52);
+    if (ex == 0)                                           /* subnormal: printf's business */
         return d + sprintf(d, "%e", v);
-    long double q = (long double)v * pow10_tab[350 + 6 - E];
-    if (q >= 1e7L) {                                       /* the estimate can be one low */
-        ++E;
-        q = (long double)v * pow10_tab[350 + 6 - E];
+    const uint64_t mv = ((bits & (((uint64_t)1 << 52) - 1)) | ((uint64_t)1 << 52)) << 11;
+    const int ev = ex - 1075 - 11;
+    const int b2 = ex - 1023;                              /* 2^b2 <= v < 2^(b2+1) */
+    int E = (b2 * 78913) / 262144 - (b2 < 0);              /* floor(b2 * log10 2) or one off: settled below */
+    uint64_t I = 0;
+    unsigned __int128 prod = 0;
+    int s = 0, settled = 0;
+    for (int tries = 0; tries < 3 && !settled; ++tries) {
+        const int k = 350 + 6 - E;
+        if (k < 1 || k > 699)
+            return d + sprintf(d, "%e", v);
+        prod = (unsigned __int128)mv * p10_m[k];           /* q = prod * 2^-s */
+        s = -(ev + p10_e[k]);
+        if (s < 65 || s > 126)
+            return d + sprintf(d, "%e", v);
+        I = (uint64_t)(prod >> s);
+        if (I >= 10000000u)
+            ++E;
+        else if (I < 1000000u)
+            --E;
+        else
+            settled = 1;
     }
-    /* q in [10^6, 10^7): seven digits.  Too close to a boundary to trust the last bits of q: printf decides. */
-    if (!(q >= 1e6L + 1e-5L) || !(q < 1e7L - 1e-5L))
+    if (!settled)
         return d + sprintf(d, "%e", v);
-    const unsigned long Dq = (unsigned long)q;             /* q > 0: truncation is the floor (no libm call) */
-    const long double fr = q - (long double)Dq;
-    if (fr > 0.5L - 1e-6L && fr < 0.5L + 1e-6L)
-        return d + sprintf(d, "%e", v);
-    unsigned long D = Dq + (fr > 0.5L ? 1u : 0u);
+    unsigned long D;
+    if (E <= 6 && E >= 6 - 27) {
+        /* 10^0 .. 10^27 are exact in the table, so prod is q itself: round to nearest, ties to even, on all its bits
+         * (1.0, 0.5, 0.25 -- rows without reads -- are exactly such ties or exact values) */
+        const unsigned __int128 rem = prod & (((unsigned __int128)1 << s) - 1), half = (unsigned __int128)1 << (s - 1);
+        D = I + ((rem > half || (rem == half && (I & 1))) ? 1u : 0u);
+    } else {
+        const uint64_t fr = (uint64_t)((prod << (128 - s)) >> 64);            /* the fraction, 0.64 fixed point */
+        const uint64_t tol5 = 184467440737096ull, tol6 = 18446744073710ull, half = (uint64_t)1 << 63;   /* 1e-5, 1e-6 * 2^64 */
+        if ((I == 1000000u && fr < tol5) || (I == 9999999u && fr > ~tol5))
+            return d + sprintf(d, "%e", v);
+        if (fr > half - tol6 && fr < half + tol6)
+            return d + sprintf(d, "%e", v);
+        D = I + (fr > half ? 1u : 0u);
+    }
     if (D >= 10000000ul) {
         D /= 10;
         ++E;
@@ -935,12 +977,13 @@ static int fmt_check(long n)
     for (long i = 0; i < n; ++i) {
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;
         double v;
-        switch (i % 6) {
+        switch (i % 7) {
         case 0: { uint64_t bits = x; memcpy(&v, &bits, 8); break; }                       /* any bit pattern */
         case 1: v = (double)(x >> 11) / 9007199254740992.0; break;                         /* [0,1) */
         case 2: v = ldexp((double)(x >> 11) / 9007199254740992.0, -(int)(x % 1070)); break; /* likelihood-like */
         case 3: v = (double)(x % 20000001) / 1e7 * pow(10.0, (int)(x >> 40) % 40 - 20); break; /* short decimals */
         case 4: v = (double)(x % 2000001) / 128.0 / 15625.0; break;                         /* %lf ties: k/2^7 scaled */
+        case 5: v = ((double)(1000000 + x % 9000000) + 0.5) / (double)(1u << ((x >> 32) % 3)); break; /* %e ties and near-ties */
         default: v = (double)((x >> 20) % 5009) / 5008.0; break;                           /* allele frequencies */
         }
         if (isnan(v))
