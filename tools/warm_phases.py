@@ -15,13 +15,18 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     open(os.path.join(d, "p.hap"), "w").write("placeholder\n")
     st = os.stat(os.path.join(d, "p.hap"))
     bench.write_panel_cache(os.path.join(d, "p.cache"), words, 2504, st)
-    base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o", "--summary-only"]
+    base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o"]
     os.makedirs(os.path.join(d, "o"))
-    for label, extra_env in (("default (_exit once the files are closed)", {}), ("IBDGEM_KEEP_TEARDOWN=1 (ibdg_destroy, orderly exit)", {"IBDGEM_KEEP_TEARDOWN": "1"})):
+    for label, extra_env, extra in (("--summary-only, default (_exit once the files are closed)", {}, ["--summary-only"]),
+                                    ("--summary-only, IBDGEM_KEEP_TEARDOWN=1 (ibdg_destroy, orderly exit)", {"IBDGEM_KEEP_TEARDOWN": "1"}, ["--summary-only"]),
+                                    ("with the per-site table, default", {}, []),
+                                    ("with the per-site table, IBDGEM_KEEP_TEARDOWN=1", {"IBDGEM_KEEP_TEARDOWN": "1"}, []),
+                                    ("with the per-site table, one host thread", {}, ["--threads", "1"]),
+                                    ("--summary-only again", {}, ["--summary-only"])):
         print(label)
         for rep in range(4):
             t0 = time.perf_counter()
-            r = subprocess.run(base, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1", **extra_env), capture_output=True, text=True)
+            r = subprocess.run(base + extra, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1", **extra_env), capture_output=True, text=True)
             dt = time.perf_counter() - t0
             ph = [l[8:] for l in r.stderr.splitlines() if l.startswith("## time")]
             covered = sum(float(x.rsplit(" ", 1)[1]) for x in ph)
