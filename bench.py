@@ -282,16 +282,25 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
         # (option "async": ibdg_run returns once its kernels are queued and ibdg_get_window_ll is what waits -- one host
         # wait for the comparison instead of two)
         eng.set_option("async", 1)
-        once()
-        ms = best_of(5, once)
+        for _ in range(10):
+            once()
+        all_ms = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            once()
+            all_ms.append((time.perf_counter() - t0) * 1e3)
         eng.set_option("async", 0)
         eng.set_option("count_in_run", 0)
-        return ms
+        medians.append(float(np.median(all_ms)))
+        return min(all_ms)
+    medians = []
     full = clock(True, True)
     ec = {
         "definition": "site arrays (row index, n_ref, n_alt) resident in HBM -> per-window LIBD0/1/2 in host memory: "
                       "ibdg_upload_sites_dev + ibdg_run with the alt-allele counts recomputed inside (K0) + "
-                      "ibdg_get_window_ll into page-locked memory; host wall clock, best of 5",
+                      "ibdg_get_window_ll into page-locked memory; host wall clock of one comparison, best of 20 after 10 untimed "
+                      "ones (the chip's clock takes that long to settle after the other legs: 1.05 ms for the first few, "
+                      "0.97-0.99 from then on, profiles/r03_engine_clock_ab.txt)",
         "ms": full, "sites_per_s": n_cov / (full * 1e-3),
         "alt_counts_amortised_ms": None, "alt_counts_amortised_sites_per_s": None,
         "from_pageable_host_arrays_ms": None,
@@ -300,6 +309,7 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
     ec["alt_counts_amortised_ms"] = am
     ec["alt_counts_amortised_sites_per_s"] = n_cov / (am * 1e-3)
     ec["from_pageable_host_arrays_ms"] = clock(True, False)
+    ec["median_of_20_ms"] = {"ms": medians[0], "alt_counts_amortised_ms": medians[1], "from_pageable_host_arrays_ms": medians[2]}
     if eng2 is not None:
         # comparisons in a stream: two contexts on this GPU (each with the panel) take turns, so the preparation of
         # comparison i+1 is on the device under the --LD kernel of comparison i and the host waits once per comparison
@@ -310,6 +320,7 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
         engs, outs = [eng, eng2], [win_pin, win_pin2]
         for e in engs:
             e.set_option("async", 1)
+            e.set_option("dev_inputs_ready", 1)     # the arrays were complete long ago: no device-wide wait per upload
 
         def submit(e):
             e.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), n, window)
@@ -328,12 +339,13 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
         alt = min(stream_of(40) for _ in range(3))
         for e in engs:
             e.set_option("async", 0)
+            e.set_option("dev_inputs_ready", 0)
         ec["two_contexts_alternating_ms"] = alt
         ec["two_contexts_alternating_sites_per_s"] = n_cov / (alt * 1e-3)
         ec["two_contexts_alternating_bits_equal_single"] = bool(
             np.array_equal(single, win_pin.array) and np.array_equal(single, win_pin2.array))
         ec["two_contexts_alternating_note"] = (
-            "40 comparisons through two ibdg contexts on one GPU taking turns (upload_sites_dev + run of i+1 queued before the "
+            "40 comparisons through two ibdg contexts on one GPU taking turns, option dev_inputs_ready (upload_sites_dev + run of i+1 queued before the "
             "window table of i is fetched); host wall clock per comparison, best of 3; a throughput, where `ms` above is the "
             "latency of one comparison")
         win_pin2.close()

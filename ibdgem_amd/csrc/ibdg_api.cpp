@@ -138,6 +138,7 @@ struct ibdg_ctx {
                                     // gives the dominant kernel's own duration, but costs ~10 us per run more than
                                     // one event record (measured), so it is off unless asked for
     long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
+    long opt_dev_inputs_ready = 0;   // 1: ibdg_upload_sites_dev trusts the caller that its arrays are complete (no device-wide wait)
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
     long opt_variant = 0;  // 0 auto, 1 strict products, 2 exponent counting, 3 strict products + serial sums in
@@ -1095,8 +1096,11 @@ int ibdg_upload_sites_dev(ibdg_ctx *c, const void *dev_row_index, const void *de
     const auto t0 = std::chrono::steady_clock::now();
     if (upload_sites_check(c, dev_n_ref, dev_n_alt, dev_row_index != nullptr, n_sites, window)) return 1;
     if (quiesce(c)) return 1;
-    // the arrays may have been produced on another stream (e.g. torch's): make them visible first
-    HIP_TRY(c, hipDeviceSynchronize());
+    // the arrays may have been produced on another stream (e.g. torch's): make them visible first.  This waits for the
+    // whole device -- other contexts' kernels included -- so a caller who knows the arrays are complete says so
+    // (option "dev_inputs_ready") and its preparation can run under another context's --LD kernel.
+    if (!c->opt_dev_inputs_ready)
+        HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipEventRecord(c->ev_up[0], c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_up[1], c->stream));
     return upload_sites_finish(c, upload_sites_core(c, (const uint32_t *)dev_row_index, (const uint8_t *)dev_n_ref,
@@ -1671,6 +1675,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
+    if (!strcmp(name, "dev_inputs_ready")) { c->opt_dev_inputs_ready = value != 0; return 0; }
     if (!strcmp(name, "staged_upload")) { c->opt_staged_upload = value != 0; return 0; }
     if (!strcmp(name, "stage_workers")) {
         if (value < 1 || value > ibdg_ctx::STAGE_WORKERS) return fail(c, "[::] ERROR in ibdg_set_option: stage_workers must be 1..%d", ibdg_ctx::STAGE_WORKERS);

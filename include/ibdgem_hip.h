@@ -117,7 +117,10 @@ int ibdg_upload_sites(ibdg_ctx *ctx, const uint32_t *row_index, const uint8_t *n
 
 /* Same, with row_index / n_ref / n_alt already in this context's device memory
  * (uint32 / uint8 / uint8; dev_row_index may be NULL as above).  f_override
- * stays a HOST array (or NULL): its powers are taken with the host's libm. */
+ * stays a HOST array (or NULL): its powers are taken with the host's libm.
+ * The call first waits for the whole device (the arrays may come from any stream); with option
+ * "dev_inputs_ready" 1 the caller vouches that they are complete and the wait is left out -- the
+ * preparation of one context can then run under the --LD kernel of another on the same GPU. */
 int ibdg_upload_sites_dev(ibdg_ctx *ctx, const void *dev_row_index, const void *dev_n_ref,
                           const void *dev_n_alt, const double *f_override, size_t n_sites,
                           unsigned window);
@@ -201,7 +204,8 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * run more than the default single event record); "async" (0/1: ibdg_run returns as soon as its kernels are queued;
  * ibdg_sync, ibdg_run_ms and every ibdg_get_* wait for them -- lets a caller
  * queue one run per comparison individual without a host round trip between
- * them); "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
+ * them); "dev_inputs_ready" (0/1: ibdg_upload_sites_dev does not wait for the whole device first, see there);
+ * "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it; beside the --LD kernel the recount runs with "recount_blocks_per_cu"
  * single-wave workgroups per CU, default 4, 0 = its full grid); "site_results" (what ibdg_run keeps per row: 1, the default,
  * LIBD0/1/2 of every row and comparison individual for ibdg_get_site_ll; 0 nothing -- no n_targets x n_sites x 24 bytes

@@ -726,6 +726,54 @@ def test_device_resident_inputs_identity_rows_and_pinned_arrays(oracle, L, W, co
     assert_ld_close(got[0][0][:, :2], res["win"][:, :2], "LD")
 
 
+def test_two_contexts_taking_turns_give_the_bits_of_one(oracle):
+    """Comparisons streamed through two contexts on one GPU (bench.py engine_clock.two_contexts_alternating_ms): with
+    "async" and "dev_inputs_ready" the preparation of one context's comparison runs under the --LD kernel of the
+    other's; every window table is the one a lone context computes for that comparison."""
+    import torch
+    N, L, W = 96, 6000, 20
+    alle, nr0, na0 = synth(4242, L, N, 1.2)
+    rng = np.random.default_rng(77)
+    comps = []
+    for k in range(6):                       # six comparisons: different read counts and comparison individuals
+        nr = rng.poisson(0.7, L).clip(0, 10).astype(np.uint8)
+        na = rng.poisson(0.5, L).clip(0, 10).astype(np.uint8)
+        comps.append((nr, na, int(rng.integers(0, N))))
+    dev = [(torch.from_numpy(nr).cuda(), torch.from_numpy(na).cuda()) for nr, na, _ in comps]
+    torch.cuda.synchronize()
+    words = E.pack_alleles_fast(alle)
+    lone = []
+    with E.Engine() as eng:
+        eng.upload_panel(words, N)
+        for (nr, na, t), (dnr, dna) in zip(comps, dev):
+            eng.upload_sites_dev(None, dnr.data_ptr(), dna.data_ptr(), L, W)
+            eng.run([t], ld=True)
+            lone.append(eng.window_ll(0).copy())
+    with E.Engine() as a, E.Engine() as b:
+        engs = [a, b]
+        for e in engs:
+            e.upload_panel(words, N)
+            e.set_option("async", 1)
+            e.set_option("dev_inputs_ready", 1)
+        got = [None] * len(comps)
+
+        def submit(i):
+            e = engs[i & 1]
+            e.upload_sites_dev(None, dev[i][0].data_ptr(), dev[i][1].data_ptr(), L, W)
+            e.run([comps[i][2]], ld=True)
+        submit(0)
+        for i in range(1, len(comps)):
+            submit(i)
+            got[i - 1] = engs[(i - 1) & 1].window_ll(0).copy()
+        got[-1] = engs[(len(comps) - 1) & 1].window_ll(0).copy()
+    for i, (g, w) in enumerate(zip(got, lone)):
+        assert_bits(g, w, f"comparison {i} through two contexts")
+    nr, na, t = comps[3]
+    res = oracle.compare(alle, nr, na, t, window=W, ld=True)
+    assert_bits(got[3][:, 2], res["win"][:, 2], "LIBD2")
+    assert_ld_close(got[3][:, :2], res["win"][:, :2], "LD")
+
+
 def test_rows_in_any_order_and_the_first_offending_site(oracle):
     """Rows visited in a random order (several scan blocks, duplicates included) take the strict kernel and
     still equal the oracle; errors name the first offending site in list order, its row before its counts."""

@@ -84,6 +84,15 @@ for case in range(n_cases):
                 if not ok:
                     bad += 1
                     print("MISMATCH", desc, "target", t, flush=True)
+                    if os.environ.get("FUZZ_DETAIL"):          # which part: per-row values, window count, LIBD2, --LD columns
+                        sd = np.flatnonzero((site.view(np.uint64) != res["site"].view(np.uint64)).any(axis=1))
+                        print("   rows that differ:", len(sd), sd[:8], "| windows", len(win), "vs", len(res["win"]), flush=True)
+                        if len(win) == len(res["win"]) and len(win):
+                            wd = np.flatnonzero(win[:, 2].view(np.uint64) != res["win"][:, 2].view(np.uint64))
+                            ld = np.flatnonzero(~np.isclose(win[:, :2], res["win"][:, :2], rtol=1e-10, atol=0, equal_nan=True).all(axis=1))
+                            print("   LIBD2 windows that differ:", len(wd), wd[:8], "| --LD windows:", len(ld), ld[:8], flush=True)
+                            if len(ld):
+                                print("   first:", win[ld[0]], res["win"][ld[0]], flush=True)
                     break
     except Exception as e:                        # noqa: BLE001
         bad += 1
