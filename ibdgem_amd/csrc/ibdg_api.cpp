@@ -138,6 +138,7 @@ struct ibdg_ctx {
                                     // gives the dominant kernel's own duration, but costs ~10 us per run more than
                                     // one event record (measured), so it is off unless asked for
     long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
+    long opt_rows_blocks = 0;   // non-LD run: workgroups of k_rows_windows per CU (resident grid, each wave takes several windows); 0 = one wave per window
     long opt_dev_inputs_ready = 0;   // 1: ibdg_upload_sites_dev trusts the caller that its arrays are complete (no device-wide wait)
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
@@ -1513,7 +1514,13 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
     if (rows_on_main) {
         if (join_streams(c)) return 1;           // an earlier run's kernel on stream2 may still write the results
-        ibdg::launch_rows_windows(sa, (unsigned)T, c->stream, 0);
+        // alone on the chip: a wave per window (the default).  A resident grid whose waves walk over several windows -- even
+        // with the next window's records kept in flight -- measured slower at every size (rows_blocks_per_cu 4..28:
+        // 0.048-0.041 ms against 0.040)
+        unsigned blocks = 0;
+        if (c->opt_rows_blocks > 0)
+            blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_rows_blocks / T));
+        ibdg::launch_rows_windows(sa, (unsigned)T, c->stream, blocks);
     }
     if (!dispatch_events)
         HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
@@ -1684,6 +1691,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "site_results")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0 or 1");
         c->opt_site_results = value; return 0;
+    }
+    if (!strcmp(name, "rows_blocks_per_cu")) {
+        if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: rows_blocks_per_cu must be 0..128");
+        c->opt_rows_blocks = value; return 0;
     }
     if (!strcmp(name, "site_blocks_per_cu")) {
         if (value < 0 || value > 128) return fail(c, "[::] ERROR in ibdg_set_option: site_blocks_per_cu must be 0..128");

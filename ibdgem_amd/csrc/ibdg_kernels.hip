@@ -120,11 +120,12 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 // pick of every row: one table look-up, nothing stored.
 // ---------------------------------------------------------------------------
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_rows_windows(RowsArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_rows_windows(RowsArgs a)
 {
     constexpr int NV = FULL ? 3 : 1;                 // values per row kept for the products
     __shared__ double strip[4][128 * NV];
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave's number as a scalar: the window's bounds then come through scalar loads and live in SGPRs)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
     const uint32_t tgt = a.targets[t];
     double *buf = strip[wave];
