@@ -119,131 +119,160 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 // results only (FULL = false in --LD mode: the host program's --summary-only) computes just the IBD2
 // pick of every row: one table look-up, nothing stored.
 // ---------------------------------------------------------------------------
+// One turn of a window: rows [base, base + 128) below e, two per lane, all their gathers in flight; the rows' values go to
+// site_ll (when kept) and their factors for the window products -- 1.0 for a row without reads or beyond e -- into `buf`.
 template <bool FULL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_rows_windows(RowsArgs a)
+__device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_t tgt, size_t base, size_t e, unsigned lane,
+                                          double *__restrict__ buf)
+{
+    constexpr int NV = FULL ? 3 : 1;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    uint2 rc[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const size_t s = base + 64 * u + lane;
+        live[u] = s < e;
+        rc[u] = live[u] ? a.rec_all[s] : make_uint2(0, 0);
+    }
+    uint32_t k[2];
+    uint2 tw[2];
+    double p00[2], p01[2], p11[2], fo[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc[u].y);
+        p00[u] = L[0];
+        p01[u] = L[1];
+        p11[u] = L[2];
+        k[u] = FULL && live[u] ? a.alt_count[rc[u].x] : 0u;
+        if (a.t32) {
+            // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
+            // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
+            const uint2 *p = reinterpret_cast<const uint2 *>(
+                a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc[u].x >> 6)) * 64 + (tgt & 63));
+            tw[u] = live[u] ? p[(rc[u].x >> 5) & 1] : make_uint2(0, 0);
+        } else {
+            const uint64_t *row = a.panel + (size_t)rc[u].x * a.stride;
+            const uint64_t r0 = live[u] ? row[2 * (tgt >> 6)] : 0, r1 = live[u] ? row[2 * (tgt >> 6) + 1] : 0;
+            tw[u] = make_uint2((uint32_t)((r0 >> (tgt & 63)) & 1u) << (rc[u].x & 31),
+                               (uint32_t)((r1 >> (tgt & 63)) & 1u) << (rc[u].x & 31));
+        }
+        fo[u] = FULL && a.fo && live[u] ? a.fo[3 * (base + 64 * u + lane)] : qnan;
+    }
+    double f[2], pw1[2], pw2[2];
+    if (FULL) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f[u] = (double)k[u] / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
+            pw1[u] = a.pow_tab[2 * k[u]];
+            pw2[u] = a.pow_tab[2 * k[u] + 1];
+            if (fo[u] == fo[u]) {          // not NaN: -A override (src/ibdgem.c:609-614)
+                const size_t s = base + 64 * u + lane;
+                f[u] = fo[u];
+                pw1[u] = a.fo[3 * s + 1];
+                pw2[u] = a.fo[3 * s + 2];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const size_t s = base + 64 * u + lane;
+        const unsigned A0 = (tw[u].x >> (rc[u].x & 31)) & 1u, A1 = (tw[u].y >> (rc[u].x & 31)) & 1u;
+        const unsigned g = A0 + A1;
+        const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
+        const bool covered = rc[u].y != 0;            // table offset 0 <=> no reads
+        double *o = buf + (64 * u + lane) * NV;
+        if (FULL) {
+            const double omf = 1 - f[u];
+            double ibd0 = 1.0;
+            if (!(p00[u] == 1 || p01[u] == 1 || p11[u] == 1)) {
+                const double t1 = pw1[u] * p00[u];
+                const double t2 = ((2 * omf) * f[u]) * p01[u];
+                const double t3 = pw2[u] * p11[u];
+                ibd0 = (t1 + t2) + t3;
+                if (ibd0 == 0.0)
+                    ibd0 = 2.2250738585072014e-308;      // DBL_MIN
+            }
+            double ibd1;
+            if (g == 0)
+                ibd1 = (f[u] * p01[u]) + (omf * p00[u]);
+            else if (g == 1)
+                ibd1 = ((0.5 * p01[u]) + ((0.5 * omf) * p00[u])) + ((0.5 * f[u]) * p11[u]);
+            else
+                ibd1 = (omf * p01[u]) + (f[u] * p11[u]);
+            if (ibd1 == 0.0)
+                ibd1 = 2.2250738585072014e-308;
+            if (live[u]) {
+                if (a.site_ll) {
+                    double *d = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
+                    d[0] = ibd0;
+                    d[1] = ibd1;
+                    d[2] = ibd2;
+                }
+            }
+            o[0] = covered ? ibd0 : 1.0;
+            o[1] = covered ? ibd1 : 1.0;
+            o[2] = covered ? ibd2 : 1.0;
+        } else {
+            o[0] = covered ? ibd2 : 1.0;
+        }
+    }
+}
+
+// WPW consecutive windows per wave: their turns fill WPW strips one after the other, then lanes 0 .. NV*WPW-1 multiply the
+// strips up side by side -- an LDS read instruction costs the LDS pipeline the same 8 cycles whether 3 lanes or 64 take part,
+// and with one window per wave those reads kept it busy 60 % of the kernel's time (PMC LdsUtil), the busiest unit of all.
+#ifndef IBDG_ROWS_WPW
+#define IBDG_ROWS_WPW 2
+#endif
+template <bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rows_windows(RowsArgs a)
 {
     constexpr int NV = FULL ? 3 : 1;                 // values per row kept for the products
-    __shared__ double strip[4][128 * NV];
-    // (the wave's number as a scalar: the window's bounds then come through scalar loads and live in SGPRs)
+    constexpr int WPW = IBDG_ROWS_WPW;
+    __shared__ double strip[4][WPW][128 * NV];
+    // (the wave's number as a scalar: the windows' bounds then come through scalar loads and live in SGPRs)
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
     const uint32_t tgt = a.targets[t];
-    double *buf = strip[wave];
     const uint32_t n_w = a.n_win ? a.n_win : 1;      // no covered row at all: the rows still get their values
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-    for (uint32_t w = blockIdx.x * 4 + wave; w < n_w; w += gridDim.x * 4) {
-        const size_t b = w == 0 ? 0 : a.cov_site[(size_t)w * a.window];
-        const size_t e = w + 1 >= a.n_win ? a.n_sites : a.cov_site[(size_t)(w + 1) * a.window];
+    const uint32_t n_groups = (n_w + WPW - 1) / WPW;
+    const unsigned cq = lane / NV, cc = lane % NV;   // the chain a lane multiplies up: window cq of the group, value cc
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+        const uint32_t w0 = g * WPW;
+        size_t bd[WPW + 1];                          // window w0 + q takes the rows [bd[q], bd[q + 1])
+        bd[0] = w0 == 0 ? 0 : a.cov_site[(size_t)w0 * a.window];
+        size_t span = 0;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const uint32_t w = w0 + q;
+            bd[q + 1] = w >= n_w ? bd[q] : (w + 1 >= a.n_win ? a.n_sites : a.cov_site[(size_t)(w + 1) * a.window]);
+            span = bd[q + 1] - bd[q] > span ? bd[q + 1] - bd[q] : span;
+        }
         double acc = 1.0;
-        for (size_t base = b; base < e; base += 128) {
-            uint2 rc[2];
-            bool live[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const size_t s = base + 64 * u + lane;
-                live[u] = s < e;
-                rc[u] = live[u] ? a.rec_all[s] : make_uint2(0, 0);
-            }
-            uint32_t k[2];
-            uint2 tw[2];
-            double p00[2], p01[2], p11[2], fo[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc[u].y);
-                p00[u] = L[0];
-                p01[u] = L[1];
-                p11[u] = L[2];
-                k[u] = FULL && live[u] ? a.alt_count[rc[u].x] : 0u;
-                if (a.t32) {
-                    // the target's alleles from the tile-transposed copy: one 8-byte word pair serves 32
-                    // consecutive rows (the site-major row costs two 64-byte sectors per row for two bits)
-                    const uint2 *p = reinterpret_cast<const uint2 *>(
-                        a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc[u].x >> 6)) * 64 + (tgt & 63));
-                    tw[u] = live[u] ? p[(rc[u].x >> 5) & 1] : make_uint2(0, 0);
-                } else {
-                    const uint64_t *row = a.panel + (size_t)rc[u].x * a.stride;
-                    const uint64_t r0 = live[u] ? row[2 * (tgt >> 6)] : 0, r1 = live[u] ? row[2 * (tgt >> 6) + 1] : 0;
-                    tw[u] = make_uint2((uint32_t)((r0 >> (tgt & 63)) & 1u) << (rc[u].x & 31),
-                                       (uint32_t)((r1 >> (tgt & 63)) & 1u) << (rc[u].x & 31));
-                }
-                fo[u] = FULL && a.fo && live[u] ? a.fo[3 * (base + 64 * u + lane)] : qnan;
-            }
-            double f[2], pw1[2], pw2[2];
-            if (FULL) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    f[u] = (double)k[u] / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
-                    pw1[u] = a.pow_tab[2 * k[u]];
-                    pw2[u] = a.pow_tab[2 * k[u] + 1];
-                    if (fo[u] == fo[u]) {          // not NaN: -A override (src/ibdgem.c:609-614)
-                        const size_t s = base + 64 * u + lane;
-                        f[u] = fo[u];
-                        pw1[u] = a.fo[3 * s + 1];
-                        pw2[u] = a.fo[3 * s + 2];
-                    }
-                }
-            }
-            // (the strip's previous turn has been read: a wave's LDS operations execute in order)
+        for (size_t off = 0; off < span; off += 128) {
+            // (the strips' previous turn has been read: a wave's LDS operations execute in order)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const size_t s = base + 64 * u + lane;
-                const unsigned A0 = (tw[u].x >> (rc[u].x & 31)) & 1u, A1 = (tw[u].y >> (rc[u].x & 31)) & 1u;
-                const unsigned g = A0 + A1;
-                const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
-                const bool covered = rc[u].y != 0;            // table offset 0 <=> no reads
-                double *o = buf + (64 * u + lane) * NV;
-                if (FULL) {
-                    const double omf = 1 - f[u];
-                    double ibd0 = 1.0;
-                    if (!(p00[u] == 1 || p01[u] == 1 || p11[u] == 1)) {
-                        const double t1 = pw1[u] * p00[u];
-                        const double t2 = ((2 * omf) * f[u]) * p01[u];
-                        const double t3 = pw2[u] * p11[u];
-                        ibd0 = (t1 + t2) + t3;
-                        if (ibd0 == 0.0)
-                            ibd0 = 2.2250738585072014e-308;      // DBL_MIN
-                    }
-                    double ibd1;
-                    if (g == 0)
-                        ibd1 = (f[u] * p01[u]) + (omf * p00[u]);
-                    else if (g == 1)
-                        ibd1 = ((0.5 * p01[u]) + ((0.5 * omf) * p00[u])) + ((0.5 * f[u]) * p11[u]);
-                    else
-                        ibd1 = (omf * p01[u]) + (f[u] * p11[u]);
-                    if (ibd1 == 0.0)
-                        ibd1 = 2.2250738585072014e-308;
-                    if (live[u]) {
-                        if (a.site_ll) {
-                            double *d = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
-                            d[0] = ibd0;
-                            d[1] = ibd1;
-                            d[2] = ibd2;
-                        }
-                    }
-                    o[0] = covered ? ibd0 : 1.0;
-                    o[1] = covered ? ibd1 : 1.0;
-                    o[2] = covered ? ibd2 : 1.0;
-                } else {
-                    o[0] = covered ? ibd2 : 1.0;
-                }
-            }
+            for (int q = 0; q < WPW; ++q)            // (a window that has run out of rows gets a strip of 1.0s)
+                rows_turn<FULL>(a, t, tgt, bd[q] + off, bd[q + 1], lane, strip[wave][q]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t n = (uint32_t)(e - base < 128 ? e - base : 128);
-            if (lane < NV) {
+            const uint32_t n = (uint32_t)(span - off < 128 ? span - off : 128);
+            if (lane < NV * WPW) {
+                const double *src = &strip[wave][cq][cc];
 #pragma unroll 8
                 for (uint32_t j = 0; j < n; ++j)
-                    acc *= buf[j * NV + lane];
+                    acc *= src[j * NV];
             }
         }
-        if (w < a.n_win && lane < NV) {
-            double *o = a.win_ll + ((size_t)t * a.n_win + w) * 3;
+        if (lane < NV * WPW && w0 + cq < a.n_win) {
+            double *o = a.win_ll + ((size_t)t * a.n_win + w0 + cq) * 3;
             if (!FULL)
                 o[2] = acc;
-            else if (!a.ld_mode || lane == 2)
-                o[lane] = acc;
+            else if (!a.ld_mode || cc == 2)
+                o[cc] = acc;
         }
     }
 }
@@ -487,7 +516,7 @@ void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, 
     if (a.n_sites == 0 || n_targets == 0)
         return;
     const uint32_t n_w = a.n_win ? a.n_win : 1;
-    size_t blocks = ((size_t)n_w + 3) / 4;
+    size_t blocks = (((size_t)n_w + IBDG_ROWS_WPW - 1) / IBDG_ROWS_WPW + 3) / 4;      // a wave per group of windows
     if (max_blocks && blocks > max_blocks)
         blocks = max_blocks;
     dim3 grid((unsigned)blocks, n_targets);

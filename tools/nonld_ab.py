@@ -39,3 +39,15 @@ for rnd in range(3):
             e.set_option("async", 0)
             k = float(np.mean([e.run_ms(i)["rows"] for i in range(16)]))
             print(f"{os.path.basename(path)} rows_blocks_per_cu={rb} site_results={res}: {ms:.4f} ms per step, kernel {k:.4f} ms", flush=True)
+
+# the builds' results against the first one's: every bit of the window table and of the per-row values
+ref = None
+for path, e in engs:
+    e.set_option("site_results", 1)
+    e.run([7], ld=False)
+    got = (e.window_ll(0).copy(), e.site_ll(0).copy())
+    if ref is None:
+        ref = got
+    else:
+        same = all(np.array_equal(x.view(np.uint64), y.view(np.uint64)) for x, y in zip(got, ref))
+        print(f"{os.path.basename(path)}: results bit-equal to {os.path.basename(engs[0][0])}: {same}")
