@@ -40,6 +40,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <errno.h>
 
 #include "../../include/ibdgem_hip.h"
 #include "ingest.h"
@@ -1075,49 +1076,169 @@ static void *fmt_rows(void *arg)
 
 /* Rounds of 2^18 rows (bounds the text held in memory); the team formats round k+1 into a second set of buffers
  * while this thread writes round k -- a third of the phase was the copy into the page cache with the team idle. */
+/* The rows in chunks of 2^14 (1.3 MB of text): a team of threads takes chunk numbers from a counter and formats each into
+ * one of a ring of buffers; the calling thread writes the chunks in order as they become ready and hands the buffers back.
+ * The team is started once per table and the writer never formats: putting ready text into the file (6 GB/s from one
+ * thread, tools/write_floor.c) is the longer of the two jobs once sixteen threads format, so nothing may hold it up.
+ * (Until round 3 a team was started per 2^18 rows and the caller wrote one round's text while the next was formatted.) */
+typedef struct {
+    fmt_job proto;
+    size_t n, chunk_rows, n_chunks;
+    int ring;                      /* buffers (a chunk uses buffer chunk % ring) */
+    fmt_job *slot;                 /* [ring] */
+    int *state;                    /* [ring]: 0 free, 1 being formatted, 2 ready */
+    size_t next_chunk;             /* the next chunk a formatter takes */
+    int failed;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_ready, cv_free;
+} row_pipe;
+
+static void *row_pipe_worker(void *arg)
+{
+    row_pipe *P = arg;
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        size_t c;
+        int b;
+        for (;;) {
+            c = P->next_chunk;
+            if (c >= P->n_chunks || P->failed) {
+                pthread_mutex_unlock(&P->mu);
+                return NULL;
+            }
+            b = (int)(c % (size_t)P->ring);
+            if (P->state[b] == 0)
+                break;
+            pthread_cond_wait(&P->cv_free, &P->mu);      /* the buffer's previous chunk is not written yet */
+        }
+        P->next_chunk = c + 1;
+        P->state[b] = 1;
+        pthread_mutex_unlock(&P->mu);
+        fmt_job *j = &P->slot[b];
+        j->a = c * P->chunk_rows;
+        j->b = j->a + P->chunk_rows < P->n ? j->a + P->chunk_rows : P->n;
+        j->len = 0;
+        fmt_rows(j);
+        pthread_mutex_lock(&P->mu);
+        if (j->failed)
+            P->failed = 1;
+        P->state[b] = 2;
+        pthread_cond_broadcast(&P->cv_ready);
+        if (P->failed)
+            pthread_cond_broadcast(&P->cv_free);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+/* format and write in turns (small tables, one thread, no thread to be had) */
+static int write_rows_serial(FILE *tab, fmt_job proto, size_t n)
+{
+    fmt_job j = proto;
+    j.buf = NULL;
+    j.cap = 0;
+    int rc = 0;
+    for (size_t a = 0; a < n && !rc; a += 65536) {
+        j.a = a;
+        j.b = a + 65536 < n ? a + 65536 : n;
+        j.len = 0;
+        fmt_rows(&j);
+        if (j.failed || fwrite(j.buf, 1, j.len, tab) != j.len)
+            rc = 1;
+    }
+    free(j.buf);
+    return rc;
+}
+
 static int write_rows_parallel(FILE *tab, fmt_job proto, size_t n, int threads)
 {
-    const size_t batch = (size_t)1 << 18;
-    static fmt_job jobs[2][64];
-    pthread_t tid[64];
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
-    for (int k = 0; k < 2; ++k)
-        for (int t = 0; t < threads; ++t) {
-            jobs[k][t] = proto;
-            jobs[k][t].buf = NULL;
-            jobs[k][t].cap = 0;
-        }
-    int rc = 0, prev_team = 0, cur = 0;
-    for (size_t r0 = 0; (r0 < n || prev_team) && !rc; r0 += batch, cur ^= 1) {
-        int team = 0, started[64] = {0};
-        if (r0 < n) {
-            const size_t r1 = r0 + batch < n ? r0 + batch : n, m = r1 - r0;
-            team = m < 4096 ? 1 : threads;
-            for (int t = 0; t < team; ++t) {
-                jobs[cur][t].a = r0 + m * (size_t)t / (size_t)team;
-                jobs[cur][t].b = r0 + m * (size_t)(t + 1) / (size_t)team;
-                jobs[cur][t].len = 0;
-                started[t] = team > 1 && pthread_create(&tid[t], NULL, fmt_rows, &jobs[cur][t]) == 0;
-            }
-        }
-        /* the previous round's text goes out while the team works */
-        for (int t = 0; t < prev_team; ++t) {
-            fmt_job *j = &jobs[cur ^ 1][t];
-            if (j->failed || fwrite(j->buf, 1, j->len, tab) != j->len)
-                rc = 1;
-        }
-        for (int t = 0; t < team; ++t) {
-            if (started[t])
-                pthread_join(tid[t], NULL);
-            else
-                fmt_rows(&jobs[cur][t]);
-        }
-        prev_team = team;
+    /* (IBDGEM_MT_MIN_BYTES in the environment, the tests' switch for the threaded readers, also sends small tables through
+     * the pipeline: chunks of 37 rows and a ring short enough that formatters wait for the writer) */
+    const int tiny = ls_mt_min_bytes() < 4096;
+    if (threads == 1 || (n < 8192 && !tiny))
+        return write_rows_serial(tab, proto, n);
+    row_pipe P;
+    memset(&P, 0, sizeof P);
+    P.proto = proto;
+    P.n = n;
+    P.chunk_rows = tiny ? 37 : 16384;
+    P.n_chunks = (n + P.chunk_rows - 1) / P.chunk_rows;
+    P.ring = tiny ? threads + 1 : 3 * threads;
+    P.slot = calloc((size_t)P.ring, sizeof *P.slot);
+    P.state = calloc((size_t)P.ring, sizeof *P.state);
+    if (!P.slot || !P.state) {
+        free(P.slot);
+        free(P.state);
+        return 1;
     }
-    for (int k = 0; k < 2; ++k)
-        for (int t = 0; t < threads; ++t)
-            free(jobs[k][t].buf);
+    for (int b = 0; b < P.ring; ++b) {
+        P.slot[b] = proto;
+        P.slot[b].buf = NULL;
+        P.slot[b].cap = 0;
+    }
+    pthread_mutex_init(&P.mu, NULL);
+    pthread_cond_init(&P.cv_ready, NULL);
+    pthread_cond_init(&P.cv_free, NULL);
+    pthread_t tid[64];
+    int n_started = 0;
+    for (int t = 0; t < threads; ++t)
+        if (pthread_create(&tid[n_started], NULL, row_pipe_worker, &P) == 0)
+            ++n_started;
+    int rc = 0;
+    if (n_started == 0) {
+        free(P.slot);
+        free(P.state);
+        pthread_mutex_destroy(&P.mu);
+        pthread_cond_destroy(&P.cv_ready);
+        pthread_cond_destroy(&P.cv_free);
+        return write_rows_serial(tab, proto, n);
+    }
+    if (fflush(tab) != 0)
+        rc = 1;
+    const int fd = fileno(tab);
+    for (size_t c = 0; c < P.n_chunks && !rc; ++c) {
+        const int b = (int)(c % (size_t)P.ring);
+        pthread_mutex_lock(&P.mu);
+        while (P.state[b] != 2 && !P.failed)
+            pthread_cond_wait(&P.cv_ready, &P.mu);
+        const int bad = P.failed || P.state[b] != 2;
+        pthread_mutex_unlock(&P.mu);
+        if (bad) {
+            rc = 1;
+            break;
+        }
+        const fmt_job *j = &P.slot[b];
+        for (size_t off = 0; off < j->len;) {        /* straight to the descriptor: stdio would copy 1.3 MB through its buffer */
+            const ssize_t w = write(fd, j->buf + off, j->len - off);
+            if (w < 0) {
+                if (errno == EINTR)
+                    continue;
+                rc = 1;
+                break;
+            }
+            off += (size_t)w;
+        }
+        pthread_mutex_lock(&P.mu);
+        P.state[b] = 0;
+        pthread_cond_broadcast(&P.cv_free);
+        pthread_mutex_unlock(&P.mu);
+    }
+    if (rc) {
+        pthread_mutex_lock(&P.mu);
+        P.failed = 1;
+        pthread_cond_broadcast(&P.cv_free);
+        pthread_mutex_unlock(&P.mu);
+    }
+    for (int t = 0; t < n_started; ++t)
+        pthread_join(tid[t], NULL);
+    for (int b = 0; b < P.ring; ++b)
+        free(P.slot[b].buf);
+    free(P.slot);
+    free(P.state);
+    pthread_mutex_destroy(&P.mu);
+    pthread_cond_destroy(&P.cv_ready);
+    pthread_cond_destroy(&P.cv_free);
     return rc;
 }
 
