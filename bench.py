@@ -836,7 +836,7 @@ def main():
                   "hbm_frac": nl_bytes * n_rows / (nl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "kernel_hbm_frac": nl_bytes * n_rows / (nl_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "note": "non-LD comparison (per-row LIBD0/1/2 + window products, BASELINE.json configs[1] at this row count), "
-                          "queued steps, host wall clock; one kernel (k_rows_windows: a wave per window computes its rows' "
+                          "queued steps, host wall clock; one kernel (k_rows_windows: a wave per pair of windows computes their rows' "
                           "values, stores them and multiplies them up -- nothing is read back; the AF column is made by "
                           "ibdg_get_site_af when asked for, not by the run); hbm_frac on the step clock, kernel_hbm_frac on "
                           "the kernel's own events"}

@@ -138,7 +138,7 @@ struct ibdg_ctx {
                                     // gives the dominant kernel's own duration, but costs ~10 us per run more than
                                     // one event record (measured), so it is off unless asked for
     long opt_async = 0;    // 1: ibdg_run returns once its kernels are queued
-    long opt_rows_blocks = 0;   // non-LD run: workgroups of k_rows_windows per CU (resident grid, each wave takes several windows); 0 = one wave per window
+    long opt_rows_blocks = 0;   // non-LD run: workgroups of k_rows_windows per CU (resident grid, each wave takes several windows); 0 = one wave per pair of windows
     long opt_dev_inputs_ready = 0;   // 1: ibdg_upload_sites_dev trusts the caller that its arrays are complete (no device-wide wait)
     long opt_cpw = 0;      // 0 = auto
     long opt_waves = 8;
@@ -1514,7 +1514,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
     if (rows_on_main) {
         if (join_streams(c)) return 1;           // an earlier run's kernel on stream2 may still write the results
-        // alone on the chip: a wave per window (the default).  A resident grid whose waves walk over several windows -- even
+        // alone on the chip: a wave per pair of windows (the default).  A resident grid whose waves walk over several windows -- even
         // with the next window's records kept in flight -- measured slower at every size (rows_blocks_per_cu 4..28:
         // 0.048-0.041 ms against 0.040)
         unsigned blocks = 0;

@@ -250,7 +250,7 @@ void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t w
 // chip); a small number (e.g. 8 per CU) when it runs beside a kernel that should keep most of the slots
 void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t *alt_count,
                       hipStream_t st, unsigned max_blocks = 0);
-// max_blocks: 0 = a wave per window (four per workgroup); otherwise at most that many workgroups per target, which
+// max_blocks: 0 = a wave per pair of consecutive windows (four waves per workgroup); otherwise at most that many workgroups per target, which
 // walk the windows grid-stride (few long-lived waves: for running beside the --LD kernel)
 void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
 // af[s] of every site (k_site_af)

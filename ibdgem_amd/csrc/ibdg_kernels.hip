@@ -109,12 +109,12 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 // pow(1-f,2.0) and pow(f,2.0) come from pow_tab (indexed by alt count) or, with an -A override, from
 // the per-site fo array {f, pow(1-f,2), pow(f,2)}.
 //
-// A wave per (window, comparison individual): its lanes take the rows from the window's first covered
+// A wave per (two consecutive windows, comparison individual): for each window its lanes take the rows from the window's first covered
 // row up to the next window's (rows without reads in between are printed but join no window,
 // src/ibdgem.c:657-663; the rows before the first window go with window 0, those behind the last one
 // with it), 128 rows per turn with all their gathers in flight, compute the row's three values, store
 // them when per-site results are wanted, and leave the factors -- 1.0 for a row without reads: x * 1.0
-// is x -- in the wave's LDS strip, where three lanes multiply them up in row order.  The per-site triple
+// is x -- in the window's LDS strip of the wave, where three lanes per window multiply them up in row order (six side by side).  The per-site triple
 // is never read back (a separate product kernel re-read 24 B per row), and a run that wants window
 // results only (FULL = false in --LD mode: the host program's --summary-only) computes just the IBD2
 // pick of every row: one table look-up, nothing stored.
