@@ -207,7 +207,9 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * them); "dev_inputs_ready" (0/1: ibdg_upload_sites_dev does not wait for the whole device first, see there);
  * "count_in_run" (0/1: recompute alt counts inside every ibdg_run,
  * so the timed region covers it; beside the --LD kernel the recount runs with "recount_blocks_per_cu"
- * single-wave workgroups per CU, default 4, 0 = its full grid); "site_results" (what ibdg_run keeps per row: 1, the default,
+ * single-wave workgroups per CU, default 4, 0 = its full grid); "site_blocks_per_cu" (default 4: workgroups per CU of the
+ * per-row kernel beside the exponent-counting --LD kernel, 0 = its full grid) and "rows_blocks_per_cu" (default 0 = full
+ * grid: the same for a non-LD run, where it has the chip to itself); "site_results" (what ibdg_run keeps per row: 1, the default,
  * LIBD0/1/2 of every row and comparison individual for ibdg_get_site_ll; 0 nothing -- no n_targets x n_sites x 24 bytes
  * of device memory, no per-row stores, and in --LD mode only the IBD2 pick of a row is computed at all: for callers that
  * want the window table only, e.g. hundreds of comparison individuals in one call; ibdg_get_site_ll then fails.  The AF
