@@ -442,25 +442,26 @@ def write_panel_cache(path, words_all, n_ids, st):
 ALL_RUNS = {}            # every wall clock behind a best-of figure of the host-program legs, by output directory
 
 
-def timed_run(cmd, cwd, repeat=3):
+def timed_run(cmd, cwd, repeat=3, env=None):
     """Best of `repeat` runs (the first run of the host program after this process's own GPU work is regularly
     0.3 s slower than the ones after it; all times are kept in ALL_RUNS)."""
     times = []
     for _ in range(repeat):
         t0 = time.perf_counter()
-        subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, **env) if env else None)
         times.append(time.perf_counter() - t0)
     ALL_RUNS[cmd[cmd.index("-O") + 1] if "-O" in cmd else str(len(ALL_RUNS))] = times
     return min(times)
 
 
-def run_phases(cmd, cwd):
+def run_phases(cmd, cwd, env=None):
     """One more run with IBDGEM_TIMING=1: the host program's own wall clock per phase (summed per name), the wall
     clock of that run as its parent sees it, and what the phases do not cover (the end of the process: the driver
     taking the device memory and the mappings back)."""
     t0 = time.perf_counter()
     r = subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
-                       env=dict(os.environ, IBDGEM_TIMING="1"))
+                       env=dict(os.environ, IBDGEM_TIMING="1", **(env or {})))
     wall = time.perf_counter() - t0
     out = {}
     for line in r.stderr.splitlines():
@@ -535,6 +536,22 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
                                                                  ph_many.get("per individual: output files", 0.0)) / 30,
                                     "wall_clock_difference_per_individual_s": (t_many - t_sum) / 29,
                                     "phases_s": ph_many}
+        # eight individuals WITH their per-site tables (the default run): 8 x 330 MB of text.  The files of up to three
+        # individuals are written beside the main thread's work on the ones after them; IBDGEM_OUT_SLOTS=1 is one at a time.
+        eight = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(8))
+        ebase = [a if a != f"ind{target}" else eight for a in base]
+        os.makedirs(os.path.join(d, "o6"))
+        per = {}
+        for label, env in (("side_by_side", None), ("one_at_a_time", {"IBDGEM_OUT_SLOTS": "1"})):
+            t8 = timed_run(ebase + ["-O", "o6"], d, repeat=2, env=env)
+            ph8 = run_phases(ebase + ["-O", "o6"], d, env=env)
+            own = sum(v for k, v in ph8.items() if k.startswith("per individual: engine") or k.startswith("per individual: output")
+                      or k.startswith("output files of the last"))
+            per[label] = {"s": t8, "s_per_individual_from_phases": own / 8, "phases_s": ph8}
+        warm["eight_individuals_with_tables"] = dict(per, table_bytes_each=warm["per_site_table_bytes"],
+                                                     note="default run (tables written) of 8 comparison individuals in one batch")
+        for fn in os.listdir(os.path.join(d, "o6")):
+            os.remove(os.path.join(d, "o6", fn))
         for fn in ("p.cache",):
             os.remove(os.path.join(d, fn))
         # ---- cold: text .hap of the first cold_rows rows

@@ -1673,6 +1673,119 @@ static void *dev_start(void *arg)
         quit(1);                          \
     } while (0)
 
+
+/* ---- the two output files of one comparison individual (src/ibdgem.c:144-152, :547-548, :731-733, :751-768) ---------
+ * Everything the files are made of, so that they can be written while the next individual is on the device: with the
+ * site list shared by all individuals (no -v, no -D) a default run of many of them is bound by its 330 MB tables, and
+ * tables of different individuals go into different files, which take writers side by side (tools/write_floor.c: one
+ * file 3-6 GB/s whatever the number of writers, eight files 22-32 GB/s). */
+typedef struct {
+    /* shared with every other individual of the run (read only while a job runs) */
+    const char *out_dir, *user_cmd;
+    const unsigned long *in_dist;
+    double mean_cov, cull_p;
+    const cand_t *cand;
+    const uint32_t *s_cand, *s_row;
+    const uint8_t *s_nr, *s_na;
+    const pileup_t *pu;
+    /* this individual */
+    const char *tname;
+    uint32_t tgt;
+    size_t n, n_win;
+    unsigned long processed, skipped, final_total, final_dist[128];
+    const double *site_ll;                      /* per-row values (NULL with --summary-only) */
+    uint32_t *w_first, *w_last, *w_ncov;        /* owned: freed when the files are closed */
+    double *win_ll;
+    int threads;
+    /* when it runs beside the main thread */
+    pthread_t th;
+    int running, failed;
+} out_job;
+
+static void *output_individual(void *arg)
+{
+    out_job *o = arg;
+    o->failed = 1;
+    FILE *tab, *sum;
+    if (opt_plan) {
+        tab = stdout;
+        sum = stdout;
+        printf("## PLAN %s %s processed=%lu skipped=%lu windows=%zu cull_p=%f\n", opt_sq, o->tname, o->processed, o->skipped,
+               o->n_win, o->cull_p);
+    } else {
+        char *tab_fn, *sum_fn;
+        if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", o->out_dir, opt_sq, o->tname) < 0 ||
+            asprintf(&sum_fn, "%s/%s.%s.summary.txt", o->out_dir, opt_sq, o->tname) < 0)
+            return NULL;
+        tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
+        sum = fopen(sum_fn, "w");
+        if (!tab || !sum) {
+            fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
+            return NULL;
+        }
+        free(tab_fn);
+        free(sum_fn);
+        fprintf(tab, "# Entered command: %s\n\n", o->user_cmd);
+    }
+    /* header block (:144-152, :547-548) */
+    fprintf(tab, "# INPUT COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
+    for (unsigned c = 0; c <= opt_max_cov; ++c)
+        fprintf(tab, "# %d %lu\n", c, o->in_dist[c]);
+    fprintf(tab, "# MEAN DEPTH = %lf\n# CULL DEPTH RATIO = %lf\n", o->mean_cov, o->cull_p);
+    fprintf(tab, "# CHR\trsID\tPOS\tREF\tALT\tAF\tDP\tSQ_NREF\tSQ_NALT\tGT_A0\tGT_A1\tLIBD0\tLIBD1\tLIBD2\n");
+    if (!opt_plan)
+        fprintf(sum, "# SEGMENT\tSTART\tEND\tLIBD0\tLIBD1\tLIBD2\tNUM_SITES\n");
+    if (!opt_summary_only) {
+        fmt_job proto;
+        memset(&proto, 0, sizeof proto);
+        proto.cand = o->cand;
+        proto.s_cand = o->s_cand;
+        proto.pu = o->pu;
+        proto.site_ll = o->site_ll;
+        proto.s_nr = o->s_nr;
+        proto.s_na = o->s_na;
+        proto.tgt = o->tgt;
+        proto.plan = opt_plan;
+        if (write_rows_parallel(tab, proto, o->n, o->threads)) {
+            fprintf(stderr, "[::] ERROR writing the per-site rows of %s.\n", o->tname);
+            return NULL;
+        }
+    }
+    if (opt_plan) {
+        for (size_t w = 0; w < o->n_win; ++w)
+            printf("## WINDOW %zu\t%lu\t%lu\t%u\n", w + 1, rows[o->s_row[o->w_first[w]]].pos, rows[o->s_row[o->w_last[w]]].pos,
+                   o->w_ncov[w]);
+    } else {
+        /* the summary rows (:751-756) through the program's own conversions, by the team of threads: with many
+         * comparison individuals per run the seven stdio calls per window were the longest item of an individual
+         * (25 ms of 33 at 35 000 windows) */
+        sum_job sj;
+        memset(&sj, 0, sizeof sj);
+        sj.s_row = o->s_row; sj.w_first = o->w_first; sj.w_last = o->w_last; sj.w_ncov = o->w_ncov; sj.win_ll = o->win_ll;
+        if (write_summary_parallel(sum, sj, o->n_win, o->threads)) {
+            fprintf(stderr, "[::] ERROR writing the summary rows of %s.\n", o->tname);
+            return NULL;
+        }
+    }
+    /* footer (:761-768) */
+    fprintf(tab, "# FINAL COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
+    for (unsigned c = 0; c <= opt_max_cov; ++c)
+        fprintf(tab, "# %d %lu\n", c, o->final_dist[c]);
+    fprintf(tab, "# FINAL MEAN DEPTH = %lf\n", (double)o->final_total / o->processed);
+    fprintf(tab, "## Number of sites processed: %lu\n", o->processed);
+    fprintf(tab, "## Number of sites skipped: %lu\n", o->skipped);
+    int bad = 0;
+    if (!opt_plan) {
+        bad |= fclose(tab) != 0;
+        bad |= fclose(sum) != 0;
+    }
+    free(o->w_first); free(o->w_last); free(o->w_ncov); free(o->win_ll);
+    o->w_first = o->w_last = o->w_ncov = NULL;
+    o->win_ll = NULL;
+    o->failed = bad;
+    return NULL;
+}
+
 int main(int argc, char **argv)
 {
     const clock_t t_start = clock();
@@ -1947,8 +2060,33 @@ int main(int argc, char **argv)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("result arrays");
     uint32_t *s_row_dev = NULL;     /* slice_mode: the site list's rows counted from each device's first row */
+    /* The files of up to OUT_SLOTS individuals are written beside the main thread's work on the ones after them, each from
+     * a per-row array of its own -- when the site list is the same for all of them (it is read by the writers), the rows go
+     * to files (stdout keeps its order) and there is a table to write at all. */
+    enum { OUT_SLOTS = 3 };
+    static out_job outs[OUT_SLOTS];
+    const int overlap = !has_v && cull_p == 1.0 && !opt_plan && !opt_summary_only && targets.n > 1;
+    double *site_slot[OUT_SLOTS] = {site_ll, NULL, NULL};
+    int out_slots = OUT_SLOTS;                  /* (IBDGEM_OUT_SLOTS=1..3: fewer of them, for the tests and for measurements) */
+    if (getenv("IBDGEM_OUT_SLOTS") && atoi(getenv("IBDGEM_OUT_SLOTS")) >= 1 && atoi(getenv("IBDGEM_OUT_SLOTS")) < OUT_SLOTS)
+        out_slots = atoi(getenv("IBDGEM_OUT_SLOTS"));
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
+        if (overlap) {
+            out_job *prev = &outs[ti % (size_t)out_slots]; /* the slot's previous individual: its files must be closed */
+            if (prev->running) {
+                pthread_join(prev->th, NULL);
+                prev->running = 0;
+                if (prev->failed)
+                    quit(1);
+            }
+            if (!site_slot[ti % (size_t)out_slots]) {
+                site_slot[ti % (size_t)out_slots] = io_alloc(n_site_out * 24, pin);
+                if (!site_slot[ti % (size_t)out_slots])
+                    DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
+            }
+            site_ll = site_slot[ti % (size_t)out_slots];
+        }
         const char *tname = ids.names[tgt];
         fprintf(stderr, "Running %s-vs-%s comparison...\n", opt_sq, tname);
         /* Without -v and -D the site list does not depend on the comparison individual (:584, :627-628): it is
@@ -2105,81 +2243,34 @@ int main(int argc, char **argv)
         }
 
         phase("per individual: engine (upload, run, results)");
-        FILE *tab, *sum;
-        if (opt_plan) {
-            tab = stdout;
-            sum = stdout;
-            printf("## PLAN %s %s processed=%lu skipped=%lu windows=%zu cull_p=%f\n", opt_sq, tname, processed, skipped,
-                   n_win, cull_p);
-        } else {
-            char *tab_fn, *sum_fn;
-            if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
-                asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
+        out_job *o = &outs[overlap ? ti % (size_t)out_slots : 0];
+        o->out_dir = out_dir; o->user_cmd = user_cmd; o->in_dist = in_dist; o->mean_cov = mean_cov; o->cull_p = cull_p;
+        o->cand = cand; o->s_cand = s_cand; o->s_row = s_row; o->s_nr = s_nr; o->s_na = s_na; o->pu = pu;
+        o->tname = tname; o->tgt = tgt; o->n = n; o->n_win = n_win;
+        o->processed = processed; o->skipped = skipped; o->final_total = final_total;
+        memcpy(o->final_dist, final_dist, sizeof o->final_dist);
+        o->site_ll = site_ll;
+        o->w_first = w_first; o->w_last = w_last; o->w_ncov = w_ncov; o->win_ll = win_ll;
+        const int all_threads = opt_threads > 0 ? opt_threads : default_threads();
+        o->threads = overlap && all_threads > 3 ? all_threads / 2 : all_threads;
+        o->running = overlap && pthread_create(&o->th, NULL, output_individual, o) == 0;
+        if (!o->running) {
+            output_individual(o);
+            if (o->failed)
                 quit(1);
-            tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
-            sum = fopen(sum_fn, "w");
-            if (!tab || !sum) {
-                fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
-                quit(1);
-            }
-            free(tab_fn);
-            free(sum_fn);
-            fprintf(tab, "# Entered command: %s\n\n", user_cmd);
         }
-        /* header block (:144-152, :547-548) */
-        fprintf(tab, "# INPUT COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
-        for (unsigned c = 0; c <= opt_max_cov; ++c)
-            fprintf(tab, "# %d %lu\n", c, in_dist[c]);
-        fprintf(tab, "# MEAN DEPTH = %lf\n# CULL DEPTH RATIO = %lf\n", mean_cov, cull_p);
-        fprintf(tab, "# CHR\trsID\tPOS\tREF\tALT\tAF\tDP\tSQ_NREF\tSQ_NALT\tGT_A0\tGT_A1\tLIBD0\tLIBD1\tLIBD2\n");
-        if (!opt_plan)
-            fprintf(sum, "# SEGMENT\tSTART\tEND\tLIBD0\tLIBD1\tLIBD2\tNUM_SITES\n");
-        if (!opt_summary_only) {
-            fmt_job proto;
-            memset(&proto, 0, sizeof proto);
-            proto.cand = cand;
-            proto.s_cand = s_cand;
-            proto.pu = pu;
-            proto.site_ll = site_ll;
-            proto.s_nr = s_nr;
-            proto.s_na = s_na;
-            proto.tgt = tgt;
-            proto.plan = opt_plan;
-            if (write_rows_parallel(tab, proto, n, opt_threads > 0 ? opt_threads : default_threads())) {
-                fprintf(stderr, "[::] ERROR writing the per-site rows of %s.\n", tname);
-                quit(1);
-            }
-        }
-        if (opt_plan) {
-            for (size_t w = 0; w < n_win; ++w)
-                printf("## WINDOW %zu\t%lu\t%lu\t%u\n", w + 1, rows[s_row[w_first[w]]].pos, rows[s_row[w_last[w]]].pos,
-                       w_ncov[w]);
-        } else {
-            /* the summary rows (:751-756) through the program's own conversions, by the team of threads: with many
-             * comparison individuals per run the seven stdio calls per window were the longest item of an individual
-             * (25 ms of 33 at 35 000 windows) */
-            sum_job sj;
-            memset(&sj, 0, sizeof sj);
-            sj.s_row = s_row; sj.w_first = w_first; sj.w_last = w_last; sj.w_ncov = w_ncov; sj.win_ll = win_ll;
-            if (write_summary_parallel(sum, sj, n_win, opt_threads > 0 ? opt_threads : default_threads())) {
-                fprintf(stderr, "[::] ERROR writing the summary rows of %s.\n", tname);
-                quit(1);
-            }
-        }
-        /* footer (:761-768) */
-        fprintf(tab, "# FINAL COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
-        for (unsigned c = 0; c <= opt_max_cov; ++c)
-            fprintf(tab, "# %d %lu\n", c, final_dist[c]);
-        fprintf(tab, "# FINAL MEAN DEPTH = %lf\n", (double)final_total / processed);
-        fprintf(tab, "## Number of sites processed: %lu\n", processed);
-        fprintf(tab, "## Number of sites skipped: %lu\n", skipped);
-        if (!opt_plan) {
-            fclose(tab);
-            fclose(sum);
-        }
-        free(w_first); free(w_last); free(w_ncov); free(win_ll);
         phase("per individual: output files");
     }
+    for (int k = 0; k < OUT_SLOTS; ++k) {
+        if (outs[k].running) {
+            pthread_join(outs[k].th, NULL);
+            outs[k].running = 0;
+            if (outs[k].failed)
+                quit(1);
+        }
+    }
+    if (overlap)
+        phase("output files of the last individuals (written beside the engine's work on the ones after them)");
 #if !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
     if (!getenv("IBDGEM_KEEP_TEARDOWN")) {
         /* every output file is closed: leave without tearing the device contexts and the runtime down -- the driver

@@ -49,3 +49,50 @@ def test_threaded_host_paths_are_race_free_under_tsan():
             assert "ThreadSanitizer" not in got.stderr, got.stderr[-2000:]
             assert got.returncode == want.returncode == 0
             assert got.stdout == want.stdout
+
+
+def test_output_files_of_several_individuals_written_side_by_side_under_tsan(tmp_path):
+    """The per-site tables of up to three comparison individuals are written beside the main thread's work on the ones
+    after them, each through the ordered formatter pipeline (IBDGEM_MT_MIN_BYTES=1: chunks of 37 rows, short ring):
+    no ThreadSanitizer report on the reference's own fixture (3 individuals, no device: non-LD) and on a synthetic case
+    with more of them, and the files are the golden ones."""
+    import golden_io as G
+    import gzip
+    subprocess.run(["make", "-C", os.path.join(REPO, "ibdgem_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", HOST, "ibdgem_tsan"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, IBDGEM_MT_MIN_BYTES="1", TSAN_OPTIONS="halt_on_error=1:exitcode=66", HIP_VISIBLE_DEVICES="",
+               ROCR_VISIBLE_DEVICES="", IBDGEM_KEEP_TEARDOWN="1")
+    fix_in = os.path.join(G.GOLD, "ibdgem-test", "input")
+    args = ["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "test1.pileup", "-N", "sample1", "--threads", "4",
+            "-O", str(tmp_path)]
+    for slots in ("3", "2", "1"):                    # fewer slots: an individual waits for the files of the one before it
+        got = subprocess.run([os.path.join(HOST, "ibdgem_tsan")] + args, cwd=fix_in, capture_output=True, text=True,
+                             env=dict(env, IBDGEM_OUT_SLOTS=slots))
+        assert "ThreadSanitizer" not in got.stderr, got.stderr[-2000:]
+        assert got.returncode == 0, got.stderr[-2000:]
+        for t in (1, 2, 3):
+            for kind in ("tab", "summary"):
+                fn = f"sample1.sample{t}.{kind}.txt"
+                a = open(tmp_path / fn).read().splitlines()
+                b = open(os.path.join(G.GOLD, "ibdgem-test", "output", fn)).read().splitlines()
+                assert a[1:] == b[1:], fn
+                os.remove(tmp_path / fn)
+    meta = G.cases("synA")
+    case = "nonld_all_targets_w2"
+    out2 = tmp_path / "syn"
+    out2.mkdir()
+    got = subprocess.run([os.path.join(HOST, "ibdgem_tsan")] + meta["base_args"] + meta["cases"][case] +
+                         ["--threads", "5", "-O", str(out2)], cwd=os.path.join(G.GOLD, "synA", "input"), capture_output=True,
+                         text=True, env=env)
+    assert "ThreadSanitizer" not in got.stderr, got.stderr[-2000:]
+    assert got.returncode == 0, got.stderr[-2000:]
+    ref = os.path.join(G.GOLD, "synA", case, "ref7")
+    n_tab = 0
+    for fn in sorted(os.listdir(ref)):
+        want = gzip.open(os.path.join(ref, fn), "rt").read().splitlines()
+        have = open(out2 / fn[:-3]).read().splitlines()
+        if fn.endswith(".tab.txt.gz"):
+            have = have[1:]
+            n_tab += 1
+        assert have == want, fn
+    assert n_tab >= 2
