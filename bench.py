@@ -546,7 +546,7 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
             t8 = timed_run(ebase + ["-O", "o6"], d, repeat=2, env=env)
             ph8 = run_phases(ebase + ["-O", "o6"], d, env=env)
             own = sum(v for k, v in ph8.items() if k.startswith("per individual: engine") or k.startswith("per individual: output")
-                      or k.startswith("output files of the last"))
+                      or k.startswith("per individual: waiting") or k.startswith("output files of the last"))
             per[label] = {"s": t8, "s_per_individual_from_phases": own / 8, "phases_s": ph8}
         warm["eight_individuals_with_tables"] = dict(per, table_bytes_each=warm["per_site_table_bytes"],
                                                      note="default run (tables written) of 8 comparison individuals in one batch")

@@ -2079,6 +2079,7 @@ int main(int argc, char **argv)
                 prev->running = 0;
                 if (prev->failed)
                     quit(1);
+                phase("per individual: waiting for the output files of an earlier individual");
             }
             if (!site_slot[ti % (size_t)out_slots]) {
                 site_slot[ti % (size_t)out_slots] = io_alloc(n_site_out * 24, pin);
