@@ -536,7 +536,7 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
                                                                  ph_many.get("per individual: output files", 0.0)) / 30,
                                     "wall_clock_difference_per_individual_s": (t_many - t_sum) / 29,
                                     "phases_s": ph_many}
-        # eight individuals WITH their per-site tables (the default run): 8 x 330 MB of text.  The files of up to three
+        # eight individuals WITH their per-site tables (the default run): 8 x 330 MB of text.  The files of up to four
         # individuals are written beside the main thread's work on the ones after them; IBDGEM_OUT_SLOTS=1 is one at a time.
         eight = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(8))
         ebase = [a if a != f"ind{target}" else eight for a in base]

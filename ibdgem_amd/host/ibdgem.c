@@ -2060,16 +2060,17 @@ int main(int argc, char **argv)
         DIE("[::] ERROR: out of memory for %zu rows.\n", n_cand);
     phase("result arrays");
     uint32_t *s_row_dev = NULL;     /* slice_mode: the site list's rows counted from each device's first row */
-    /* The files of up to OUT_SLOTS individuals are written beside the main thread's work on the ones after them, each from
+    /* The files of up to out_slots individuals are written beside the main thread's work on the ones after them, each from
      * a per-row array of its own -- when the site list is the same for all of them (it is read by the writers), the rows go
      * to files (stdout keeps its order) and there is a table to write at all. */
-    enum { OUT_SLOTS = 3 };
+    enum { OUT_SLOTS = 6 };
     static out_job outs[OUT_SLOTS];
     const int overlap = !has_v && cull_p == 1.0 && !opt_plan && !opt_summary_only && targets.n > 1;
-    double *site_slot[OUT_SLOTS] = {site_ll, NULL, NULL};
-    int out_slots = OUT_SLOTS;                  /* (IBDGEM_OUT_SLOTS=1..3: fewer of them, for the tests and for measurements) */
-    if (getenv("IBDGEM_OUT_SLOTS") && atoi(getenv("IBDGEM_OUT_SLOTS")) >= 1 && atoi(getenv("IBDGEM_OUT_SLOTS")) < OUT_SLOTS)
+    double *site_slot[OUT_SLOTS] = {site_ll};
+    int out_slots = 4;                  /* (IBDGEM_OUT_SLOTS=1..6, default 4: for the tests and for measurements) */
+    if (getenv("IBDGEM_OUT_SLOTS") && atoi(getenv("IBDGEM_OUT_SLOTS")) >= 1 && atoi(getenv("IBDGEM_OUT_SLOTS")) <= OUT_SLOTS)
         out_slots = atoi(getenv("IBDGEM_OUT_SLOTS"));
+    const int out_threads_env = getenv("IBDGEM_OUT_THREADS") ? atoi(getenv("IBDGEM_OUT_THREADS")) : 0;   /* (measurement switch) */
     for (size_t ti = 0; ti < targets.n; ++ti) {
         const uint32_t tgt = targets.idx[ti];
         if (overlap) {
@@ -2253,7 +2254,11 @@ int main(int argc, char **argv)
         o->site_ll = site_ll;
         o->w_first = w_first; o->w_last = w_last; o->w_ncov = w_ncov; o->win_ll = win_ll;
         const int all_threads = opt_threads > 0 ? opt_threads : default_threads();
-        o->threads = overlap && all_threads > 3 ? all_threads / 2 : all_threads;
+        /* (tools/many_tables.py: files of 1 / 2 / 3 / 4 / 6 individuals at once with 8 threads each 73* / 66 / 57 / 47 / 54 ms per
+         * individual, *16 threads; 4 x 4 threads 58, 3 x 16 threads 57) */
+        o->threads = overlap && out_slots > 1 && all_threads > 3 ? all_threads / 2 : all_threads;
+        if (overlap && out_threads_env > 0)
+            o->threads = out_threads_env;
         o->running = overlap && pthread_create(&o->th, NULL, output_individual, o) == 0;
         if (!o->running) {
             output_individual(o);

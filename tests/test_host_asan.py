@@ -52,7 +52,7 @@ def test_threaded_host_paths_are_race_free_under_tsan():
 
 
 def test_output_files_of_several_individuals_written_side_by_side_under_tsan(tmp_path):
-    """The per-site tables of up to three comparison individuals are written beside the main thread's work on the ones
+    """The per-site tables of up to four comparison individuals are written beside the main thread's work on the ones
     after them, each through the ordered formatter pipeline (IBDGEM_MT_MIN_BYTES=1: chunks of 37 rows, short ring):
     no ThreadSanitizer report on the reference's own fixture (3 individuals, no device: non-LD) and on a synthetic case
     with more of them, and the files are the golden ones."""
