@@ -639,9 +639,11 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-program clocks (warm_e2e, cold_e2e)")
     ap.add_argument("--no-many", action="store_true", help="skip the run over many comparison individuals")
     ap.add_argument("--many-targets", type=int, default=60, help="comparison individuals of that run (configs[4] shape)")
-    ap.add_argument("--prewarm-ms", type=float, default=80.0,
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps before the warm-up steps until this much wall time has passed: the chip's clocks take "
-                         "~30 ms of load to settle, more than a short --warmup at a fraction of a millisecond per step provides")
+                         "tens of ms of load to settle, more than a short --warmup at a fraction of a millisecond per step "
+                         "provides (80 ms until round 3: --steps 20 --warmup 5 then gave 4.08 / 4.26 / 4.46e9 in three fresh "
+                         "processes on one box, 4.41 / 4.47 with 300 ms, 4.44 with 600; profiles/r03_prewarm.txt)")
     ap.add_argument("--timed-only", action="store_true",
                     help="warm-up and timed steps only (no recount / engine-clock / upload / host legs): the command to put under "
                          "rocprofv3 --kernel-trace --stats, so that the per-kernel averages are those of the timed steps")
