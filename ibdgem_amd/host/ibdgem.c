@@ -1016,6 +1016,9 @@ typedef struct {
     const uint8_t *s_nr, *s_na;
     unsigned tgt;
     int plan;
+    /* columns 1-9 of every row as text, when somebody made them once for all comparison individuals (row_prefix_build) */
+    const char *pre;
+    const uint32_t *pre_off;       /* [n + 1] */
     /* this thread's rows and its text */
     size_t a, b;
     char *buf;
@@ -1023,19 +1026,39 @@ typedef struct {
     int failed;
 } fmt_job;
 
+/* columns 1-9 of a row, "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t" (src/ibdgem.c:731-733): none of them depends on the
+ * comparison individual */
+static char *put_row_prefix(char *d, const pileup_t *pu, const cand_t *c, unsigned nr, unsigned na)
+{
+    const row_t *R = &rows[c->row];
+    const pu_line *pl = &pu->lines[c->pu];
+    d = put_str(d, pu->chr_names[pl->chr]); *d++ = '\t';
+    d = put_str(d, arena + R->id_off); *d++ = '\t';
+    d = put_u64(d, R->pos); *d++ = '\t';
+    d = put_str(d, arena + R->ref_off); *d++ = '\t';
+    d = put_str(d, arena + R->alt_off); *d++ = '\t';
+    d = put_lf6(d, c->f); *d++ = '\t';          /* alt count / (2 N) or the -A value: the division the engine makes too */
+    d = put_u64(d, pl->cov); *d++ = '\t';
+    d = put_u64(d, nr); *d++ = '\t';
+    d = put_u64(d, na); *d++ = '\t';
+    return d;
+}
+
+static size_t row_prefix_room(const pileup_t *pu, const cand_t *c)
+{
+    const row_t *R = &rows[c->row];
+    /* strings + 3 x %lu/%lf (<= 330 chars for the largest double) + 5 x %u + 3 x %e + separators */
+    return strlen(pu->chr_names[pu->lines[c->pu].chr]) + strlen(arena + R->id_off) + strlen(arena + R->ref_off) +
+           strlen(arena + R->alt_off) + 512;
+}
+
 static void *fmt_rows(void *arg)
 {
     fmt_job *j = arg;
     j->failed = 0;
     for (size_t i = j->a; i < j->b; ++i) {
         const cand_t *c = &j->cand[j->s_cand[i]];
-        const row_t *R = &rows[c->row];
-        const pu_line *pl = &j->pu->lines[c->pu];
-        const double f = c->f;           /* alt count / (2 N) or the -A value: the division the engine makes too */
-        const char *chr = j->pu->chr_names[pl->chr], *id = arena + R->id_off, *ref = arena + R->ref_off,
-                   *alt = arena + R->alt_off;
-        /* strings + 3 x %lu/%lf (<= 330 chars for the largest double) + 5 x %u + 3 x %e + separators */
-        const size_t room = strlen(chr) + strlen(id) + strlen(ref) + strlen(alt) + 512;
+        const size_t room = j->pre ? (size_t)(j->pre_off[i + 1] - j->pre_off[i]) + 128 : row_prefix_room(j->pu, c);
         if (j->len + room > j->cap) {
             size_t nc = j->cap ? j->cap * 2 : ((size_t)1 << 20);
             while (j->len + room > nc)
@@ -1050,15 +1073,13 @@ static void *fmt_rows(void *arg)
         }
         char *d = j->buf + j->len;
         /* "%s\t%s\t%lu\t%s\t%s\t%lf\t%u\t%u\t%u\t%u\t%u" (src/ibdgem.c:731-733) */
-        d = put_str(d, chr); *d++ = '\t';
-        d = put_str(d, id); *d++ = '\t';
-        d = put_u64(d, R->pos); *d++ = '\t';
-        d = put_str(d, ref); *d++ = '\t';
-        d = put_str(d, alt); *d++ = '\t';
-        d = put_lf6(d, f); *d++ = '\t';
-        d = put_u64(d, pl->cov); *d++ = '\t';
-        d = put_u64(d, j->s_nr[i]); *d++ = '\t';
-        d = put_u64(d, j->s_na[i]); *d++ = '\t';
+        if (j->pre) {
+            const size_t len = j->pre_off[i + 1] - j->pre_off[i];
+            memcpy(d, j->pre + j->pre_off[i], len);
+            d += len;
+        } else {
+            d = put_row_prefix(d, j->pu, c, j->s_nr[i], j->s_na[i]);
+        }
         d = put_u64(d, row_allele(c->row, j->tgt, 0)); *d++ = '\t';
         d = put_u64(d, row_allele(c->row, j->tgt, 1));
         if (j->plan) {
@@ -1072,6 +1093,118 @@ static void *fmt_rows(void *arg)
         j->len = (size_t)(d - j->buf);
     }
     return NULL;
+}
+
+/* Columns 1-9 of all n rows once, for runs whose comparison individuals share the site list: a team formats contiguous
+ * ranges into buffers of their own, which are then joined (offsets per row).  ~50 bytes per row; a table-writing thread
+ * then copies a row's prefix instead of converting nine columns again (3 of the 6 conversions of a row that are not %e,
+ * and all its string handling). */
+typedef struct {
+    fmt_job j;                     /* a, b, buf, len, cap as in fmt_rows */
+    uint32_t *lens;                /* [n]: shared, every thread writes its own range */
+    char *dst;                     /* the joined text (second step) */
+    size_t dst_off;
+} pre_job;
+
+static void *pre_rows(void *arg)
+{
+    pre_job *p = arg;
+    fmt_job *j = &p->j;
+    j->failed = 0;
+    for (size_t i = j->a; i < j->b; ++i) {
+        const cand_t *c = &j->cand[j->s_cand[i]];
+        const size_t room = row_prefix_room(j->pu, c);
+        if (j->len + room > j->cap) {
+            size_t nc = j->cap ? j->cap * 2 : ((size_t)1 << 20);
+            while (j->len + room > nc)
+                nc *= 2;
+            char *nb = realloc(j->buf, nc);
+            if (!nb) {
+                j->failed = 1;
+                return NULL;
+            }
+            j->buf = nb;
+            j->cap = nc;
+        }
+        char *d = j->buf + j->len;
+        char *e = put_row_prefix(d, j->pu, c, j->s_nr[i], j->s_na[i]);
+        p->lens[i] = (uint32_t)(e - d);
+        j->len += (size_t)(e - d);
+    }
+    return NULL;
+}
+
+static void *pre_join(void *arg)
+{
+    pre_job *p = arg;
+    memcpy(p->dst + p->dst_off, p->j.buf, p->j.len);
+    return NULL;
+}
+
+/* 0 on success: *pre_out (malloc'd text) and *off_out (malloc'd, n + 1 offsets); on any failure nothing is kept and the
+ * tables are formatted row by row as before */
+static int row_prefix_build(fmt_job proto, size_t n, int threads, char **pre_out, uint32_t **off_out)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pre_job jobs[64];
+    pthread_t tid[64];
+    int started[64] = {0};
+    uint32_t *off = malloc((n + 1) * sizeof *off);
+    if (!off)
+        return 1;
+    for (int t = 0; t < threads; ++t) {
+        memset(&jobs[t], 0, sizeof jobs[t]);
+        jobs[t].j = proto;
+        jobs[t].j.buf = NULL;
+        jobs[t].j.cap = jobs[t].j.len = 0;
+        jobs[t].j.a = n * (size_t)t / (size_t)threads;
+        jobs[t].j.b = n * (size_t)(t + 1) / (size_t)threads;
+        jobs[t].lens = off;                                       /* lengths first, offsets after the scan below */
+    }
+    for (int t = 0; t + 1 < threads; ++t)
+        started[t] = pthread_create(&tid[t], NULL, pre_rows, &jobs[t]) == 0;
+    for (int t = 0; t < threads; ++t)
+        if (!started[t])
+            pre_rows(&jobs[t]);
+    int bad = 0;
+    size_t total = 0;
+    for (int t = 0; t < threads; ++t) {
+        if (started[t])
+            pthread_join(tid[t], NULL);
+        bad |= jobs[t].j.failed;
+        jobs[t].dst_off = total;
+        total += jobs[t].j.len;
+    }
+    char *pre = !bad && total < 0xffffffffu ? malloc(total ? total : 1) : NULL;
+    if (pre) {
+        for (int t = 0; t < threads; ++t) {
+            jobs[t].dst = pre;
+            started[t] = t + 1 < threads && pthread_create(&tid[t], NULL, pre_join, &jobs[t]) == 0;
+        }
+        for (int t = 0; t < threads; ++t)
+            if (!started[t])
+                pre_join(&jobs[t]);
+        for (int t = 0; t < threads; ++t)
+            if (started[t])
+                pthread_join(tid[t], NULL);
+        uint32_t run = 0;                                         /* lengths -> offsets */
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t len = off[i];
+            off[i] = run;
+            run += len;
+        }
+        off[n] = run;
+    }
+    for (int t = 0; t < threads; ++t)
+        free(jobs[t].j.buf);
+    if (!pre) {
+        free(off);
+        return 1;
+    }
+    *pre_out = pre;
+    *off_out = off;
+    return 0;
 }
 
 /* Rounds of 2^18 rows (bounds the text held in memory); the team formats round k+1 into a second set of buffers
@@ -1694,6 +1827,8 @@ typedef struct {
     size_t n, n_win;
     unsigned long processed, skipped, final_total, final_dist[128];
     const double *site_ll;                      /* per-row values (NULL with --summary-only) */
+    const char *pre;                            /* columns 1-9 of every row as text (row_prefix_build), or NULL */
+    const uint32_t *pre_off;
     uint32_t *w_first, *w_last, *w_ncov;        /* owned: freed when the files are closed */
     double *win_ll;
     int threads;
@@ -1746,6 +1881,8 @@ static void *output_individual(void *arg)
         proto.s_na = o->s_na;
         proto.tgt = o->tgt;
         proto.plan = opt_plan;
+        proto.pre = o->pre;
+        proto.pre_off = o->pre_off;
         if (write_rows_parallel(tab, proto, o->n, o->threads)) {
             fprintf(stderr, "[::] ERROR writing the per-site rows of %s.\n", o->tname);
             return NULL;
@@ -2067,7 +2204,9 @@ int main(int argc, char **argv)
     static out_job outs[OUT_SLOTS];
     const int overlap = !has_v && cull_p == 1.0 && !opt_plan && !opt_summary_only && targets.n > 1;
     double *site_slot[OUT_SLOTS] = {site_ll};
-    int out_slots = 4;                  /* (IBDGEM_OUT_SLOTS=1..6, default 4: for the tests and for measurements) */
+    int out_slots = 4;
+    char *row_pre = NULL;                       /* columns 1-9 of every row as text, shared by all individuals' tables */
+    uint32_t *row_pre_off = NULL;                  /* (IBDGEM_OUT_SLOTS=1..6, default 4: for the tests and for measurements) */
     if (getenv("IBDGEM_OUT_SLOTS") && atoi(getenv("IBDGEM_OUT_SLOTS")) >= 1 && atoi(getenv("IBDGEM_OUT_SLOTS")) <= OUT_SLOTS)
         out_slots = atoi(getenv("IBDGEM_OUT_SLOTS"));
     const int out_threads_env = getenv("IBDGEM_OUT_THREADS") ? atoi(getenv("IBDGEM_OUT_THREADS")) : 0;   /* (measurement switch) */
@@ -2132,6 +2271,17 @@ int main(int argc, char **argv)
         }
         const unsigned long processed = n;
         phase("per individual: site list");
+        if (ti == 0 && overlap && targets.n >= 3 && n > 0) {
+            /* nine of a row's fourteen columns are the same for every comparison individual: their text is made once */
+            fmt_job pp;
+            memset(&pp, 0, sizeof pp);
+            pp.cand = cand; pp.s_cand = s_cand; pp.pu = pu; pp.s_nr = s_nr; pp.s_na = s_na;
+            if (row_prefix_build(pp, n, opt_threads > 0 ? opt_threads : default_threads(), &row_pre, &row_pre_off)) {
+                row_pre = NULL;
+                row_pre_off = NULL;
+            }
+            phase("columns 1-9 of every row as text, once for all individuals");
+        }
 
         /* windows: runs of opt_window covered rows (:572, :657-663, :723-730) */
         size_t n_win = 0;
@@ -2252,6 +2402,7 @@ int main(int argc, char **argv)
         o->processed = processed; o->skipped = skipped; o->final_total = final_total;
         memcpy(o->final_dist, final_dist, sizeof o->final_dist);
         o->site_ll = site_ll;
+        o->pre = row_pre; o->pre_off = row_pre_off;
         o->w_first = w_first; o->w_last = w_last; o->w_ncov = w_ncov; o->win_ll = win_ll;
         const int all_threads = opt_threads > 0 ? opt_threads : default_threads();
         /* (tools/many_tables.py: files of 1 / 2 / 3 / 4 / 6 individuals at once with 8 threads each 73* / 66 / 57 / 47 / 54 ms per
