@@ -18,12 +18,15 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     st = os.stat(os.path.join(d, "p.hap"))
     bench.write_panel_cache(os.path.join(d, "p.cache"), words, 2504, st)
     del words
-    names = ",".join(f"ind{7 + 5 * i}" for i in range(8))
+    n_ind = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    names = ",".join(f"ind{7 + 5 * i}" for i in range(n_ind))
     base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", names, "--LD", "--threads", "16",
             "--panel-cache", "p.cache", "-O", "o"]
     os.makedirs(os.path.join(d, "o"))
-    for slots, thr in ((1, 16), (2, 8), (3, 8), (3, 16), (4, 8), (4, 4), (6, 4), (6, 8), (3, 6)):
+    sweep = ((1, 16), (2, 8), (3, 8), (3, 16), (4, 8), (4, 4), (6, 4), (6, 8), (3, 6)) if n_ind == 8 else ((1, 16), (4, 8), (6, 8))
+    for slots, thr in sweep:
         best = None
+        best_ph = None
         for rep in range(3):
             r = subprocess.run(base, cwd=d, env=dict(os.environ, IBDGEM_TIMING="1", IBDGEM_OUT_SLOTS=str(slots), IBDGEM_OUT_THREADS=str(thr)),
                                capture_output=True, text=True)
@@ -34,5 +37,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
                     ph[k] = ph.get(k, 0.0) + float(v)
             own = sum(v for k, v in ph.items() if k.startswith("per individual: engine") or k.startswith("per individual: output")
                       or k.startswith("per individual: waiting") or k.startswith("output files of the last"))
-            best = own if best is None else min(best, own)
-        print(f"files of {slots} individuals at once, {thr} formatter threads each: {best / 8 * 1e3:.1f} ms per individual (engine + output, best of 3)", flush=True)
+            if best is None or own < best:
+                best, best_ph = own, ph
+        print(f"{n_ind} individuals, files of {slots} at once, {thr} formatter threads each: {best / n_ind * 1e3:.1f} ms per individual (engine + output, best of 3)", flush=True)
+        if n_ind != 8:
+            print("    " + " | ".join(f"{k[:45]} {v:.3f}" for k, v in best_ph.items() if "individual" in k or "columns" in k), flush=True)
