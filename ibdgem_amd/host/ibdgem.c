@@ -1829,6 +1829,7 @@ typedef struct {
     const double *site_ll;                      /* per-row values (NULL with --summary-only) */
     const char *pre;                            /* columns 1-9 of every row as text (row_prefix_build), or NULL */
     const uint32_t *pre_off;
+    FILE *tab, *sum;                            /* open (stdout with --plan); closed by the job */
     uint32_t *w_first, *w_last, *w_ncov;        /* owned: freed when the files are closed */
     double *win_ll;
     int threads;
@@ -1841,27 +1842,12 @@ static void *output_individual(void *arg)
 {
     out_job *o = arg;
     o->failed = 1;
-    FILE *tab, *sum;
-    if (opt_plan) {
-        tab = stdout;
-        sum = stdout;
+    FILE *tab = o->tab, *sum = o->sum;           /* opened by the main thread: a directory that cannot be written stops the run at once */
+    if (opt_plan)
         printf("## PLAN %s %s processed=%lu skipped=%lu windows=%zu cull_p=%f\n", opt_sq, o->tname, o->processed, o->skipped,
                o->n_win, o->cull_p);
-    } else {
-        char *tab_fn, *sum_fn;
-        if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", o->out_dir, opt_sq, o->tname) < 0 ||
-            asprintf(&sum_fn, "%s/%s.%s.summary.txt", o->out_dir, opt_sq, o->tname) < 0)
-            return NULL;
-        tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
-        sum = fopen(sum_fn, "w");
-        if (!tab || !sum) {
-            fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
-            return NULL;
-        }
-        free(tab_fn);
-        free(sum_fn);
+    else
         fprintf(tab, "# Entered command: %s\n\n", o->user_cmd);
-    }
     /* header block (:144-152, :547-548) */
     fprintf(tab, "# INPUT COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
     for (unsigned c = 0; c <= opt_max_cov; ++c)
@@ -2404,6 +2390,22 @@ int main(int argc, char **argv)
         o->site_ll = site_ll;
         o->pre = row_pre; o->pre_off = row_pre_off;
         o->w_first = w_first; o->w_last = w_last; o->w_ncov = w_ncov; o->win_ll = win_ll;
+        if (opt_plan) {
+            o->tab = o->sum = stdout;
+        } else {
+            char *tab_fn, *sum_fn;
+            if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
+                asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
+                quit(1);
+            o->tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
+            o->sum = fopen(sum_fn, "w");
+            if (!o->tab || !o->sum) {
+                fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
+                quit(1);
+            }
+            free(tab_fn);
+            free(sum_fn);
+        }
         const int all_threads = opt_threads > 0 ? opt_threads : default_threads();
         /* (tools/many_tables.py: files of 1 / 2 / 3 / 4 / 6 individuals at once with 8 threads each 73* / 66 / 57 / 47 / 54 ms per
          * individual, *16 threads; 4 x 4 threads 58, 3 x 16 threads 57) */
