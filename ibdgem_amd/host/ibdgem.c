@@ -40,6 +40,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <fcntl.h>
 #include <errno.h>
 
 #include "../../include/ibdgem_hip.h"
@@ -1846,8 +1847,13 @@ static void *output_individual(void *arg)
     if (opt_plan)
         printf("## PLAN %s %s processed=%lu skipped=%lu windows=%zu cull_p=%f\n", opt_sq, o->tname, o->processed, o->skipped,
                o->n_win, o->cull_p);
-    else
+    else {
+        if ((!opt_summary_only && ftruncate(fileno(tab), 0) != 0) || ftruncate(fileno(sum), 0) != 0) {
+            fprintf(stderr, "[::] ERROR in compare_impute(): Cannot empty the output files of %s.\n", o->tname);
+            return NULL;
+        }
         fprintf(tab, "# Entered command: %s\n\n", o->user_cmd);
+    }
     /* header block (:144-152, :547-548) */
     fprintf(tab, "# INPUT COVERAGE DISTRIBUTION:\n# COVERAGE N_SITES\n");
     for (unsigned c = 0; c <= opt_max_cov; ++c)
@@ -2397,8 +2403,12 @@ int main(int argc, char **argv)
             if (asprintf(&tab_fn, "%s/%s.%s.tab.txt", out_dir, opt_sq, tname) < 0 ||
                 asprintf(&sum_fn, "%s/%s.%s.summary.txt", out_dir, opt_sq, tname) < 0)
                 quit(1);
-            o->tab = fopen(opt_summary_only ? "/dev/null" : tab_fn, "w");
-            o->sum = fopen(sum_fn, "w");
+            /* opened here, emptied by whoever writes them: giving back the pages of an earlier run's 330 MB table takes
+             * tens of milliseconds, which belong to the individual's output job, not between two engine calls */
+            const int tab_fd = open(opt_summary_only ? "/dev/null" : tab_fn, O_WRONLY | O_CREAT, 0666);
+            const int sum_fd = open(sum_fn, O_WRONLY | O_CREAT, 0666);
+            o->tab = tab_fd >= 0 ? fdopen(tab_fd, "w") : NULL;
+            o->sum = sum_fd >= 0 ? fdopen(sum_fd, "w") : NULL;
             if (!o->tab || !o->sum) {
                 fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
                 quit(1);
