@@ -2453,6 +2453,8 @@ int main(int argc, char **argv)
     for (int d = 0; d < n_eng; ++d)
         ibdg_destroy(engs[d]);
     phase("engine shutdown");
+    free(row_pre);
+    free(row_pre_off);
     pileup_free(pu);
     fprintf(stderr, "Run time: %f minutes.\n", ((double)(clock() - t_start) / CLOCKS_PER_SEC) / 60);
     return EXIT_SUCCESS;
