@@ -103,6 +103,13 @@ struct ibdg_ctx {
     bool up_ms_pending = false;         // the first two are still to be read from the events
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
+    // the compacted, window-aligned tiles of the current site list (k_gather_transpose32) and whether the segments,
+    // window constants and control words at hand were cut from them (true) or from the panel's own tiles (false)
+    DevBuf t32c;
+    uint32_t n_pairs_c = 0;
+    bool compact = false;
+    bool segs_clean = false;            // the segment array is still the zeros stage A left
+    uint32_t first_row = 0, last_row = 0;   // panel rows of the first / last site of the upload
     DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, pow3, partial;
     // many comparison individuals (k_ld_mfma): target operands of a batch of groups, window constants per slot,
     // partial sums per half chunk, background multiplicities without the comparison individual's exclusion
@@ -118,7 +125,7 @@ struct ibdg_ctx {
     int planes = 0;
     bool pop_lut_ok = false;     // P(D|G) table is the unclamped binomial form
     bool pop_sites_ok = false;   // site rows strictly increasing, segments built
-    bool pop_dense_enough = true; // covered rows / spanned rows high enough for it to be the faster kernel
+    bool pop_dense_enough = true; // the site list went to the layout asked for (false: "compact_tiles" -1 on a sparse pileup)
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
     // inputs of the previous ibdg_run whose device copies are still valid
@@ -158,6 +165,11 @@ struct ibdg_ctx {
     long opt_site_blocks = 4;        // 256-thread workgroups per CU of k_site inside an --LD run (0 = a thread per site)
     long opt_recount_blocks = 4;     // single-wave workgroups per CU of k_alt_count when it runs inside an --LD run
                                      // (0 = the full grid; 4 measured best: tools/recount_sweep.py)
+    long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
+                                     // dense, compacted where it is sparse or the rows are out of file order) and
+                                     // per run (many comparison individuals), 1 = always compacted, -1 = never
+    long opt_compact_density = 3;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
+    long opt_compact_targets = 96;   // ... or when a run has at least this many comparison individuals (the re-layout is paid once)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under
@@ -598,19 +610,37 @@ int wait_info(ibdg_ctx *c, uint32_t seq)
 // Segments, per-window constants, control words and power tables of the fast --LD kernel, built on
 // the device from the covered-row list (ibdg_prep.hip); the host keeps what depends on the window
 // count only (the run structure) and the epsilon-only power tables.
-int build_segments(ibdg_ctx *c)
+int build_segments(ibdg_ctx *c, bool compact)
 {
     c->pop_sites_ok = false;
     if (!c->pop_lut_ok || c->n_cov == 0)
         return 0;
     const ibdg::PrepInfo &I = *c->info_h;
+    const uint32_t tpw = (c->window + 31) / 32;        // tiles per window of the compacted layout
     // segments <= windows + tiles spanned when the rows are in file order (otherwise the device stops
     // writing at the capacity and the exponent-counting kernel is not used); never more than stage A cleared
     uint64_t seg_cap = c->n_cov;
-    const uint32_t first_row = I.first_row, last_row = I.last_row;     // of stage A: the mirror is overwritten by stage B's hand-over
-    if (last_row >= first_row)
+    const uint32_t first_row = c->first_row, last_row = c->last_row;
+    if (compact)
+        seg_cap = (uint64_t)c->n_win * tpw;
+    else if (last_row >= first_row)
         seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((last_row >> 5) - (first_row >> 5)) + 1);
     seg_cap = std::min<uint64_t>(seg_cap, c->seg_room);
+    if (!c->segs_clean)                    // a second layout for the same upload: the masks are OR-ed into zeros
+        HIP_TRY(c, hipMemsetAsync(c->segs.p, 0, c->seg_room * sizeof(ibdg::Seg), c->stream));
+    c->segs_clean = false;
+    if (compact) {
+        // the rows with reads, gathered and transposed into tiles that start with their window
+        const uint64_t pairs = ((uint64_t)c->n_win * tpw + 1) / 2;
+        if (pairs >= (1ull << 31))
+            return 0;
+        c->n_pairs_c = (uint32_t)((pairs + 3) & ~3ull);
+        if (ensure(c, c->t32c, (size_t)c->n_chunks * c->n_pairs_c * 64 * 16))
+            return 1;
+        ibdg::launch_gather_transpose32((const uint64_t *)c->panel.p, c->stride, (const uint2 *)c->rec_cov.p, c->n_cov,
+                                        c->window, c->n_chunks, c->n_pairs_c, (uint32_t *)c->t32c.p, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
         ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
         return 1;
@@ -633,6 +663,7 @@ int build_segments(ibdg_ctx *c)
     sa.block_tmp = (uint32_t *)c->scan_tmp.p;
     sa.info = (ibdg::PrepInfo *)c->info_dev.p;
     sa.mirror = c->info_h;
+    sa.compact = compact ? 1u : 0u;
     c->prep_dirty = true;
     // (stream2 is idle: ibdg_upload_sites drained both streams before it began; stage A has been waited for)
     ibdg::launch_prep_segments(sa, c->stream, c->stream2);
@@ -664,8 +695,8 @@ int build_segments(ibdg_ctx *c)
         if (wait_info(c, c->prep_seq))
             return 1;
         c->prep_dirty = false;
-        if (I.out_of_order || I.n_segs > seg_cap)
-            return 0;                      // not in file order: only the strict kernel applies
+        if ((!compact && I.out_of_order) || I.n_segs > seg_cap)
+            return 0;                      // not in file order: the panel's own tiles do not apply
         if ((size_t)I.max_seg * (sizeof(ibdg::Seg) + 8) <= (size_t)c->opt_recbytes || g == 1)
             break;
     }
@@ -698,13 +729,39 @@ int build_segments(ibdg_ctx *c)
                              (ibdg::WinConst *)c->wconst.p, c->stream);
     HIP_TRY(c, hipGetLastError());
     c->pop_sites_ok = true;
-    // Sparse coverage: the exponent-counting kernel streams every 32-row tile between a window's first
-    // and last row (~175 issue cycles per tile and chunk) while the strict kernel touches covered rows
-    // only (~49 cycles per row and chunk): below ~1 covered row in 9 the strict kernel is the faster one.
-    {
-        const uint64_t span = (uint64_t)last_row - first_row + 1;
-        c->pop_dense_enough = (uint64_t)c->n_cov * 9 >= span;
-    }
+    c->compact = compact;
+    return 0;
+}
+
+// Sparse coverage: on the panel's own tiles the exponent-counting kernels stream every 32-row tile between a
+// window's first and last row, whether its rows carry reads or not; on the compacted tiles a window costs
+// ceil(window / 32) tile words whatever the density, plus its share of the gather (~6 tile words' worth of time per
+// 100 rows).  Below about one covered row in three the compacted layout is the faster one for a single run.
+bool sparse_sites(const ibdg_ctx *c)
+{
+    if (c->last_row < c->first_row)
+        return true;                       // not even the ends are in file order
+    const uint64_t span = (uint64_t)c->last_row - c->first_row + 1;
+    return (uint64_t)c->n_cov * (uint64_t)std::max<long>(1, c->opt_compact_density) < span;
+}
+
+// Segments for the layout the options and the site list ask for; the compacted one also serves when the panel's own
+// tiles turn out not to apply (rows out of file order, rows too far apart for the control words).
+int build_layout(ibdg_ctx *c)
+{
+    c->pop_sites_ok = false;
+    c->compact = false;
+    c->pop_dense_enough = true;
+    if (!c->pop_lut_ok || c->n_cov == 0)
+        return 0;
+    const bool sparse = sparse_sites(c);
+    const bool want_compact = c->opt_compact > 0 || (c->opt_compact == 0 && sparse);
+    if (build_segments(c, want_compact))
+        return 1;
+    if (!c->pop_sites_ok && !want_compact && c->opt_compact == 0 && build_segments(c, true))
+        return 1;
+    if (c->opt_compact < 0 && sparse)
+        c->pop_dense_enough = false;       // the caller forbade the layout this pileup wants: the strict kernel is the faster one
     return 0;
 }
 
@@ -849,7 +906,7 @@ void ibdg_destroy(ibdg_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
-                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32,
+                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32, &c->t32c,
                       &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
@@ -944,7 +1001,10 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     c->win_bounds_valid = false;
     c->have_fo = false;
     // segments of stage B: at most one per site, and in file order at most windows + tiles of the panel
-    const size_t seg_room = std::min<size_t>(n_sites, (n_sites + window - 1) / window + (c->n_rows + 31) / 32 + 1);
+    // (compacted tiles: ceil(window / 32) per window)
+    const size_t n_win_max = (n_sites + window - 1) / window;
+    const size_t seg_room = std::min<size_t>(n_sites, std::max<size_t>(n_win_max + (c->n_rows + 31) / 32 + 1,
+                                                                      n_win_max * ((window + 31) / 32)));
     const bool fresh_info = !c->info_dev.p;
     if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
         ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
@@ -962,6 +1022,8 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
         c->prep_dirty = false;
     }
     c->seg_room = c->pop_lut_ok ? seg_room : 0;
+    c->segs_clean = n_sites != 0;           // stage A's scatter kernel clears the array
+    c->compact = false;
     if (n_sites) {
         c->prep_dirty = true;
         ibdg::PrepSiteArgs pa;
@@ -1008,8 +1070,10 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
                     (size_t)I.err_cov_site, (unsigned)r + a, c->max_cov);
     }
     c->n_cov = I.n_cov;
+    c->first_row = I.first_row;             // (the mirror is overwritten by stage B's hand-over)
+    c->last_row = I.last_row;
     c->n_win = (uint32_t)(((uint64_t)c->n_cov + window - 1) / window);
-    if (build_segments(c))
+    if (build_layout(c))
         return 1;
     if (f_override) {
         std::vector<double> fo(3 * n_sites);
@@ -1232,8 +1296,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     }
 
     bool use_pop = false, s2_after_prep = false, side_fast = false;
+    if (ld_mode && c->pop_lut_ok && c->pop_sites_ok && !c->compact && c->opt_compact == 0 && c->opt_variant != 1 &&
+        c->opt_variant != 3 && T >= (size_t)std::max<long>(1, c->opt_compact_targets)) {
+        // many comparison individuals over one site list: the compacted tiles' one-off gather is paid back by the
+        // fewer segments every one of them counts (the site list belongs to the pileup, not to the comparison
+        // individual: src/ibdgem.c:522 loops the individuals over the same rows)
+        if (quiesce(c)) return 1;
+        if (build_segments(c, true)) return 1;
+        if (!c->pop_sites_ok && build_segments(c, false)) return 1;     // (cannot happen: it applied a moment ago)
+    }
     if (ld_mode) {
-        const bool can = c->pop_lut_ok && c->pop_sites_ok && c->t32.p;
+        const bool can = c->pop_lut_ok && c->pop_sites_ok && (c->compact ? c->t32c.p : c->t32.p);
         if (c->opt_variant == 2 && !can)
             return fail(c, "[::] ERROR in ibdg_run: ld_variant 2 (exponent counting) is not applicable here "
                            "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
@@ -1308,7 +1381,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         size_t n_gg = 0, T_g = 0;
         // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
         const size_t group_bytes = (size_t)c->n_win * c->n_chunks * 32 * TGs + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
-        if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && c->n_pairs < (1u << 23) &&
+        if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && (c->compact ? c->n_pairs_c : c->n_pairs) < (1u << 23) &&
             group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
             n_gg = T / TGs;
@@ -1342,8 +1415,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ensure(c, c->partial_h, T_batch * (size_t)c->n_win * c->n_chunks * 32))
             return 1;
         ibdg::PopArgs pa;
-        pa.t32 = (const uint32_t *)c->t32.p;
-        pa.n_pairs = c->n_pairs;
+        pa.t32 = (const uint32_t *)(c->compact ? c->t32c.p : c->t32.p);
+        pa.n_pairs = c->compact ? c->n_pairs_c : c->n_pairs;
         pa.n_chunks = c->n_chunks;
         pa.segs = (const ibdg::Seg *)c->segs.p;
         pa.n_segs = c->n_segs;
@@ -1668,6 +1741,13 @@ int ibdg_last_run_ms(ibdg_ctx *c, float out[5])
 
 int ibdg_last_ld_variant(const ibdg_ctx *c) { return c ? c->last_variant : 0; }
 
+int ibdg_ld_layout(const ibdg_ctx *c)
+{
+    if (!c || !c->sites_valid || !c->pop_sites_ok)
+        return 0;
+    return c->compact ? 2 : 1;
+}
+
 int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
 {
     if (!c || !name) return 1;
@@ -1687,6 +1767,18 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "stage_workers")) {
         if (value < 1 || value > ibdg_ctx::STAGE_WORKERS) return fail(c, "[::] ERROR in ibdg_set_option: stage_workers must be 1..%d", ibdg_ctx::STAGE_WORKERS);
         c->opt_stage_workers = value; return 0;
+    }
+    if (!strcmp(name, "compact_tiles")) {
+        if (value < -1 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: compact_tiles must be -1 (never), 0 (auto) or 1 (always)");
+        c->opt_compact = value; return 0;
+    }
+    if (!strcmp(name, "compact_density")) {
+        if (value < 1 || value > 1000000) return fail(c, "[::] ERROR in ibdg_set_option: compact_density must be 1..1000000");
+        c->opt_compact_density = value; return 0;
+    }
+    if (!strcmp(name, "compact_targets")) {
+        if (value < 1 || value > 65536) return fail(c, "[::] ERROR in ibdg_set_option: compact_targets must be 1..65536");
+        c->opt_compact_targets = value; return 0;
     }
     if (!strcmp(name, "site_results")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: site_results must be 0 or 1");

@@ -168,6 +168,10 @@ int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelE
 
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
                         uint32_t n_pairs, uint32_t *t32, hipStream_t st);
+// the compacted, window-aligned tiles of a site list: covered row j -> virtual row (j / window) * 32 * ceil(window / 32)
+// + j % window; n_pairs tile pairs per chunk (whole octs, zero beyond the last window)
+void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
+                               uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
@@ -229,6 +233,7 @@ struct PrepSegArgs {
     uint32_t *block_tmp;        // prep_scan_blocks(n_cov) words
     PrepInfo *info;
     PrepInfo *mirror;
+    uint32_t compact = 0;       // 1: segments of the compacted, window-aligned tiles (k_gather_transpose32)
 };
 
 size_t prep_scan_blocks(size_t n);

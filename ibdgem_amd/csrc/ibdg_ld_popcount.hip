@@ -97,21 +97,10 @@ __device__ __forceinline__ uint32_t block_exchange(uint32_t w, uint32_t lane)
     return (w & keep) | (rot & ~keep);                                           // v_bfi_b32
 }
 
-__global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict__ panel,
-                                                     uint32_t stride, size_t n_rows,
-                                                     uint32_t n_chunks, uint32_t n_pairs,
-                                                     uint4 *__restrict__ t32)
+// the two 64 x 64 bit matrices of a wave (lane = row; {plane 0 lo, hi, plane 1 lo, hi}) transposed in registers:
+// afterwards lane = individual, the return value the uint4 of the layout above
+__device__ __forceinline__ uint4 transpose_pair(uint4 w, uint32_t lane)
 {
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned c = blockIdx.y * 8 + wave;
-    if (c >= n_chunks)
-        return;
-    const uint32_t pair = blockIdx.x;
-    const size_t r = (size_t)pair * 64 + lane;
-    uint4 w = make_uint4(0, 0, 0, 0);                 // {plane 0 lo, hi, plane 1 lo, hi} of row r
-    if (r < n_rows)
-        w = *reinterpret_cast<const uint4 *>(panel + r * stride + 2 * c);
     // s = 32: the high halves of lanes 0..31 and the low halves of lanes 32..63 change places
     {
         auto p0 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);
@@ -132,8 +121,63 @@ __global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict_
     IBDG_T_STEP(2)
     IBDG_T_STEP(1)
 #undef IBDG_T_STEP
-    // lane = individual now; w.x / w.y = rows 0..31 / 32..63 of the first haplotype, w.z / w.w of the second
-    t32[((size_t)c * n_pairs + pair) * 64 + lane] = make_uint4(w.x, w.z, w.y, w.w);
+    // w.x / w.y = rows 0..31 / 32..63 of the first haplotype, w.z / w.w of the second
+    return make_uint4(w.x, w.z, w.y, w.w);
+}
+
+__global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict__ panel,
+                                                     uint32_t stride, size_t n_rows,
+                                                     uint32_t n_chunks, uint32_t n_pairs,
+                                                     uint4 *__restrict__ t32)
+{
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned c = blockIdx.y * 8 + wave;
+    if (c >= n_chunks)
+        return;
+    const uint32_t pair = blockIdx.x;
+    const size_t r = (size_t)pair * 64 + lane;
+    uint4 w = make_uint4(0, 0, 0, 0);                 // {plane 0 lo, hi, plane 1 lo, hi} of row r
+    if (r < n_rows)
+        w = *reinterpret_cast<const uint4 *>(panel + r * stride + 2 * c);
+    t32[((size_t)c * n_pairs + pair) * 64 + lane] = transpose_pair(w, lane);
+}
+
+// ---------------------------------------------------------------------------
+// The compacted, window-aligned layout of ONE site list (once per ibdg_upload_sites, or on the first run with
+// several comparison individuals): only the rows that carry reads, in the order of the site list, every
+// window starting on a tile boundary --
+//     virtual row v = (j / W) * 32 * TPW + j % W      for covered row j (W = window, TPW = ceil(W / 32) tiles per window)
+// -- gathered from the site-major panel through the covered-row list and transposed like above, same uint4
+// layout, so the --LD kernels run on it unchanged (their segments are cut from the virtual rows,
+// ibdg_prep.hip).  In the reference the rows a window multiplies are the rows that passed the filter chain
+// and carry reads (src/ibdgem.c:596-601, :657-663), however far apart they lie in the panel: here a window
+// costs TPW tile words whatever the pileup's density, where the in-place tiles cost one word per 32 PANEL
+// rows between its first and last row; and no tile is shared by two windows (4 segments per window of 100
+// rows instead of 4.6).  The rows of the virtual tiles beyond a window's W (and beyond the last covered row)
+// are zero bits.  Access pattern as in k_transpose32: a lane fetches 16 bytes of its row, the eight waves of a
+// workgroup eight neighbouring chunks = one 128-byte piece of each of the 64 rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_gather_transpose32(const uint64_t *__restrict__ panel, uint32_t stride,
+                                                            const uint2 *__restrict__ rec_cov, uint32_t n_cov,
+                                                            uint32_t window, uint32_t win_rows /* 32 * TPW */,
+                                                            uint32_t n_chunks, uint32_t n_pairs,
+                                                            uint4 *__restrict__ t32)
+{
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned c = blockIdx.y * 8 + wave;
+    if (c >= n_chunks)
+        return;
+    const uint32_t pair = blockIdx.x;
+    const uint64_t v = (uint64_t)pair * 64 + lane;
+    const uint64_t win = v / win_rows;
+    const uint32_t k = (uint32_t)(v - win * win_rows);
+    const uint64_t j = win * window + k;
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (k < window && j < n_cov)
+        w = *reinterpret_cast<const uint4 *>(panel + (size_t)rec_cov[j].x * stride + 2 * c);
+    t32[((size_t)c * n_pairs + pair) * 64 + lane] = transpose_pair(w, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -975,6 +1019,15 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
         return;
     hipLaunchKernelGGL(k_transpose32, dim3(n_pairs, (n_chunks + 7) / 8), dim3(512), 0, st, panel, stride,
                        n_rows, n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
+}
+
+void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
+                               uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st)
+{
+    if (n_pairs == 0)
+        return;
+    hipLaunchKernelGGL(k_gather_transpose32, dim3(n_pairs, (n_chunks + 7) / 8), dim3(512), 0, st, panel, stride, rec_cov,
+                       n_cov, window, 32u * ((window + 31) / 32), n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
 }
 
 // ev.start / ev.stop (may be null): events the dispatch itself updates with the kernel's start and

@@ -247,17 +247,32 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, c
 // ---- stage B: covered rows -> segments --------------------------------------------------------
 // Covered row j starts a segment when it starts a window (j % window == 0) or lies in another
 // 32-row tile than row j-1.
+// With the compacted layout (k_gather_transpose32) the row of covered row j is the VIRTUAL row
+// (j / window) * win_rows + j % window, win_rows = 32 * ceil(window / 32): windows start on tile boundaries, rows
+// without reads do not exist, and the order of the rows in the panel plays no part.
 struct SegIn {
     const uint2 *rec_cov;
     uint32_t n_cov;
     uint32_t window;
     uint32_t d;             // max_cov + 1
+    uint32_t win_rows;      // 0: the panel's own rows (in-place tiles); otherwise virtual rows per window
 };
+
+__device__ __forceinline__ uint32_t seg_row(const SegIn &in, size_t j)
+{
+    if (in.win_rows == 0)
+        return in.rec_cov[j].x;
+    const size_t w = j / in.window;
+    return (uint32_t)(w * in.win_rows + (j - w * in.window));
+}
 
 __device__ __forceinline__ bool seg_start(const SegIn &in, size_t j)
 {
-    if (j % in.window == 0)
+    const size_t k = j % in.window;
+    if (k == 0)
         return true;
+    if (in.win_rows)
+        return (k & 31) == 0;
     return (in.rec_cov[j].x >> 5) != (in.rec_cov[j - 1].x >> 5);
 }
 
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint3
 {
     const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
     const uint32_t tot = block_count(base, in.n_cov, [&](size_t j) {
-        if (j > 0 && in.rec_cov[j].x <= in.rec_cov[j - 1].x)
+        if (in.win_rows == 0 && j > 0 && in.rec_cov[j].x <= in.rec_cov[j - 1].x)
             info->out_of_order = 1;                    // not in file order: only the strict kernel applies
         return seg_start(in, j);
     });
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
         if (live) {
             const uint2 rc = in.rec_cov[j];
             const uint32_t idx = rc.y / 24u, r = idx / in.d;
-            row = rc.x;
+            row = in.win_rows ? seg_row(in, j) : rc.x;
             al = idx - r * in.d;
             cv = r + al;
         }
@@ -569,6 +584,7 @@ void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2)
     in.n_cov = a.n_cov;
     in.window = a.window;
     in.d = a.max_cov + 1;
+    in.win_rows = a.compact ? 32u * ((a.window + 31) / 32) : 0u;
     const unsigned nb = blocks_for(a.n_cov);
     // the per-window constants on the second stream, beside the three segment kernels
     hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 63) / 64), dim3(64), 0, st2, in, a.n_win, a.nck, a.wconst, a.raw,

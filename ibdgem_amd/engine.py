@@ -45,6 +45,7 @@ SYMBOLS = {
     "ibdg_run_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_run_kernel_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_last_ld_variant": (C.c_int, [_P]),
+    "ibdg_ld_layout": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "ibdg_set_background_order": (C.c_int, [_P, _P, C.c_size_t]),
     "ibdg_sync": (C.c_int, [_P]),
@@ -269,6 +270,10 @@ class Engine:
 
     def last_ld_variant(self):
         return self.lib.ibdg_last_ld_variant(self.ctx)
+
+    def ld_layout(self):
+        """0 none, 1 the panel's own tiles, 2 the compacted, window-aligned tiles of the site list."""
+        return self.lib.ibdg_ld_layout(self.ctx)
 
     def sync(self):
         self._chk(self.lib.ibdg_sync(self.ctx))

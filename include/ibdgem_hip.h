@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 3   /* 3: options site_results, stage_workers; ibdg_get_site_af computes on demand; ibdg_last_run_ms out[4] is 0 */
+#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+                              * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
+                              * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
 typedef struct ibdg_ctx ibdg_ctx;
 
@@ -199,6 +201,15 @@ int ibdg_run_kernel_ms(ibdg_ctx *ctx, unsigned back, float *ms);
  * to the reference; ~12x the time of 2). */
 int ibdg_last_ld_variant(const ibdg_ctx *ctx);
 
+/* Which tiles the exponent-counting / matrix-core --LD kernels read for the site list at hand: 0 none prepared
+ * (no sites, or only the strict kernel applies), 1 the panel's own 32-row tiles (every tile between a window's
+ * first and last panel row is streamed), 2 the compacted, window-aligned tiles of this site list: only the rows
+ * that carry reads (the rows the reference's window loop multiplies, src/ibdgem.c:596-601, :657-663), gathered
+ * and transposed once per ibdg_upload_sites -- or by the first ibdg_run with "compact_targets" or more
+ * comparison individuals -- so that a window costs ceil(window / 32) tile words whatever the pileup's density.
+ * Chosen per upload (option "compact_tiles"). */
+int ibdg_ld_layout(const ibdg_ctx *ctx);
+
 /* Options: "dispatch_events" (0/1: time the --LD launches through their own
  * dispatch packets, which makes ibdg_run_kernel_ms available; costs ~10 us per
  * run more than the default single event record); "async" (0/1: ibdg_run returns as soon as its kernels are queued;
@@ -219,6 +230,10 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * threads instead of the runtime's pageable-memory path); "ld_variant" (0 = pick automatically,
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference
  * order);
+ * "compact_tiles" (set before ibdg_upload_sites: 0, the default = the compacted tiles of ibdg_ld_layout when fewer than
+ * one panel row in "compact_density" (default 3) between the first and the last site carries reads, when the rows
+ * are not in file order, or when a run has "compact_targets" (default 96) or more comparison individuals, the panel's
+ * own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;

@@ -481,30 +481,37 @@ def test_site_results_option_changes_no_window_bit(oracle, N, L, W, T):
 
 # --------------------------------------------------------------------------- kernel selection
 def test_kernel_selection_and_fallback(oracle):
-    """Auto picks the exponent-counting kernel when the P(D|G) table is the plain binomial
-    form and the rows are in file order; otherwise the strict kernel (never an error)."""
+    """Auto picks the exponent-counting kernel when the P(D|G) table is the plain binomial form -- on the
+    panel's own tiles when the rows are in file order, on the compacted tiles otherwise; with a clamped
+    table the strict kernel (never an error)."""
     N, L = 150, 500
     alle, nr, na = synth(61, L, N)
     with E.Engine(0, 0.02, 20) as eng:
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(np.arange(L), nr, na, 100)
         eng.run([1], ld=True)
-        assert eng.last_ld_variant() == 2
+        assert eng.last_ld_variant() == 2 and eng.ld_layout() == 1
         fast = eng.window_ll(0)
         eng.set_option("ld_variant", 1)
         eng.run([1], ld=True)
         assert eng.last_ld_variant() == 1
         assert_ld_close(fast[:, :2], eng.window_ll(0)[:, :2], "fast vs strict")
         assert_bits(fast[:, 2], eng.window_ll(0)[:, 2], "LIBD2")
-        # rows out of file order: only the strict kernel applies
+        # rows out of file order: the panel's own tiles do not apply, the compacted ones do
         eng.set_option("ld_variant", 0)
         perm = np.arange(L)
         perm[[3, 4]] = perm[[4, 3]]
         eng.upload_sites(perm, nr[perm], na[perm], 100)
         eng.run([1], ld=True)
-        assert eng.last_ld_variant() == 1
+        assert eng.last_ld_variant() == 2 and eng.ld_layout() == 2
         res = oracle.compare(alle[perm], nr[perm], na[perm], 1, window=100, ld=True)
         assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "permuted rows")
+        # ... unless the caller forbids them: then only the strict kernel is left
+        eng.set_option("compact_tiles", -1)
+        eng.upload_sites(perm, nr[perm], na[perm], 100)
+        eng.run([1], ld=True)
+        assert eng.last_ld_variant() == 1 and eng.ld_layout() == 0
+        assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "permuted rows, strict")
         eng.set_option("ld_variant", 2)
         with pytest.raises(E.EngineError, match="not applicable"):
             eng.run([1], ld=True)
@@ -595,17 +602,87 @@ def test_sparse_pileup_rows_far_apart(oracle):
     alle, nr, na = synth(91, Lp, N)
     keep = np.sort(rng.choice(Lp, size=900, replace=False))
     nrk, nak = np.maximum(nr[keep], 1), na[keep]
-    for variant in (0, 1, 2):
+    res = oracle.compare(alle[keep], nrk, nak, 7, window=100, ld=True)
+    got = {}
+    for variant, tiles in ((0, 0), (1, 0), (2, 0), (2, -1), (0, -1)):
         with E.Engine() as eng:
             eng.set_option("ld_variant", variant)
+            eng.set_option("compact_tiles", tiles)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nrk, nak, 100)
             eng.run([7], ld=True)
-            # few covered rows among those spanned: the automatic choice is the strict kernel
-            assert eng.last_ld_variant() == (2 if variant == 2 else 1)
-            res = oracle.compare(alle[keep], nrk, nak, 7, window=100, ld=True)
+            # few covered rows among those spanned: the exponent-counting kernel on the compacted tiles of the site
+            # list (src/ibdgem.c:596-601: rows without a pileup line never reach the window loop); with those
+            # forbidden, the strict kernel rather than streaming every tile in between
+            assert eng.last_ld_variant() == (1 if variant == 1 or (variant, tiles) == (0, -1) else 2)
+            assert eng.ld_layout() == (2 if tiles == 0 else 1)
             assert_bits(eng.site_ll(0), res["site"], "site")
-            assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"sparse variant={variant}")
+            assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"sparse variant={variant} tiles={tiles}")
+            got[variant, tiles] = eng.window_ll(0)
+    # the counts are exact integers whichever tiles they are taken from: same bits
+    assert_bits(got[2, 0], got[2, -1], "compacted vs the panel's own tiles")
+    assert_bits(got[0, 0], got[2, 0], "auto = compacted")
+
+
+@pytest.mark.parametrize("N,L,W,M,cov,T", [(150, 2600, 100, 20, 2.0, 1), (70, 900, 2, 20, 2.0, 2), (131, 1700, 33, 3, 1.0, 4),
+                                            (300, 3000, 64, 20, 0.4, 9), (700, 5000, 257, 40, 9.0, 17), (64, 640, 32, 20, 2.0, 5),
+                                            (2504, 1300, 100, 20, 2.0, 3), (130, 4000, 31, 20, 5.0, 31)])
+def test_compacted_tiles_give_the_bits_of_the_panel_tiles(oracle, N, L, W, M, cov, T):
+    """The compacted, window-aligned tiles of a site list (rows with reads only, every window on a tile boundary)
+    against the panel's own tiles: the exponents are exact integer sums over the same rows, so every --LD kernel
+    (single, groups of four, matrix cores) returns the same bits from either; and both agree with the oracle."""
+    alle, nr, na = synth(7000 + N + W, L, N, cov_mean=cov)
+    na = np.minimum(na, M).astype(np.uint8)
+    nr = np.minimum(nr, M - na.astype(int)).astype(np.uint8)
+    rng = np.random.default_rng(N * W)
+    targets = [int(t) for t in rng.choice(N, size=min(T, N), replace=False)]
+    out = {}
+    for tiles in (-1, 1):
+        with E.Engine(0, 0.02, M) as eng:
+            eng.set_option("compact_tiles", tiles)
+            eng.set_option("ld_variant", 2)          # (a thin pileup on the panel's own tiles would take the strict kernel)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, W)
+            eng.run(targets, ld=True, pu_id=targets[-1] if T > 2 else -1)
+            assert eng.last_ld_variant() == 2 and eng.ld_layout() == (2 if tiles == 1 else 1)
+            out[tiles] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(len(targets))]
+    for i, t in enumerate(targets):
+        assert_bits(out[1][i][0], out[-1][i][0], f"t={t} per-row values")
+        assert_bits(out[1][i][1], out[-1][i][1], f"t={t} windows")
+    for i in sorted({0, len(targets) - 1}):
+        res = oracle.compare(alle, nr, na, targets[i], window=W, ld=True, pu_id=targets[-1] if T > 2 else -1, max_cov=M)
+        assert_bits(out[1][i][0], res["site"], "site")
+        assert_bits(out[1][i][1][:, 2], res["win"][:, 2], "LIBD2")
+        assert_ld_close(out[1][i][1][:, :2], res["win"][:, :2], f"compacted tiles t={targets[i]}")
+
+
+def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
+    """A run with "compact_targets" or more comparison individuals re-lays the site list out once (the site list belongs
+    to the pileup, src/ibdgem.c:522); later runs on the same upload keep the compacted tiles; results unchanged."""
+    N, L = 200, 3000
+    alle, nr, na = synth(4242, L, N)
+    targets = list(range(3, 3 + 20))
+    with E.Engine() as eng:
+        eng.set_option("compact_targets", 16)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run(targets[:4], ld=True)
+        assert eng.ld_layout() == 1
+        four = [eng.window_ll(i) for i in range(4)]
+        eng.run(targets, ld=True)
+        assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2
+        many = [eng.window_ll(i) for i in range(len(targets))]
+        for i in (0, 7, 19):
+            res = oracle.compare(alle, nr, na, targets[i], window=100, ld=True)
+            assert_ld_close(many[i][:, :2], res["win"][:, :2], f"t={targets[i]}")
+            assert_bits(many[i][:, 2], res["win"][:, 2], "LIBD2")
+        eng.run(targets[:4], ld=True)
+        assert eng.ld_layout() == 2
+        for i in range(4):
+            assert_bits(eng.window_ll(i), four[i], f"four again, t={targets[i]}")
+        # a new upload starts from the panel's own tiles again
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        assert eng.ld_layout() == 1
 
 
 def test_dispatch_events_give_the_dominant_kernel_duration():
@@ -775,7 +852,7 @@ def test_two_contexts_taking_turns_give_the_bits_of_one(oracle):
 
 
 def test_rows_in_any_order_and_the_first_offending_site(oracle):
-    """Rows visited in a random order (several scan blocks, duplicates included) take the strict kernel and
+    """Rows visited in a random order (several scan blocks, duplicates included) go through the compacted tiles and
     still equal the oracle; errors name the first offending site in list order, its row before its counts."""
     N, Lp, L = 70, 3000, 10000
     alle, _, _ = synth(81, Lp, N)
@@ -788,7 +865,7 @@ def test_rows_in_any_order_and_the_first_offending_site(oracle):
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(rows, nr, na, 100)
         eng.run([1], ld=True)
-        assert eng.last_ld_variant() == 1
+        assert eng.last_ld_variant() == 2 and eng.ld_layout() == 2
         res = oracle.compare(alle[rows], nr, na, 1, window=100, ld=True)
         assert_bits(eng.site_ll(0), res["site"], "site")
         assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], "LD")

@@ -33,7 +33,9 @@ for case in range(n_cases):
     c = np.minimum(rng.poisson(cov, size=L), M)
     na = rng.binomial(c, f).astype(np.uint8)
     nr = (c - na).astype(np.uint8)
-    keep = np.sort(rng.choice(L, size=max(1, int(L * rng.choice([1.0, 1.0, 0.5, 0.05]))), replace=False))
+    keep = np.sort(rng.choice(L, size=max(1, int(L * rng.choice([1.0, 1.0, 0.5, 0.2, 0.05, 0.02, 0.005]))), replace=False))
+    if rng.random() < 0.1:
+        keep = rng.permutation(keep)                # rows out of file order: the compacted tiles (or the strict kernel)
     T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40]))     # 5 and more: the matrix-core kernel (k_ld_mfma)
     T = min(T, N)
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
@@ -44,16 +46,19 @@ for case in range(n_cases):
     if variant == 3 and bg is not None and rng.random() < 0.7:
         order = rng.permutation(np.repeat(np.arange(N), bg))        # the -B list in some file order
     opts = {}
+    tiles = int(rng.choice([0, 0, 1, -1]))         # tiles of the exponent-counting kernels: auto, compacted, the panel's own
     if rng.random() < 0.5:
         opts = {"ring_slots": int(rng.choice([2, 3, 4, 8])), "windows_per_wave": int(rng.choice([1, 2, 5, 16, 64])),
                 "guided_runs": int(rng.choice([0, 1, 4, 16])), "multi_target": int(rng.choice([0, 1])),
                 "mfma_targets": int(rng.choice([0, 1, 1])), "mfma_min": int(rng.choice([1, 2, 8, 15]))}
-    desc = f"case {case}: N={N} L={L} keep={len(keep)} W={W} eps={eps} M={M} cov={cov} T={T} bg={'y' if bg is not None else 'n'} pu={pu} variant={variant} {opts}"
+    desc = f"case {case}: N={N} L={L} keep={len(keep)} W={W} eps={eps} M={M} cov={cov} T={T} bg={'y' if bg is not None else 'n'} pu={pu} variant={variant} tiles={tiles} {opts}"
     try:
         with E.Engine(0, eps, M) as eng:
             for k, v in opts.items():
                 eng.set_option(k, v)
             eng.set_option("ld_variant", variant)
+            eng.set_option("compact_tiles", tiles)
+            eng.set_option("compact_targets", int(rng.choice([3, 8, 96])))
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
             eng.set_background_order(order)
