@@ -366,6 +366,77 @@ def upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, targe
     return up, ec, d2h
 
 
+def sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, target, many_t, seed):
+    """The reference's real inputs are thin pileups (low-coverage ancient DNA): a panel row without a pileup line
+    never reaches the window loop (src/ibdgem.c:596-601), and every row that does costs the same (:669-722).
+    Engine clock -- site arrays resident in HBM -> window tables in host memory: ibdg_upload_sites_dev (site
+    preparation AND the gather + transposition of the compacted tiles inside) + ibdg_run + ibdg_get_window_ll of
+    every comparison individual -- with a pileup on 10 % and on 2 % of this rank's panel rows, one comparison
+    individual and many; beside it the same with the compacted tiles forbidden (option compact_tiles -1: what
+    round 3 did with such a pileup -- the strict fp64 kernel), and the largest relative difference between the two
+    window tables."""
+    n = len(n_ref)
+    rng = np.random.default_rng(seed + 77)
+    out = {}
+    for share in (0.10, 0.02):
+        rows = np.sort(rng.choice(n, size=int(n * share), replace=False)).astype(np.uint32)
+        nr, na = n_ref[rows].copy(), n_alt[rows].copy()
+        nr[(nr.astype(np.int32) + na) == 0] = 1            # a pileup line means a read
+        k = len(rows)
+        d_idx = torch.from_numpy(rows.view(np.int32)).cuda()
+        d_nr, d_na = torch.from_numpy(nr).cuda(), torch.from_numpy(na).cuda()
+        torch.cuda.synchronize()
+        leg = {"panel_rows": int(n), "pileup_rows": int(k), "windowed_sites": int(k)}
+        for name, tg in (("one_individual", [target]), ("many_individuals", many_t)):
+            T = len(tg)
+            res = {}
+            tables = {}
+            for tiles in (0, -1):
+                eng.set_option("compact_tiles", tiles)
+                eng.set_option("async", 1)
+                eng.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), k, window)
+                n_win = eng.n_windows
+                pin = ibdgem_amd.PinnedArray((T, n_win, 3), np.float64)
+
+                def once():
+                    eng.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), k, window)
+                    eng.run(tg, ld=True)
+                    for i in range(T):
+                        eng.window_ll(i, out=pin.array[i])
+                for _ in range(3):
+                    once()
+                ms = []
+                for _ in range(5 if tiles < 0 and T > 1 else 10):
+                    t0 = time.perf_counter()
+                    once()
+                    ms.append((time.perf_counter() - t0) * 1e3)
+                eng.set_option("async", 0)
+                c = eng.upload_ms()
+                r = eng.last_run_ms()
+                tables[tiles] = pin.array.copy()
+                pin.close()
+                res["compacted_tiles" if tiles == 0 else "compacted_tiles_forbidden"] = {
+                    "ms": min(ms), "median_ms": float(np.median(ms)),
+                    "site_individual_pairs_per_s": k * T / (min(ms) * 1e-3),
+                    "ld_variant": eng.last_ld_variant(), "ld_layout": eng.ld_layout(), "windows": int(n_win),
+                    "upload_device_prep_ms": c["device_prep"], "ld_launches_ms": r["ld"], "rows_kernel_ms": r["rows"]}
+            a, b = tables[0][..., :2], tables[-1][..., :2]
+            big = np.abs(b) >= 1e-290
+            res["max_rel_diff_of_the_two"] = float((np.abs(a[big] - b[big]) / np.abs(b[big])).max()) if big.any() else 0.0
+            res["libd2_bits_equal"] = bool(np.array_equal(tables[0][..., 2], tables[-1][..., 2]))
+            res["speedup"] = res["compacted_tiles_forbidden"]["ms"] / res["compacted_tiles"]["ms"]
+            res["comparison_individuals"] = T
+            leg[name] = res
+        out[f"pileup_on_{int(share * 100)}pct_of_rows"] = leg
+        del d_idx, d_nr, d_na
+    eng.set_option("compact_tiles", 0)
+    out["note"] = ("engine clock (host wall, best of 10 after 3 untimed; upload_sites_dev + run + every window table to page-locked "
+                   "memory, option async), the re-layout inside it; ld_variant 2 = exponent counting / matrix cores, 1 = strict fp64 "
+                   "products; ld_layout 2 = compacted window-aligned tiles of the site list, 1 = the panel's own tiles")
+    return out
+
+
+
 def valu_roofline(launch_ms, n_win, n_chunks):
     """The second roofline of the dominant kernel: VALU issue.
     Instructions per launch come from the committed PMC passes of this very workload (profiles/*_ld_pmc.json,
@@ -390,7 +461,7 @@ def valu_roofline(launch_ms, n_win, n_chunks):
     cyc = p["cycles_per_valu_instruction"]["value"]
     issue = k["SQ_INSTS_VALU"] * cyc / p["simds"]
     bound_ms = issue / p["nominal_clock_hz"] * 1e3
-    return {"bound": "valu-issue", "profile": fn, "valu_instructions_per_launch": k["SQ_INSTS_VALU"],
+    return {"bound": "valu-issue", "profile": fn, "instruction_counts_replayed_from_profile": True, "valu_instructions_per_launch": k["SQ_INSTS_VALU"],
             "valu_instructions_per_window_and_chunk": d["valu_per_window_chunk"],
             "cycles_per_instruction": cyc, "simds": p["simds"], "issue_cycles_per_simd": issue,
             "kernel_cycles_profiled": d["kernel_cycles"], "frac_of_kernel_cycles": issue / d["kernel_cycles"],
@@ -599,7 +670,7 @@ def traffic_bytes(args, world):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/*_ld_traffic.json, tools/pmc_traffic.sh) when they were taken on this very
     workload; None otherwise (counters cannot be read from inside the process)."""
-    best = None
+    best, src = None, None
     pdir = os.path.join(REPO, "profiles")
     for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not fn.endswith("_ld_traffic.json"):
@@ -608,8 +679,8 @@ def traffic_bytes(args, world):
             t = json.load(fh)
         c = t.get("config", {})
         if world == 1 and (c.get("sites"), c.get("n_ids"), c.get("window")) == (args.sites, args.ids, args.window):
-            best = t.get("dominant_kernel_hbm_bytes_per_launch")
-    return best
+            best, src = t.get("dominant_kernel_hbm_bytes_per_launch"), fn
+    return best, src
 
 
 # ----------------------------------------------------------------------------- main
@@ -887,6 +958,22 @@ def main():
             ms = eng.last_run_ms()
             best0 = ms if best0 is None or ms["total"] < best0["total"] else best0
         eng.set_option("site_results", 1)
+        # the same run from the compacted, window-aligned tiles of the site list (the engine switches by itself from
+        # "compact_targets" = 96 comparison individuals; forced here): the re-layout is paid once, inside the first run
+        eng.set_option("compact_targets", 1)
+        eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
+        eng.sync()
+        t_c = time.perf_counter()
+        eng.run(many_t, ld=True)
+        first_c_ms = (time.perf_counter() - t_c) * 1e3
+        layout_c = eng.ld_layout()
+        best_c = None
+        for _ in range(3):
+            eng.run(many_t, ld=True)
+            ms = eng.last_run_ms()
+            best_c = ms if best_c is None or ms["total"] < best_c["total"] else best_c
+        eng.set_option("compact_targets", 96)
+        eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)      # back to the panel's own tiles
         b_site_T0 = args.ids / 4.0 + 4.0 + T * 0.24                  # ... without the 24 B per row and individual
         pmc = None
         pdir = os.path.join(REPO, "profiles")
@@ -905,6 +992,7 @@ def main():
                              "sites_per_launch": n_cov, "kernel_ms": best["ld"], "achieved": achieved_T, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved_T / HBM_PEAK_GBS,
                              "busy_shares_from_profile": pmc,
+                             "busy_shares_note": "replayed from the committed counter profile named in it, not measured by this run",
                              "note": "bytes_per_site = N/4 + 4 + T x 24.24 (SURVEY.md s8(d): the panel row once per launch, 24 B "
                                      "of per-row output per individual); kernel_ms = the --LD launches of the run (k_win_target_g, "
                                      "k_win_slot_g, k_ld_mfma, k_ld_finalize for all groups) from the engine's events.  This path is "
@@ -917,9 +1005,21 @@ def main():
                                             "device_memory_for_results_bytes": int(T * eng.n_windows * 24),
                                             "note": "option site_results 0: no T x rows x 24 B array, no per-row stores; LIBD2 of "
                                                     "the windows from the IBD2 pick of every row (k_rows_windows<false>)"},
+                "from_compacted_tiles": {"ld_layout": layout_c, "run_ms": best_c["total"], "ms_per_individual": best_c["total"] / T,
+                                         "ld_launches_ms": best_c["ld"],
+                                         "first_run_wall_ms_with_the_relayout_inside": first_c_ms,
+                                         "relayout_pays_from_individuals": (
+                                             (first_c_ms - best_c["total"]) / max(1e-9, (best["total"] - best_c["total"]) / T)
+                                             if best["total"] > best_c["total"] else None),
+                                         "note": "rows with reads gathered and transposed into tiles that start with their window: 4 "
+                                                 "segments per window of 100 rows instead of 4.6, no rows without reads streamed"},
                 "note": "one ibdg_run over that many comparison individuals against the resident panel (device time, best of 3): "
                         "groups of 15 through k_ld_mfma -- the sums that depend on the comparison individual as integer matrix "
                         "products (DESIGN.md s4.2); per-site values and window products of all of them included"}
+    sparse = None
+    if world == 1 and not args.no_many:
+        sparse = sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, args.target, many_t, args.seed)
+        eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
     eng.run(targets, ld=True)
     win_full = eng.window_ll(0) if rank == 0 else None
     ld_variant = eng.last_ld_variant()
@@ -966,7 +1066,11 @@ def main():
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world)[0],
+                         "traffic_from_profile": traffic_bytes(args, world)[1],
+                         "traffic_note": "replayed, not measured by this run: counter bytes per launch of the committed PMC passes "
+                                         "of this workload (the file named in traffic_from_profile); counters cannot be read from "
+                                         "inside the process",
                          "bytes_per_site": b_site, "sites_per_launch": n_cov, "kernel_ms": dom_ms,
                          "kernel_ms_note": "achieved = bytes_per_site x sites_per_launch / kernel_ms; kernel_ms = "
                                            "dominant_kernel_only_ms when the kernel could be timed alone, else launch_ms",
@@ -994,6 +1098,7 @@ def main():
             "per_rank": per_rank,
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "many_comparison_individuals": many,
+            "sparse_pileup": sparse,
             "non_ld": non_ld,
             "rows_per_s_all_processed": rows_total / (dt_max / args.steps),
         }

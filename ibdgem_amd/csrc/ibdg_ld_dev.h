@@ -98,6 +98,13 @@ __device__ __forceinline__ uint4 lds_read_b128(uint32_t addr)
     return v;
 }
 
+__device__ __forceinline__ uint2 lds_read_b64(uint32_t addr)
+{
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, uint32_t addr1)
 {
     asm volatile("ds_read_b128 %0, %2\n\t"

@@ -24,9 +24,12 @@
 //     A operand: 16 bytes per lane of the segment's target image (k_win_target_g: weight of row r for target
 //                haplotype m, rows outside the window 0), a coalesced 1 KiB load two segments ahead;
 //     two MFMAs (x0 and x1) accumulate into 2 x 16 registers;  C(x0 & x1) by and + popcount as before.
-//   per window: result register pair i of lane half h holds G(x, t0), G(x, t1) of comparison individual
-//     slot(h, i) for the lane's background individual, so every lane finishes 8 (individual, comparison
-//     individual) pairs without any exchange.  The exponents of a product are (header of ibdg_ld_popcount.hip)
+//   per window: target-haplotype row m of the operand is haplotype (m >> 2) & 1 of slot (m & 3) + 4 (m >> 3), so
+//     result register r of lane half h holds G(x, t_h) of comparison individual r for the lane's background
+//     individual: a lane finishes its individual against ONE haplotype of all 16 slots, the two halves of the wave
+//     the two haplotypes.  The B operand carries 16 for a set bit, so a register IS 16 G(x,t) -- the byte offset of
+//     tau^G in a table of 16-byte entries that sits at LDS address 0: no instruction forms a look-up address.
+//     The exponents of a product are (header of ibdg_ld_popcount.hip)
 //         E2 = AT - <t,alt> - A(x) + G(x,t),   E3 = <t,cov> + C(x) - 2 G(x,t),
 //     so with tau = rho / sigma^2 = 4 eps (1-eps) the product factors into three parts,
 //         K' rho^E2 sigma^E3 = [K' rho^(AT - A(x)) sigma^C(x)] . [rho^-<t,alt> sigma^<t,cov>] . tau^G(x,t)
@@ -34,9 +37,12 @@
 //     V_x once per (background haplotype, window) in the lane, U_t once per (comparison haplotype, window) from
 //     k_win_slot_g, and ONE table look-up per product (the unfactored form needs two and eight address
 //     computations per comparison individual): Q(x0,t) + Q(x1,t) = mU_t . (V_x0 tau^G0 + V_x1 tau^G1 scaled by
-//     2^eU_t), everything as mantissa and integer exponent until one ldexp per product.  The eight addends of a lane
-//     go to the wave's LDS strip as they are finished, and the sums over the 32 lanes of each half come from
-//     reading the strip transposed (eight values per lane, then two exchange steps): 13 vector instructions
+//     2^eU_t), everything as mantissa and integer exponent until one ldexp per product.  mU_t does not depend on the
+//     background individual, so it is applied AFTER the sum over the background: a lane's addend for slot r is
+//     ldexp(mV0 mtau0, eV0 + etau0 + eU) + ldexp(mV1 mtau1, eV1 + etau1 + eU) -- three vector instructions per
+//     product -- and the two haplotypes' sums meet as mU_t0 S_0 + mU_t1 S_1 in the lanes that store.  A lane's
+//     addends go to the wave's LDS strip, eight slots per turn, and the sums over the 32 lanes of each half come
+//     from reading the strip transposed (eight values per lane, then two exchange steps): 13 vector instructions
 //     where a reduction in registers took 51.  The two halves of a chunk are added by k_ld_finalize
 //     (halves = 1).  The association of the products and the order of the sums differ from the counting kernels',
 //     so the results agree with theirs (and the oracle's) to ~1e-14, not bit for bit; the bar is 1e-10.
@@ -59,16 +65,19 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr uint32_t TG = IBDG_TG;     // comparison individuals per group
 constexpr uint32_t PSEUDO = 15;      // the slot whose two rows are the weights: row 30 = cov, row 31 = alt
 
-// Result register pair i (registers 2i, 2i+1) of lane half h holds rows (2i & 3) + 8 (2i >> 2) + 4 h (+1) of
-// the product, i.e. target-haplotype rows 2 slot, 2 slot + 1 of:
-__device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t i) { return 4 * (i >> 1) + 2 * h + (i & 1); }
+// Result register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of the product (tools/ubench/
+// mfma_i8_layout.hip).  Operand row m is therefore given to
+//     target haplotype (m >> 2) & 1 of slot (m & 3) + 4 (m >> 3):
+// register r = slot r, lane half = haplotype.
+__device__ __forceinline__ uint32_t row_slot(uint32_t m) { return (m & 3) + 4 * (m >> 3); }
+__device__ __forceinline__ uint32_t row_hap(uint32_t m) { return (m >> 2) & 1; }
 
 // ---------------------------------------------------------------------------
 // Per group of comparison individuals: (1) the A operand of every segment,
-//     aimg[group][segment][lane l] = 16 bytes: row m = l & 31 (slot m >> 1, target haplotype m & 1),
+//     aimg[group][segment][lane l] = 16 bytes: row m = l & 31 (slot row_slot(m), target haplotype row_hap(m)),
 //     byte j of dword d = weight of tile row 4 (l >> 5) + d + 8 j (the order in which a shift and the mask
 //     0x01010101 take the background bits out of a tile word):  cov_r where the target haplotype carries the
-//     alt allele on a row of the segment, else 0; slot 15: cov_r (row 30) and alt_r (row 31) themselves;
+//     alt allele on a row of the segment, else 0; slot 15: cov_r (row 27) and alt_r (row 31) themselves;
 // (2) per window and slot the four table offsets 16<t0,cov> 16<t1,cov> 16(AT-<t0,alt>) 16(AT-<t1,alt>)
 //     (k_win_target's window constants).
 // ---------------------------------------------------------------------------
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
     if (i < (size_t)a.n_segs * 64) {
         // a wave per segment: the segment's masks are wave-uniform (scalar loads)
         const uint32_t s = __builtin_amdgcn_readfirstlane((uint32_t)(i >> 6));
-        const uint32_t l = (uint32_t)i & 63, m = l & 31, kb = l >> 5, q = m >> 1, th = m & 1;
+        const uint32_t l = (uint32_t)i & 63, m = l & 31, kb = l >> 5, q = row_slot(m), th = row_hap(m);
         const Seg &S = a.segs[s];
         uint32_t sel = 0;                       // rows of the tile that count in this row of the operand
         const bool use_alt = q == PSEUDO && th;
@@ -142,17 +151,21 @@ __global__ __launch_bounds__(256) void k_win_slot_g(MfmaArgs a)
         a1alt += __shfl_xor(a1alt, m);
     }
     if (l < 16) {
-        uint4 um = make_uint4(0, 0, 0, 0), ue = um;       // empty slots: U = 0
+        // per window 32 uint4: [0..3] the exponents of U_t0 of slots 0..15, [4..7] of U_t1, [8 + q] the two mantissas of slot q
+        uint4 um = make_uint4(0, 0, 0, 0);                // empty slots: U = 0
+        int e0 = 0, e1 = 0;
         if (real) {
             const PowEntry r0 = a.pow_1me[a0alt], r1 = a.pow_1me[a1alt], s0 = a.pow_eps[a0cov], s1 = a.pow_eps[a1cov];
             const double m0 = s0.m / r0.m, m1 = s1.m / r1.m;
             um = make_uint4((uint32_t)__double2loint(m0), (uint32_t)__double2hiint(m0), (uint32_t)__double2loint(m1),
                             (uint32_t)__double2hiint(m1));
-            ue = make_uint4((uint32_t)(s0.e - r0.e), (uint32_t)(s1.e - r1.e), 0, 0);
+            e0 = s0.e - r0.e;
+            e1 = s1.e - r1.e;
         }
-        uint4 *dst = a.wc_slot + (((size_t)grp * a.n_win + w) * 16 + q) * 2;
-        dst[0] = um;
-        dst[1] = ue;
+        uint4 *dst = a.wc_slot + ((size_t)grp * a.n_win + w) * 32;
+        dst[8 + q] = um;
+        reinterpret_cast<int *>(dst)[q] = e0;
+        reinterpret_cast<int *>(dst)[16 + q] = e1;
     }
 }
 
@@ -208,56 +221,43 @@ __device__ __forceinline__ void slots_swap(uint2 &x0, uint4 &a0, uint2 &x1, uint
     reg_swap(a0.w, a1.w);
 }
 
-// mU0 (q00 + q01) + mU1 (q10 + q11): the reference's ((Q00 + Q01) + Q10) + Q11 (ibdgem.c:716-719, :744-745) up to
-// the association, from the slot's U constants and the four tau^G entries
-__device__ __forceinline__ double comp_value(const uint4 &um, const uint2 &ue, const uint4 &p0, const uint4 &p1, const uint4 &p2,
-                                             const uint4 &p3, double mV0, double mV1, int eV0, int eV1)
+// Four slots of the lane (registers R0 .. R0 + 3 of the two accumulators = the byte offsets of tau^G(x0,t), tau^G(x1,t)
+// in the table at LDS address TAU0) per LDS round trip: eight reads in one statement.  At four waves per SIMD a
+// round trip is not hidden by other waves.  out[j] = V_x0 tau^G0 + V_x1 tau^G1 scaled by 2^eU of slot R0 + j: the
+// reference's Q(x0,t) + Q(x1,t) of ibdgem.c:716-719 without the mantissa of U_t (applied after the sum over the
+// background, which it does not depend on).
+template <int R0>
+__device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mV0, double mV1, int eV0,
+                                          int eV1, double (&out)[4])
 {
-    const double mU0 = __hiloint2double((int)um.y, (int)um.x), mU1 = __hiloint2double((int)um.w, (int)um.z);
-    const int eU0 = (int)ue.x, eU1 = (int)ue.y;
-    const double q00 = __builtin_ldexp(mV0 * __hiloint2double((int)p0.y, (int)p0.x), eV0 + (int)p0.z + eU0);   // x0, t0
-    const double q01 = __builtin_ldexp(mV1 * __hiloint2double((int)p1.y, (int)p1.x), eV1 + (int)p1.z + eU0);   // x1, t0
-    const double q10 = __builtin_ldexp(mV0 * __hiloint2double((int)p2.y, (int)p2.x), eV0 + (int)p2.z + eU1);   // x0, t1
-    const double q11 = __builtin_ldexp(mV1 * __hiloint2double((int)p3.y, (int)p3.x), eV1 + (int)p3.z + eU1);   // x1, t1
-    return mU0 * (q00 + q01) + mU1 * (q10 + q11);
-}
-
-// Two comparison individuals of the lane (register pairs I and I + 1 of the two accumulators) per LDS round trip:
-// twelve reads in one statement -- per individual the slot's two mantissas and two exponents (immediate offsets
-// from the lane's slot base) and four tau^G entries.  At four waves per SIMD a round trip is not hidden by other
-// waves; one per individual (eight per window) cost 11 % more than one per two.
-template <int I>
-__device__ __forceinline__ void comp_pair(const v16i &acc0, const v16i &acc1, uint32_t slot_base, uint32_t tab_tau, double mV0,
-                                          double mV1, int eV0, int eV1, double &ra, double &rb)
-{
-    constexpr int OFA = 128 * (I >> 1) + 32 * (I & 1);        // slot_of(h, I) * 32 bytes, the 2 h part is in slot_base
-    constexpr int OFB = 128 * ((I + 1) >> 1) + 32 * ((I + 1) & 1);
-    const uint32_t a0 = lshl4_add_s((uint32_t)acc0[2 * I], tab_tau), a1 = lshl4_add_s((uint32_t)acc1[2 * I], tab_tau);
-    const uint32_t a2 = lshl4_add_s((uint32_t)acc0[2 * I + 1], tab_tau), a3 = lshl4_add_s((uint32_t)acc1[2 * I + 1], tab_tau);
-    const uint32_t b0 = lshl4_add_s((uint32_t)acc0[2 * I + 2], tab_tau), b1 = lshl4_add_s((uint32_t)acc1[2 * I + 2], tab_tau);
-    const uint32_t b2 = lshl4_add_s((uint32_t)acc0[2 * I + 3], tab_tau), b3 = lshl4_add_s((uint32_t)acc1[2 * I + 3], tab_tau);
-    uint4 uma, pa0, pa1, pa2, pa3, umb, pb0, pb1, pb2, pb3;
-    uint2 uea, ueb;
-    asm volatile("ds_read_b128 %0, %12 offset:%21\n\t"
-                 "ds_read_b64 %1, %12 offset:%22\n\t"
-                 "ds_read_b128 %2, %13\n\t"
-                 "ds_read_b128 %3, %14\n\t"
-                 "ds_read_b128 %4, %15\n\t"
-                 "ds_read_b128 %5, %16\n\t"
-                 "ds_read_b128 %6, %12 offset:%23\n\t"
-                 "ds_read_b64 %7, %12 offset:%24\n\t"
-                 "ds_read_b128 %8, %17\n\t"
-                 "ds_read_b128 %9, %18\n\t"
-                 "ds_read_b128 %10, %19\n\t"
-                 "ds_read_b128 %11, %20\n\t"
+    uint4 p[8], eu;              // eu: the exponents of U of the four slots (wave-half uniform address: a broadcast read)
+#ifdef IBDG_EXP_NOTAU
+    for (int i = 0; i < 8; ++i) p[i] = make_uint4((uint32_t)acc0[R0 + (i >> 1)], 0x3fe00000u, (uint32_t)acc1[R0 + (i >> 1)] & 3, 0);
+    eu = make_uint4(eu_addr & 1, 0, 1, 0);
+#else
+    asm volatile("ds_read_b128 %0, %9\n\t"
+                 "ds_read_b128 %1, %10\n\t"
+                 "ds_read_b128 %2, %11\n\t"
+                 "ds_read_b128 %3, %12\n\t"
+                 "ds_read_b128 %4, %13\n\t"
+                 "ds_read_b128 %5, %14\n\t"
+                 "ds_read_b128 %6, %15\n\t"
+                 "ds_read_b128 %7, %16\n\t"
+                 "ds_read_b128 %8, %17 offset:%18\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(uma), "=&v"(uea), "=&v"(pa0), "=&v"(pa1), "=&v"(pa2), "=&v"(pa3), "=&v"(umb), "=&v"(ueb), "=&v"(pb0),
-                   "=&v"(pb1), "=&v"(pb2), "=&v"(pb3)
-                 : "v"(slot_base), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(OFA), "n"(OFA + 16),
-                   "n"(OFB), "n"(OFB + 16)
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(eu)
+                 : "v"(acc0[R0]), "v"(acc1[R0]), "v"(acc0[R0 + 1]), "v"(acc1[R0 + 1]), "v"(acc0[R0 + 2]), "v"(acc1[R0 + 2]),
+                   "v"(acc0[R0 + 3]), "v"(acc1[R0 + 3]), "v"(eu_addr), "n"(4 * R0)
                  : "memory");
-    ra = comp_value(uma, uea, pa0, pa1, pa2, pa3, mV0, mV1, eV0, eV1);
-    rb = comp_value(umb, ueb, pb0, pb1, pb2, pb3, mV0, mV1, eV0, eV1);
+#endif
+    const int e[4] = {(int)eu.x, (int)eu.y, (int)eu.z, (int)eu.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint4 &p0 = p[2 * j], &p1 = p[2 * j + 1];
+        const double q0 = __builtin_ldexp(mV0 * __hiloint2double((int)p0.y, (int)p0.x), eV0 + (int)p0.z + e[j]);
+        const double q1 = __builtin_ldexp(mV1 * __hiloint2double((int)p1.y, (int)p1.x), eV1 + (int)p1.z + e[j]);
+        out[j] = q0 + q1;
+    }
 }
 
 // addend I of the lane into the wave's reduction strip: row (8 h + I), column n
@@ -270,6 +270,29 @@ __device__ __forceinline__ void strip_put(uint32_t put_addr, double v)
 // Lane L = 4 s + p adds the elements p, p + 4, ..., p + 28 of row s (a wave's LDS operations execute in order: the
 // reads see the writes of strip_put); two exchange steps within the quad finish the row.  Every lane of quad s
 // ends up with the sum of row s = the sum over the 32 lanes of half s >> 3 of their addend s & 7.
+// the same with one more read in the round trip: the lane's U mantissa (8 bytes at mu_addr)
+__device__ __forceinline__ double strip_sum_mu(uint32_t get_addr, uint32_t mu_addr, double &mu)
+{
+    double r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("ds_read_b64 %0, %9\n\t"
+                 "ds_read_b64 %1, %9 offset:32\n\t"
+                 "ds_read_b64 %2, %9 offset:64\n\t"
+                 "ds_read_b64 %3, %9 offset:96\n\t"
+                 "ds_read_b64 %4, %9 offset:128\n\t"
+                 "ds_read_b64 %5, %9 offset:160\n\t"
+                 "ds_read_b64 %6, %9 offset:192\n\t"
+                 "ds_read_b64 %7, %9 offset:224\n\t"
+                 "ds_read_b64 %8, %10\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(mu)
+                 : "v"(get_addr), "v"(mu_addr)
+                 : "memory");
+    double t = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    t = t + swz_get<1>(t);
+    t = t + swz_get<2>(t);
+    return t;
+}
+
 __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 {
     double r0, r1, r2, r3, r4, r5, r6, r7;
@@ -320,12 +343,16 @@ void k_ld_mfma(MfmaArgs a)
     if (seg1 == seg0)
         return;
 
-    uint4 *wcc = reinterpret_cast<uint4 *>(smem);                  // [win_per_group] eK, 16 AT + rho table, sigma table, segment end
-    uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][16 slots][2] U mantissas | U exponents
-    uint4 *tab = wcs + (size_t)a.win_per_group * 32;                // rho^n, sigma^n, tau^n
-    uint4 *rec = tab + 3 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
+    // The tau table comes first: the kernel has no static LDS, so the table sits at LDS address 0 and the accumulators --
+    // 16 G -- are its entries' addresses as they are (hipcc itself folds the table's address to the constant 0; every
+    // parity test of this kernel would fail if that ever changed).
+    uint4 *tau = reinterpret_cast<uint4 *>(smem);                  // tau^n
+    uint4 *wcc = tau + a.tab_len;                                   // [win_per_group] eK, 16 AT + rho table, sigma table, segment end
+    uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][32]: exponents of U_t0 (4), of U_t1 (4), 16 x two mantissas
+    uint4 *tab = wcs + (size_t)a.win_per_group * 32;                // rho^n, sigma^n
+    uint4 *rec = tab + 2 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
     double *strip = reinterpret_cast<double *>(rec + 2 * (size_t)a.max_seg) + (size_t)wave * 16 * SS;   // this wave's
-    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16, tab3 = tab2 + a.tab_len * 16;
+    const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
         wcc[i] = make_uint4((uint32_t)W.eK, 16 * W.alt_total + tab1, tab2, a.wconst[w0 + i + 1].seg_begin);
@@ -335,15 +362,21 @@ void k_ld_mfma(MfmaArgs a)
         for (uint32_t i = threadIdx.x; i < (w1 - w0) * 32; i += blockDim.x)
             wcs[i] = src[i];
     }
-    for (uint32_t i = threadIdx.x; i < 3 * a.tab_len; i += blockDim.x)
-        tab[i] = i < a.tab_len ? reinterpret_cast<const uint4 *>(a.pow_1me)[i]
-                               : (i < 2 * a.tab_len ? reinterpret_cast<const uint4 *>(a.pow_eps)[i - a.tab_len]
-                                                    : reinterpret_cast<const uint4 *>(a.pow_tau)[i - 2 * a.tab_len]);
+    for (uint32_t i = threadIdx.x; i < a.tab_len; i += blockDim.x) {
+        tau[i] = reinterpret_cast<const uint4 *>(a.pow_tau)[i];
+        tab[i] = reinterpret_cast<const uint4 *>(a.pow_1me)[i];
+        tab[a.tab_len + i] = reinterpret_cast<const uint4 *>(a.pow_eps)[i];
+    }
     // the run's segments: nothing in the loops below goes through the scalar path (a scalar load per segment
     // and its wait cost more than the segment's arithmetic)
+    // word 0 of a record: tile (< 2^24) of the segment TWO AHEAD (what the loop requests while it works on this one; the
+    // run's last tile at the end), bit 24 cov planes beyond three, bit 25 first, bit 26 last segment of its window
     for (uint32_t i = threadIdx.x; i < seg1 - seg0; i += blockDim.x) {
         const Seg &S = a.segs[seg0 + i];
-        rec[2 * i] = make_uint4(S.tile | (S.flags & 0xff0000u) << 8, S.cov[0], S.cov[1], S.cov[2]);   // tile < 2^24
+        const uint32_t ahead = seg0 + i + 2 < seg1 ? seg0 + i + 2 : seg1 - 1;
+        const uint32_t first = (i == 0 || a.segs[seg0 + i - 1].last) ? 1u << 25 : 0u;
+        const uint32_t deep = ((S.flags >> 16) & 0xff) > 3 ? 1u << 24 : 0u;
+        rec[2 * i] = make_uint4(a.segs[ahead].tile | deep | first | (S.last ? 1u << 26 : 0u), S.cov[0], S.cov[1], S.cov[2]);
         rec[2 * i + 1] = make_uint4(S.cov[3], S.cov[4], S.cov[5], S.cov[6]);
     }
     __syncthreads();
@@ -355,114 +388,101 @@ void k_ld_mfma(MfmaArgs a)
     const uint32_t indiv = 64 * c + 32 * (hc & 1) + n;               // the lane's background individual
     const double wgt = a.base_weight[indiv];
     const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
-    // bit i: slot_of(h, i) is the lane's own individual (no individual is in its own background, ibdgem.c:714)
+    // bit r: slot r is the lane's own individual (no individual is in its own background, ibdgem.c:714)
     uint32_t excl = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) {
-        const uint32_t q = slot_of(h, i);
-        if (q < cnt && q != PSEUDO && a.targets[a.t_base + grp * TG + q] == indiv)
-            excl |= 1u << i;
-    }
+    for (uint32_t q = 0; q < cnt; ++q)
+        if (a.targets[a.t_base + grp * TG + q] == indiv)
+            excl |= 1u << q;
     const uint4 *xt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64 + 32 * (hc & 1) + n;   // + pair * 64
     const uint4 *ai = a.aimg + (size_t)grp * a.n_segs * 64 + lane;                                              // + segment * 64
-    const uint32_t sh = 4 * h;
+    // B operand: 16 where the individual carries the alt allele on tile row 4 h + d + 8 j (byte j of dword d of lane
+    // half h): y = x << (4 - 4 h) has that bit at 4 + d + 8 j, so dword d = (y >> d) & 0x10101010
+    const uint32_t sh = 4 - 4 * h;
 
-    // the reduction strip: lane (h, n) puts its addend I at row 8 h + I, column n; lane L = 4 s + p reads row s
+    // the reduction strip: lane (h, n) puts its addend I of a turn at row 8 h + I, column n; lane L = 4 s + p reads row s
     const uint32_t put_addr = (uint32_t)(uintptr_t)(lds_void *)strip + (8 * h * SS + n) * 8;
     const uint32_t get_addr = (uint32_t)(uintptr_t)(lds_void *)strip + ((lane >> 2) * SS + (lane & 3)) * 8;
-    // row s = lane >> 2 belongs to half s >> 3 = h and register pair s & 7: lane p = 0 of the quad stores it
-    const uint32_t st_q = slot_of(h, (lane >> 2) & 7);
-    const bool st_ok = (lane & 3) == 0 && st_q < cnt && st_q != PSEUDO;
-    const size_t st_row = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2;                       // window 0
+    // row s = lane >> 2 is haplotype h = s >> 3 of slot (s & 7) + 8 turn; lane p = 0 of the quads of half 0 stores
+    const uint32_t st_q = (lane >> 2) & 7;
+    const bool st_lane = (lane & 35) == 0;                          // p = 0, h = 0
+    const bool st_ok0 = st_lane && st_q < cnt, st_ok1 = st_lane && st_q + 8 < cnt;      // (slot 15 never: cnt <= 15)
+    const size_t st_row0 = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2;    // window 0
+    const size_t st_row1 = (((size_t)(grp * TG + st_q + 8) * a.n_win) * n_half + hc) * 2;
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
-    const uint32_t n_iter = 2 * ((cnt + 3) / 4);                   // register pairs that hold comparison individuals
-    const uint32_t wcs_lane = (uint32_t)(uintptr_t)(lds_void *)wcs + 64 * h;     // + 512 per window: slots 2 h, 2 h + 1, ...
+    const uint32_t n_quads = (cnt + 3) / 4;                          // groups of four slots that hold comparison individuals
+    const uint32_t wcs_base = (uint32_t)(uintptr_t)(lds_void *)wcs;
+    const uint32_t eu_lane = wcs_base + 64 * h;                      // + 512 per window: the exponents of U_t(h) of slots 0..15
+    const uint32_t mu_lane = wcs_base + 128 + 16 * st_q + 8 * h;     // + 512 per window (+ 128 per turn): the mantissa of U_t(h) of the lane's row
 
-    uint32_t s = seg0;
     // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested two
-    // segments ahead, into two register slots used in turn (a queue that shifts costs six moves per segment):
-    // one segment of this kernel is a few hundred cycles of work, a load from L2 or HBM takes a multiple of that
-    // (one ahead: 0.40 ms per individual against 0.36; four: 0.40; six: 0.49 -- registers).
-    uint2 xq0 = make_uint2(0, 0), xq1 = xq0;
-    uint4 aq0 = make_uint4(0, 0, 0, 0), aq1 = aq0;
-    auto fetch = [&](uint32_t seg, uint2 &xq, uint4 &aq) {
-        const uint32_t tile = __builtin_amdgcn_readfirstlane(rec[2 * (seg - seg0)].x) & 0xffffffu;
+    // segments ahead, into two register slots that the segments of the RUN take in turn (segment s: slot s & 1,
+    // whatever window it belongs to; a queue that shifts costs six moves per segment): one segment of this kernel
+    // is a few hundred cycles of work, a load from L2 or HBM takes a multiple of that.  The loop is straight-line
+    // per segment -- every segment requests the one two ahead (at the end of the run: the last one again), its
+    // record says which tile that is -- so that hipcc can count the loads in flight (s_waitcnt vmcnt(2)); with the
+    // request under a condition, and the slots swapped after windows of an odd number of segments, it drained
+    // them all (vmcnt(0)) at every window start and every swap, and a segment paid three LDS round trips.
+    uint2 xq0, xq1;
+    uint4 aq0, aq1;
+    auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
         xq = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
         aq = ai[(size_t)seg * 64];
     };
-    fetch(seg0, xq0, aq0);
-    if (seg0 + 1 < seg1)
-        fetch(seg0 + 1, xq1, aq1);
+    {
+        const uint32_t t0 = a.segs[seg0].tile, s1 = seg0 + 1 < seg1 ? seg0 + 1 : seg0, t1 = a.segs[s1].tile;
+        fetch(seg0, t0, xq0, aq0);
+        fetch(s1, t1, xq1, aq1);
+    }
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t w = w0; w < w1; ++w) {
-        const uint4 kc = wcc[w - w0];
-        const uint32_t se = __builtin_amdgcn_readfirstlane(kc.w);
-        v16i acc0, acc1;
-        uint32_t CH;
-        // one segment from operand slot (xq, aq), which is refilled for segment s + 2; the first segment of a window
-        // starts the sums (zero as the matrix instruction's addend: no 32 registers to clear per window)
-        auto segment = [&](uint2 &xq, uint4 &aq, auto first) {
-            const uint2 x = xq;
-            const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
-            const uint4 r0 = rec[2 * (s - seg0)];
-            if (s + 2 < seg1)
-                fetch(s + 2, xq, aq);
-            // B operand: byte j of dword d of lane half kb = the individual's bit of row 4 kb + d + 8 j -- one shift
-            // and one mask per dword, no table
-            const uint32_t b0 = x.x >> sh, b1 = x.y >> sh;
-            const v4i B0 = {(int)(b0 & 0x01010101u), (int)((b0 >> 1) & 0x01010101u), (int)((b0 >> 2) & 0x01010101u),
-                            (int)((b0 >> 3) & 0x01010101u)};
-            const v4i B1 = {(int)(b1 & 0x01010101u), (int)((b1 >> 1) & 0x01010101u), (int)((b1 >> 2) & 0x01010101u),
-                            (int)((b1 >> 3) & 0x01010101u)};
-            const uint32_t hom = x.x & x.y;
-            uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
-            const uint32_t ncov = __builtin_amdgcn_readfirstlane(r0.x) >> 24;
-            if (ncov > 3) {                      // deep rows (cov >= 8): max_cov < 128, seven planes at most
-                const uint4 r1 = rec[2 * (s - seg0) + 1];
-                ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
-                      ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
-            }
-            if constexpr (decltype(first)::value) {
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, zero16, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, zero16, 0, 0, 0);
-                CH = ch;
-            } else {
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
-                CH += ch;
-            }
-        };
-        // Segments take the two operand slots in turn, slot 0 first in every window: two per turn of the loop, and
-        // after an odd number of segments the slots change places (six register moves per such window instead of
-        // six per segment for a queue that shifts).
-        if (s < se) {
-            segment(xq0, aq0, std::true_type());
-            ++s;
-            if (s < se) {
-                segment(xq1, aq1, std::false_type());
-                ++s;
-                while (s + 1 < se) {
-                    segment(xq0, aq0, std::false_type());
-                    ++s;
-                    segment(xq1, aq1, std::false_type());
-                    ++s;
-                }
-                if (s < se) {
-                    segment(xq0, aq0, std::false_type());
-                    ++s;
-                    slots_swap(xq0, aq0, xq1, aq1);
-                }
-            } else {
-                slots_swap(xq0, aq0, xq1, aq1);
-            }
-        } else {                                  // (every window has a covered row, hence a segment)
-            acc0 = acc1 = zero16;
-            CH = 0;
+    v16i acc0, acc1;
+    uint32_t CH;
+    uint32_t w = w0, s = seg0;
+    const uint32_t seg_last = seg1 - 1;
+    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec;
+    // one segment from operand slot (xq, aq), which is refilled for segment s + 2; the first segment of a window
+    // starts the sums (zero as the matrix instruction's addend: no 32 registers to clear per window)
+    auto segment = [&](uint2 &xq, uint4 &aq, auto first) {
+        const uint4 r0 = lds_read_b128(rec_addr);
+        const uint32_t ctl = __builtin_amdgcn_readfirstlane(r0.x);
+        const uint2 x = xq;
+        const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
+        const uint32_t b0 = x.x << sh, b1 = x.y << sh;
+        const v4i B0 = {(int)(b0 & 0x10101010u), (int)((b0 >> 1) & 0x10101010u), (int)((b0 >> 2) & 0x10101010u),
+                        (int)((b0 >> 3) & 0x10101010u)};
+        const v4i B1 = {(int)(b1 & 0x10101010u), (int)((b1 >> 1) & 0x10101010u), (int)((b1 >> 2) & 0x10101010u),
+                        (int)((b1 >> 3) & 0x10101010u)};
+        const uint32_t hom = x.x & x.y;
+        uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
+        if (ctl & (1u << 24)) {              // deep rows (cov >= 8): max_cov < 128, seven planes at most
+            const uint4 r1 = lds_read_b128(rec_addr + 16);
+            ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
+                  ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
         }
-
-        // ---- the window's end: every lane finishes its individual against 8 comparison individuals
-        const uint32_t C0 = from_upper_half((uint32_t)acc0[14]), a0 = from_upper_half((uint32_t)acc0[15]);
-        const uint32_t C1 = from_upper_half((uint32_t)acc1[14]), a1 = from_upper_half((uint32_t)acc1[15]);
+        rec_addr += 32;
+        ++s;
+        if constexpr (decltype(first)::value) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, zero16, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, zero16, 0, 0, 0);
+            CH = ch;
+        } else {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
+            CH += ch;
+        }
+        // the slot's refill is requested only now, behind the matrix instructions that read it: issued before them, the
+        // old and the new operand would both be live, hipcc would land the new one in other registers and move it over
+        // at the end of the loop body -- behind a wait for every load in flight (s_waitcnt vmcnt(0))
+#ifndef IBDG_EXP_NOFETCH
+        fetch(s + 1 < seg_last ? s + 1 : seg_last, ctl & 0xffffffu, xq, aq);         // (s has been advanced: the segment two ahead)
+#endif
+    };
+    auto window_end_all = [&]() {
+        const uint4 kc = wcc[w - w0];
+        // ---- the window's end: every lane finishes its individual against one haplotype of the 15 comparison individuals
+        // register 15 = the weights' own rows: 16 C(x) in the lower half of the wave, 16 A(x) in the upper
+        const auto w0s = __builtin_amdgcn_permlane32_swap((uint32_t)acc0[15], (uint32_t)acc0[15], false, false);
+        const auto w1s = __builtin_amdgcn_permlane32_swap((uint32_t)acc1[15], (uint32_t)acc1[15], false, false);
+        const uint32_t C0s = w0s[0], A0s = w0s[1], C1s = w1s[0], A1s = w1s[1];        // 16 C(x0), 16 A(x0), 16 C(x1), 16 A(x1)
         const int eK = (int)kc.x;
         double wP2, mV0, mV1;
         int eV0, eV1;
@@ -470,9 +490,11 @@ void k_ld_mfma(MfmaArgs a)
             // pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH, E2 = AT - a0 - a1 + CH;
             // V_x = K' rho^(AT - A(x)) sigma^C(x) with the lane's background multiplicity folded into its mantissa
             uint4 p1, p2, r0, s0, r1, s1;
-            const uint32_t ad1 = lshl_add<4>(CH - (a0 + a1), kc.y), ad2 = lshl_add<4>(mad24<-2>(CH, C0 + C1), kc.z);
-            const uint32_t ad3 = lshl_add<4>(0u - a0, kc.y), ad4 = lshl_add<4>(C0, kc.z);
-            const uint32_t ad5 = lshl_add<4>(0u - a1, kc.y), ad6 = lshl_add<4>(C1, kc.z);
+            uint32_t m32 = (uint32_t)-32;
+            asm volatile("" : "+v"(m32));
+            const uint32_t ad1 = lshl_add<4>(CH, kc.y - (A0s + A1s)), ad2 = mad24r(CH, m32, kc.z + (C0s + C1s));
+            const uint32_t ad3 = kc.y - A0s, ad4 = kc.z + C0s;
+            const uint32_t ad5 = kc.y - A1s, ad6 = kc.z + C1s;
             asm volatile("ds_read_b128 %0, %6\n\t"
                          "ds_read_b128 %1, %7\n\t"
                          "ds_read_b128 %2, %8\n\t"
@@ -489,29 +511,13 @@ void k_ld_mfma(MfmaArgs a)
             eV0 = eK + (int)r0.z + (int)s0.z;
             eV1 = eK + (int)r1.z + (int)s1.z;
         }
-        const uint32_t slot_base = wcs_lane + (w - w0) * 512;
-        // The IBD1 addends of the lane's eight comparison individuals (:744-745) go to the strip as they are finished
-        // (a short group occupies the first register pairs only: slots 4j .. 4j+3 are pairs 2j, 2j+1 of the two halves;
-        // the upper half's last pair are the weights' own rows, whose slot has U = 0).  In the few waves that hold one
-        // of the group's comparison individuals, that lane's addends for itself are left out: no individual is in its
-        // own background (ibdgem.c:714).
+        const uint32_t eu_addr = eu_lane + (w - w0) * 512, mu_addr = mu_lane + (w - w0) * 512;
+        // The IBD1 addends of the lane's slots (:744-745) go to the strip, eight slots per turn (a short group occupies the
+        // first registers only).  In the few waves that hold one of the group's comparison individuals, that lane's
+        // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
         auto window_end = [&](auto with_excl) {
             constexpr bool EX = decltype(with_excl)::value;
-#define IBDG_COMP2(I)                                                                                        \
-            if (I < n_iter) {                                                                                \
-                double va, vb;                                                                               \
-                comp_pair<I>(acc0, acc1, slot_base, tab3, mV0, mV1, eV0, eV1, va, vb);                       \
-                if (EX) {                                                                                    \
-                    va = (excl >> I) & 1 ? 0.0 : va;                                                         \
-                    vb = (excl >> (I + 1)) & 1 ? 0.0 : vb;                                                   \
-                }                                                                                            \
-                strip_put<I>(put_addr, va);                                                                  \
-                strip_put<I + 1>(put_addr, vb);                                                              \
-            }
-            IBDG_COMP2(0) IBDG_COMP2(2) IBDG_COMP2(4) IBDG_COMP2(6)
-#undef IBDG_COMP2
-            const double t1 = strip_sum(get_addr);
-            double t0;
+            double t0lo, t0hi;
             if (!EX) {
                 // the IBD0 addends are the same for all comparison individuals: one butterfly over the half
                 double s0 = wP2;
@@ -520,21 +526,88 @@ void k_ld_mfma(MfmaArgs a)
                 s0 = swz_add<4>(s0);
                 s0 = swz_add<8>(s0);
                 s0 = swz_add<16>(s0);
-                t0 = s0;
+                t0lo = t0hi = s0;
             } else {
-                // the IBD0 addend of a lane counts for all comparison individuals but itself: a second turn of the strip
-#define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> I) & 1 ? 0.0 : wP2);
+                // the IBD0 addend of a lane counts for all comparison individuals but itself: one turn of the strip, half h
+                // of the wave (the same individuals as the other half) for slots 8 h .. 8 h + 7
+#define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> (8 * h + I)) & 1 ? 0.0 : wP2);
                 IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
 #undef IBDG_PUT0
-                t0 = strip_sum(get_addr);
+                const double t = strip_sum(get_addr);          // quad s: slot s
+                t0lo = t;                                      // lanes 0..31: slots 0..7
+                const uint32_t lo = from_upper_half((uint32_t)__double2loint(t)), hi = from_upper_half((uint32_t)__double2hiint(t));
+                t0hi = __hiloint2double((int)hi, (int)lo);     // slots 8..15 in the lanes that store them
             }
-            if (st_ok)
-                *reinterpret_cast<double2 *>(a.partial + st_row + (size_t)w * n_half * 2) = make_double2(t0, t1);
+#define IBDG_QUAD(R0, EU)                                                                                    \
+            {                                                                                                \
+                double v[4];                                                                                 \
+                comp_quad<R0>(acc0, acc1, EU, mV0, mV1, eV0, eV1, v);                                        \
+                if (EX) {                                                                                    \
+                    v[0] = (excl >> (R0)) & 1 ? 0.0 : v[0];                                                  \
+                    v[1] = (excl >> (R0 + 1)) & 1 ? 0.0 : v[1];                                              \
+                    v[2] = (excl >> (R0 + 2)) & 1 ? 0.0 : v[2];                                              \
+                    v[3] = (excl >> (R0 + 3)) & 1 ? 0.0 : v[3];                                              \
+                }                                                                                            \
+                strip_put<(R0 & 7)>(put_addr, v[0]);                                                         \
+                strip_put<(R0 & 7) + 1>(put_addr, v[1]);                                                     \
+                strip_put<(R0 & 7) + 2>(put_addr, v[2]);                                                     \
+                strip_put<(R0 & 7) + 3>(put_addr, v[3]);                                                     \
+            }
+            // a turn's sums: quad s of half h holds S_h of slot (s & 7) + 8 turn; the lanes that store add the two haplotypes:
+            // mU_t0 S_0 + mU_t1 S_1 (the reference's ((Q00 + Q01) + Q10) + Q11 up to the association)
+#define IBDG_TURN_END(TURN, OK, ROW, T0)                                                                     \
+            {                                                                                                \
+                double mu;                                                                                   \
+                const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, mu);                           \
+                const double part = mu * S;                                                                  \
+                const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
+                const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
+                if (OK)                                                                                      \
+                    *reinterpret_cast<double2 *>(a.partial + ROW + (size_t)w * n_half * 2) =                 \
+                        make_double2(T0, part + __hiloint2double((int)phi, (int)plo));                       \
+            }
+            {
+                IBDG_QUAD(0, eu_addr)
+                if (n_quads > 1)
+                    IBDG_QUAD(4, eu_addr)
+                IBDG_TURN_END(0, st_ok0, st_row0, t0lo)
+            }
+            if (n_quads > 2) {
+                IBDG_QUAD(8, eu_addr)
+                if (n_quads > 3)
+                    IBDG_QUAD(12, eu_addr)
+                IBDG_TURN_END(1, st_ok1, st_row1, t0hi)
+            }
+#undef IBDG_QUAD
+#undef IBDG_TURN_END
         };
         if (any_excl)
             window_end(std::true_type());
         else
             window_end(std::false_type());
+        ++w;
+    };
+    // One window whose first segment finds its operands in slot (xa, aa); its segments take the two slots in turn.  Returns
+    // whether it had an odd number of segments: the next window then starts from the other slot -- the same code with the
+    // slots' roles exchanged (nothing moves: the loads in flight land where the next segments look for them).
+    auto window = [&](uint2 &xa, uint4 &aa, uint2 &xb, uint4 &ab) -> bool {
+        const uint32_t n_more = __builtin_amdgcn_readfirstlane(wcc[w - w0].w) - s - 1;     // segments behind the first
+        segment(xa, aa, std::true_type());
+        for (uint32_t i = n_more >> 1; i > 0; --i) {
+            segment(xb, ab, std::false_type());
+            segment(xa, aa, std::false_type());
+        }
+        if (n_more & 1)
+            segment(xb, ab, std::false_type());
+        window_end_all();
+        return !(n_more & 1);
+    };
+    while (w < w1) {
+        if (window(xq0, aq0, xq1, aq1)) {
+            // from slot 1 until another odd window brings the run back to slot 0
+            while (w < w1 && !window(xq1, aq1, xq0, aq0)) {
+            }
+        }
     }
 }
 
