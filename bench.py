@@ -959,7 +959,7 @@ def main():
             best0 = ms if best0 is None or ms["total"] < best0["total"] else best0
         eng.set_option("site_results", 1)
         # the same run from the compacted, window-aligned tiles of the site list (the engine switches by itself from
-        # "compact_targets" = 96 comparison individuals; forced here): the re-layout is paid once, inside the first run
+        # "compact_targets" = 256 comparison individuals; forced here): the re-layout is paid once, inside the first run
         eng.set_option("compact_targets", 1)
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
         eng.sync()
@@ -972,7 +972,7 @@ def main():
             eng.run(many_t, ld=True)
             ms = eng.last_run_ms()
             best_c = ms if best_c is None or ms["total"] < best_c["total"] else best_c
-        eng.set_option("compact_targets", 96)
+        eng.set_option("compact_targets", 256)
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)      # back to the panel's own tiles
         b_site_T0 = args.ids / 4.0 + 4.0 + T * 0.24                  # ... without the 24 B per row and individual
         pmc = None

@@ -169,7 +169,7 @@ struct ibdg_ctx {
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
     long opt_compact_density = 3;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
-    long opt_compact_targets = 96;   // ... or when a run has at least this many comparison individuals (the re-layout is paid once)
+    long opt_compact_targets = 256;  // ... or when a run has at least this many comparison individuals (the re-layout is paid once)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under

@@ -322,7 +322,7 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 // the run's segment records, a reduction strip per wave
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
 {
-    return (size_t)win_per_group * 33 * 16 + (size_t)tab_len * 48 + (size_t)max_seg * 32 +
+    return (size_t)win_per_group * 33 * 16 + (size_t)tab_len * 48 + ((size_t)max_seg + 1) * 32 +
            (size_t)IBDG_MFMA_WAVES * 16 * SS * 8;
 }
 
@@ -351,7 +351,7 @@ void k_ld_mfma(MfmaArgs a)
     uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][32]: exponents of U_t0 (4), of U_t1 (4), 16 x two mantissas
     uint4 *tab = wcs + (size_t)a.win_per_group * 32;                // rho^n, sigma^n
     uint4 *rec = tab + 2 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
-    double *strip = reinterpret_cast<double *>(rec + 2 * (size_t)a.max_seg) + (size_t)wave * 16 * SS;   // this wave's
+    double *strip = reinterpret_cast<double *>(rec + 2 * ((size_t)a.max_seg + 1)) + (size_t)wave * 16 * SS;   // this wave's
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
@@ -438,12 +438,14 @@ void k_ld_mfma(MfmaArgs a)
     uint32_t CH;
     uint32_t w = w0, s = seg0;
     const uint32_t seg_last = seg1 - 1;
-    uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec;
+    const uint4 *rec_p = rec;            // the record of the NEXT segment is read while this one is worked on
+    uint4 r_cur = rec_p[0];
     // one segment from operand slot (xq, aq), which is refilled for segment s + 2; the first segment of a window
     // starts the sums (zero as the matrix instruction's addend: no 32 registers to clear per window)
     auto segment = [&](uint2 &xq, uint4 &aq, auto first) {
-        const uint4 r0 = lds_read_b128(rec_addr);
+        const uint4 r0 = r_cur;
         const uint32_t ctl = __builtin_amdgcn_readfirstlane(r0.x);
+        r_cur = rec_p[2];                    // (behind the run's last record: a spare one, never used)
         const uint2 x = xq;
         const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
         const uint32_t b0 = x.x << sh, b1 = x.y << sh;
@@ -454,11 +456,11 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t hom = x.x & x.y;
         uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
         if (ctl & (1u << 24)) {              // deep rows (cov >= 8): max_cov < 128, seven planes at most
-            const uint4 r1 = lds_read_b128(rec_addr + 16);
+            const uint4 r1 = rec_p[1];
             ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
                   ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
         }
-        rec_addr += 32;
+        rec_p += 2;
         ++s;
         if constexpr (decltype(first)::value) {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, zero16, 0, 0, 0);
@@ -517,16 +519,19 @@ void k_ld_mfma(MfmaArgs a)
         // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
         auto window_end = [&](auto with_excl) {
             constexpr bool EX = decltype(with_excl)::value;
-            double t0lo, t0hi;
+            double t0lo = 0.0, t0hi = 0.0;
             if (!EX) {
-                // the IBD0 addends are the same for all comparison individuals: one butterfly over the half
-                double s0 = wP2;
-                s0 = s0 + swz_get<1>(s0);
-                s0 = s0 + swz_get<2>(s0);
-                s0 = swz_add<4>(s0);
-                s0 = swz_add<8>(s0);
-                s0 = swz_add<16>(s0);
-                t0lo = t0hi = s0;
+                // the IBD0 addends are the same for all comparison individuals: with more than eight of them the sum rides in
+                // the second turn's spare row (the 16th slot holds no individual); otherwise one butterfly over the half
+                if (n_quads <= 2) {
+                    double s0 = wP2;
+                    s0 = s0 + swz_get<1>(s0);
+                    s0 = s0 + swz_get<2>(s0);
+                    s0 = swz_add<4>(s0);
+                    s0 = swz_add<8>(s0);
+                    s0 = swz_add<16>(s0);
+                    t0lo = t0hi = s0;
+                }
             } else {
                 // the IBD0 addend of a lane counts for all comparison individuals but itself: one turn of the strip, half h
                 // of the wave (the same individuals as the other half) for slots 8 h .. 8 h + 7
@@ -559,6 +564,11 @@ void k_ld_mfma(MfmaArgs a)
             {                                                                                                \
                 double mu;                                                                                   \
                 const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, mu);                           \
+                if (!EX && TURN == 1) {                    /* row 7 = the IBD0 sum over the half: quad 7 has it */ \
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(S), 28);                         \
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(S), 28);                         \
+                    t0lo = t0hi = __hiloint2double(hi, lo);                                                  \
+                }                                                                                            \
                 const double part = mu * S;                                                                  \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
                 const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
@@ -566,17 +576,19 @@ void k_ld_mfma(MfmaArgs a)
                     *reinterpret_cast<double2 *>(a.partial + ROW + (size_t)w * n_half * 2) =                 \
                         make_double2(T0, part + __hiloint2double((int)phi, (int)plo));                       \
             }
+            if (n_quads > 2) {                         // slots 8..15 first (their turn brings the IBD0 sum along)
+                IBDG_QUAD(8, eu_addr)
+                if (n_quads > 3)
+                    IBDG_QUAD(12, eu_addr)
+                if (!EX)
+                    strip_put<7>(put_addr, wP2);
+                IBDG_TURN_END(1, st_ok1, st_row1, t0hi)
+            }
             {
                 IBDG_QUAD(0, eu_addr)
                 if (n_quads > 1)
                     IBDG_QUAD(4, eu_addr)
                 IBDG_TURN_END(0, st_ok0, st_row0, t0lo)
-            }
-            if (n_quads > 2) {
-                IBDG_QUAD(8, eu_addr)
-                if (n_quads > 3)
-                    IBDG_QUAD(12, eu_addr)
-                IBDG_TURN_END(1, st_ok1, st_row1, t0hi)
             }
 #undef IBDG_QUAD
 #undef IBDG_TURN_END
