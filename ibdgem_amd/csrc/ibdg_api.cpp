@@ -584,27 +584,57 @@ bool grow_pow_tables(ibdg_ctx *c, size_t need)
     return true;
 }
 
-// Wait until the preparation kernels have handed hand-over number `seq` of PrepInfo to the host's mirror: a poll of
-// one word in host memory, which the last workgroup of the stage writes -- no copy to queue, no stream to drain
-// (each of those is a round trip of 10-15 us; an upload has two).  The stream is asked now and then whether it
-// has died under us.
-int wait_info(ibdg_ctx *c, uint32_t seq)
+// Poll of one word in host memory until it holds `seq`; every 4096 spins `query` says whether the producer is still
+// at work (0 = yes, 1 = it has finished, anything else = it has failed) and the wall clock is looked at.
+// Returns 0 = the word arrived, 1 = the producer finished without writing it, 2 = timed out, < 0 = -(query's code).
+template <class Q>
+int poll_seq(const volatile uint32_t *flag, uint32_t seq, double timeout_s, Q query)
 {
-    const volatile uint32_t *flag = &c->info_h->seq;
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1; *flag != seq; ++spins) {
-        if ((spins & 0xfff) == 0) {
-            const hipError_t e = hipStreamQuery(c->stream);
-            if (e != hipErrorNotReady) {
-                if (*flag == seq)
-                    break;
-                if (e == hipSuccess)
-                    return fail(c, "[::] ERROR in ibdg_upload_sites: the site preparation finished without reporting");
-                return fail(c, "[::] ERROR in ibdg_upload_sites: %s", hipGetErrorString(e));
-            }
+        if ((spins & 0xfff) != 0)
+            continue;
+        const int q = query();
+        if (q != 0) {
+            if (*flag == seq)
+                break;
+            return q == 1 ? 1 : -q;
         }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            return *flag == seq ? 0 : 2;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return 0;
+}
+
+double wait_timeout_s()
+{
+    // ten seconds: a preparation stage is a few hundred microseconds of device work.  (IBDG_WAIT_TIMEOUT_MS: for tests.)
+    if (const char *e = getenv("IBDG_WAIT_TIMEOUT_MS"))
+        return atof(e) * 1e-3;
+    return 10.0;
+}
+
+// Wait until the preparation kernels have handed hand-over number `seq` of PrepInfo to the host's mirror: a poll of
+// one word in host memory, which the last workgroup of the stage writes -- no copy to queue, no stream to drain
+// (each of those is a round trip of 10-15 us; an upload has two).  The stream is asked now and then whether it
+// has died under us, and the poll is bounded by wall time: a stream that neither finishes nor fails (a wedged queue)
+// ends the call with an error instead of a host thread spinning for ever.  prep_dirty stays set on every failure.
+int wait_info(ibdg_ctx *c, uint32_t seq)
+{
+    hipError_t last = hipSuccess;
+    const int rc = poll_seq(&c->info_h->seq, seq, wait_timeout_s(), [&]() {
+        last = hipStreamQuery(c->stream);
+        return last == hipErrorNotReady ? 0 : (last == hipSuccess ? 1 : 2);
+    });
+    if (rc == 0)
+        return 0;
+    if (rc == 1)
+        return fail(c, "[::] ERROR in ibdg_upload_sites: the site preparation finished without reporting");
+    if (rc == 2)
+        return fail(c, "[::] ERROR in ibdg_upload_sites: the site preparation did not report within %.0f s (stream: %s)",
+                    wait_timeout_s(), hipGetErrorString(hipStreamQuery(c->stream)));
+    return fail(c, "[::] ERROR in ibdg_upload_sites: %s", hipGetErrorString(last));
 }
 
 // Segments, per-window constants, control words and power tables of the fast --LD kernel, built on
@@ -1829,6 +1859,31 @@ int ibdg_set_background_order(ibdg_ctx *c, const uint32_t *ids, size_t n)
     if (n && !ids) return fail(c, "[::] ERROR in ibdg_set_background_order: ids is NULL");
     c->bg_order.assign(ids, ids + n);
     return 0;
+}
+
+int ibdg_selftest(const char *what)
+{
+    if (!what)
+        return 1;
+    if (!strcmp(what, "wait_info")) {
+        // the three ways the bounded poll ends, without a device: the word arrives (from another thread); the producer
+        // reports completion / failure without having written it; neither -- the wall-clock bound
+        volatile uint32_t flag = 0;
+        std::thread setter([&]() {
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            flag = 7;
+        });
+        const int arrived = poll_seq(&flag, 7u, 5.0, []() { return 0; });
+        setter.join();
+        flag = 0;
+        const int done = poll_seq(&flag, 9u, 5.0, []() { return 1; });
+        const int failed = poll_seq(&flag, 9u, 5.0, []() { return 5; });
+        const auto t0 = std::chrono::steady_clock::now();
+        const int timed_out = poll_seq(&flag, 9u, 0.05, []() { return 0; });
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return (arrived == 0 && done == 1 && failed == -5 && timed_out == 2 && waited >= 0.05 && waited < 2.0) ? 0 : 2;
+    }
+    return 1;
 }
 
 int ibdg_sync(ibdg_ctx *c)

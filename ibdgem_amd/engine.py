@@ -48,6 +48,7 @@ SYMBOLS = {
     "ibdg_ld_layout": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "ibdg_set_background_order": (C.c_int, [_P, _P, C.c_size_t]),
+    "ibdg_selftest": (C.c_int, [C.c_char_p]),
     "ibdg_sync": (C.c_int, [_P]),
 }
 

@@ -1740,14 +1740,26 @@ typedef struct {
 
 static pthread_t g_dev_thread;
 static int g_dev_started;
+/* the panel uploads that run beside the filter chain (one thread per device, inside the GPU runtime) */
+static upload_job g_ups[64];
+static int g_n_ups, g_uploads_pending;
+static void outs_settle(int failing);
 
-/* exit() while another thread is inside the GPU runtime's start-up is asking for trouble: wait for it first */
+/* exit() while another thread is inside the GPU runtime -- its start-up, a panel upload -- is asking for trouble (the
+ * runtime's exit handlers would run under live GPU threads), and so is leaving while output threads are still writing:
+ * wait for every thread this program started first.  On a failing exit the output files that were opened but not
+ * yet emptied are emptied, so that no complete-looking table of an earlier run survives a run that failed. */
 static void quit(int code)
 {
     if (g_dev_started) {
         g_dev_started = 0;
         pthread_join(g_dev_thread, NULL);
     }
+    if (g_uploads_pending) {
+        g_uploads_pending = 0;
+        (void)uploads_join(g_ups, g_n_ups);
+    }
+    outs_settle(code != 0);
     exit(code);
 }
 
@@ -1837,7 +1849,30 @@ typedef struct {
     /* when it runs beside the main thread */
     pthread_t th;
     int running, failed;
+    int pending;                                /* the files are open and still hold whatever an earlier run left in them */
 } out_job;
+
+enum { OUT_SLOTS = 6 };
+static out_job g_outs[OUT_SLOTS];
+
+/* see quit(): join the output threads; when the run is failing, empty the files nobody got to */
+static void outs_settle(int failing)
+{
+    for (int k = 0; k < OUT_SLOTS; ++k) {
+        out_job *o = &g_outs[k];
+        if (o->running) {
+            o->running = 0;
+            pthread_join(o->th, NULL);
+        }
+        if (failing && o->pending && !opt_plan) {
+            o->pending = 0;
+            if (o->tab && !opt_summary_only && ftruncate(fileno(o->tab), 0) != 0)
+                fprintf(stderr, "[::] WARNING: could not empty an output file of %s.\n", o->tname);
+            if (o->sum && ftruncate(fileno(o->sum), 0) != 0)
+                fprintf(stderr, "[::] WARNING: could not empty an output file of %s.\n", o->tname);
+        }
+    }
+}
 
 static void *output_individual(void *arg)
 {
@@ -1852,6 +1887,7 @@ static void *output_individual(void *arg)
             fprintf(stderr, "[::] ERROR in compare_impute(): Cannot empty the output files of %s.\n", o->tname);
             return NULL;
         }
+        o->pending = 0;
         fprintf(tab, "# Entered command: %s\n\n", o->user_cmd);
     }
     /* header block (:144-152, :547-548) */
@@ -2107,8 +2143,7 @@ int main(int argc, char **argv)
         }
     }
     const int no_engine = opt_plan || host_math;
-    static upload_job ups[64];
-    int uploads_pending = 0;
+    upload_job *const ups = g_ups;
     /* the same rows for every comparison individual unless -v looks at its genotype or -D thins the
      * reads anew for each (src/ibdgem.c:584, :627-628) */
     const int batchable = !no_engine && !has_v && cull_p == 1.0;
@@ -2131,8 +2166,9 @@ int main(int argc, char **argv)
         }
         if (!slice_mode) {
             /* whole panel to every device, all copies at once, under the filter chain below */
+            g_n_ups = n_eng;
             uploads_start(ups, n_eng);
-            uploads_pending = 1;
+            g_uploads_pending = 1;
         }
     }
     if (!alt_count_h)
@@ -2192,8 +2228,7 @@ int main(int argc, char **argv)
     /* The files of up to out_slots individuals are written beside the main thread's work on the ones after them, each from
      * a per-row array of its own -- when the site list is the same for all of them (it is read by the writers), the rows go
      * to files (stdout keeps its order) and there is a table to write at all. */
-    enum { OUT_SLOTS = 6 };
-    static out_job outs[OUT_SLOTS];
+    out_job *const outs = g_outs;
     const int overlap = !has_v && cull_p == 1.0 && !opt_plan && !opt_summary_only && targets.n > 1;
     double *site_slot[OUT_SLOTS] = {site_ll};
     int out_slots = 4;
@@ -2321,12 +2356,13 @@ int main(int argc, char **argv)
                     if (timing_on > 0)
                         fprintf(stderr, "## panel slice of device %d: rows %zu + %zu of %zu\n", d, ups[d].r0, ups[d].n, n_rows);
                 }
+                g_n_ups = n_eng;
                 uploads_start(ups, n_eng);
-                uploads_pending = 1;
+                g_uploads_pending = 1;
             }
-            if (uploads_pending) {
+            if (g_uploads_pending) {
                 const int bad = uploads_join(ups, n_eng);
-                uploads_pending = 0;
+                g_uploads_pending = 0;
                 if (bad >= 0)
                     DIE("%s\n", ibdg_last_error(engs[bad]));
                 phase("panel upload (copy, alt counts, transposition; the part not hidden behind the filter chain)");
@@ -2409,6 +2445,7 @@ int main(int argc, char **argv)
             const int sum_fd = open(sum_fn, O_WRONLY | O_CREAT, 0666);
             o->tab = tab_fd >= 0 ? fdopen(tab_fd, "w") : NULL;
             o->sum = sum_fd >= 0 ? fdopen(sum_fd, "w") : NULL;
+            o->pending = 1;
             if (!o->tab || !o->sum) {
                 fprintf(stderr, "[::] ERROR in compare_impute(): Cannot open '%s' and/or '%s' for writing.\n", tab_fn, sum_fn);
                 quit(1);

@@ -253,6 +253,11 @@ int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
  * bg_count[n] times, which is the reference's order when there is no -B. */
 int ibdg_set_background_order(ibdg_ctx *ctx, const uint32_t *ids, size_t n);
 
+/* Host-side self checks that need no device (for the CPU test tier): "wait_info" = the bounded poll the uploads
+ * wait for the site preparation with (the word arrives / the stream ends without it / the stream fails / neither:
+ * wall-clock bound).  0 = passed, 1 = unknown check, 2 = failed. */
+int ibdg_selftest(const char *what);
+
 /* Block until all work queued on the engine's stream is done. */
 int ibdg_sync(ibdg_ctx *ctx);
 

@@ -136,3 +136,12 @@ def test_ibd0_ibd1_twins_match_the_oracle_and_the_reference_grid_bitwise(oracle)
     assert lib.ibdg_pdg_ibd0(0.3, 0.0, 0.0, 0.0) == 2.2250738585072014e-308
     assert lib.ibdg_pdg_ibd1(1, 1, 1.0, 0.0, 0.0, 0.0) == 2.2250738585072014e-308
     assert lib.ibdg_pdg_ibd1(3, 0, 0.3, 0.1, 0.2, 0.3) == 1.0
+
+
+def test_bounded_poll_of_the_site_preparation():
+    """ibdg_upload_sites waits for the device's hand-over by polling one host-mapped word; the poll ends when the word
+    arrives, when the stream ends without it, when the stream fails, and -- a wedged stream -- when its wall-clock bound
+    runs out (it used to spin for ever).  Exercised without a device through the library's self check."""
+    lib = E.load_library()
+    assert lib.ibdg_selftest(b"wait_info") == 0
+    assert lib.ibdg_selftest(b"no such check") == 1

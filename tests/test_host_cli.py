@@ -258,6 +258,23 @@ def test_no_device_summary_only_and_threads(tmp_path):
         assert _read(str(tmp_path / "a" / n)) == _read(str(tmp_path / "b" / n))
 
 
+def test_a_failing_run_leaves_no_stale_tables_behind(tmp_path):
+    """The output files are opened without truncation and emptied by whoever writes them (src/ibdgem.c:529-530 truncates at
+    fopen).  A run that fails after it opened an individual's files must not leave an earlier run's complete-looking table
+    in place: the exit path empties what was opened and not yet written, after waiting for every thread it started."""
+    fix = ["-H", "test.hap", "-L", "test.legend", "-I", "test.indv", "-P", "test1.pileup", "-N", "sample1"]
+    _run_no_device(fix, FIX_IN, tmp_path)                                  # a complete earlier run
+    tab2 = tmp_path / "sample1.sample2.tab.txt"
+    assert tab2.stat().st_size > 1000
+    first = _read(str(tmp_path / "sample1.sample1.summary.txt"))
+    os.remove(tmp_path / "sample1.sample2.summary.txt")
+    os.mkdir(tmp_path / "sample1.sample2.summary.txt")                     # the second individual's summary cannot be opened
+    res = _run_no_device(fix, FIX_IN, tmp_path, expect_ok=False)
+    assert res.returncode == 1 and "Cannot open" in res.stderr
+    assert tab2.stat().st_size == 0, "the stale table of the individual whose files could not be opened survived"
+    assert _read(str(tmp_path / "sample1.sample1.summary.txt")) == first     # the individual before it is complete
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REPO, "oracle", "_ref", "ibdgem")),
                     reason="the reference binary (oracle/_ref/ibdgem) is not in this tree")
 def test_no_device_runs_against_the_reference_binary_on_random_inputs():
