@@ -675,9 +675,18 @@ int build_segments(ibdg_ctx *c, bool compact)
         ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
         return 1;
     if (!c->nck_dev.p) {
-        if (ensure(c, c->nck_dev, c->nck_h.size() * 8)) return 1;
+        // the coefficients normalised here (C << clz(C), 64 - clz(C)): the device multiplies them as they are
+        std::vector<ibdg::WinRaw> nn(c->nck_h.size());
+        for (size_t i = 0; i < nn.size(); ++i) {
+            const unsigned long v = c->nck_h[i];
+            const int z = v ? __builtin_clzl(v) : 63;
+            nn[i].m = v ? (uint64_t)v << z : (uint64_t)1 << 63;         // (0 is never looked up: r <= cov)
+            nn[i].e = v ? 64 - z : 1;
+            nn[i].pad = 0;
+        }
+        if (ensure(c, c->nck_dev, nn.size() * sizeof(ibdg::WinRaw))) return 1;
         // (a blocking copy, once per context: the kernel that reads the table runs on the second stream)
-        HIP_TRY(c, hipMemcpy(c->nck_dev.p, c->nck_h.data(), c->nck_h.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->nck_dev.p, nn.data(), nn.size() * sizeof(ibdg::WinRaw), hipMemcpyHostToDevice));
     }
     ibdg::PrepSegArgs sa;
     sa.rec_cov = (const uint2 *)c->rec_cov.p;
@@ -685,7 +694,7 @@ int build_segments(ibdg_ctx *c, bool compact)
     sa.window = c->window;
     sa.n_win = c->n_win;
     sa.max_cov = c->max_cov;
-    sa.nck = (const unsigned long long *)c->nck_dev.p;
+    sa.nck = (const ibdg::WinRaw *)c->nck_dev.p;
     sa.segs = (ibdg::Seg *)c->segs.p;
     sa.seg_cap = (uint32_t)seg_cap;
     sa.wconst = (ibdg::WinConst *)c->wconst.p;

@@ -225,7 +225,7 @@ struct PrepSiteArgs {
 struct PrepSegArgs {
     const uint2 *rec_cov;
     uint32_t n_cov, window, n_win, max_cov;
-    const unsigned long long *nck;   // [(max_cov+1)^2] binomial coefficients
+    const WinRaw *nck;          // [(max_cov+1)^2] binomial coefficients, normalised: C = m / 2^64 x 2^e, m in [2^63, 2^64)
     Seg *segs;                  // room for seg_cap segments
     uint32_t seg_cap;           // segments beyond it are counted but not written (rows out of file order only)
     WinConst *wconst;           // [n_win + 1]

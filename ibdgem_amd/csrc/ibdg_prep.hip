@@ -50,6 +50,18 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total)
     return x - v;
 }
 
+// Set bits of a wave-wide mask below this lane (v_mbcnt_lo / v_mbcnt_hi).  The kernels of this file take a lane's rank
+// and its own bit of a ballot this way, and never shift a 64-bit value by the lane number: on gfx950 a 64-bit vector
+// shift whose AMOUNT sits in the last VGPR of the wave's allocation reads it wrongly every so often (it takes v0's low
+// bits instead; tools/ubench/shift64_top_vgpr.hip: 7 % of executions, never with the amount one register lower), hipcc
+// does not work around it for this target, and where the register allocator puts a lane number is not ours to decide.
+// That is what made a variant of k_prep_site_scatter with 24 instead of 22 VGPRs scatter some waves' rows to wrong
+// ranks in round 3; tools/audit_shift64.py checks every kernel's ISA for the pattern.
+__device__ __forceinline__ uint32_t bits_below_lane(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // ---- the block-level part both stages share ---------------------------------------------------
 // A block owns PREP_BLOCK consecutive elements; thread t looks at elements base + i*256 + t, so
 // every access is coalesced.  flag_of(e) says whether element e is kept.
@@ -84,10 +96,12 @@ __device__ __forceinline__ void block_scatter(size_t base, size_t n, uint32_t bl
     __shared__ uint32_t pre[PREP_ITEMS * NW];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t ballots[PREP_ITEMS];
+    uint32_t mine = 0;                                 // bit i: this thread's element of row i is kept
 #pragma unroll
     for (int i = 0; i < PREP_ITEMS; ++i) {
         const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
         const bool f = e < n && flag_of(e);
+        mine |= (uint32_t)f << i;
         ballots[i] = __ballot(f);
         if (lane == 0)
             pre[i * NW + wave] = (uint32_t)__popcll(ballots[i]);
@@ -105,10 +119,8 @@ __device__ __forceinline__ void block_scatter(size_t base, size_t n, uint32_t bl
 #pragma unroll
     for (int i = 0; i < PREP_ITEMS; ++i) {
         const size_t e = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        if (e < n && ((ballots[i] >> lane) & 1)) {
-            const uint32_t below = (uint32_t)__popcll(ballots[i] & ((1ull << lane) - 1));
-            emit(e, block_off + pre[i * NW + wave] + below);
-        }
+        if ((mine >> i) & 1)
+            emit(e, block_off + pre[i * NW + wave] + bits_below_lane(ballots[i]));
     }
 }
 
@@ -330,11 +342,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
         const bool live = j < in.n_cov;
         if (!__any(live))
             break;
-        const uint64_t starts = __ballot(live && seg_start(in, j));
+        const bool is_start = live && seg_start(in, j);
+        const uint64_t starts = __ballot(is_start);
         // piece of this row within the wave: pieces are numbered from 0; when lane 0 does not start a
         // segment, piece 0 is the tail of a segment that began in an earlier wave
         const uint32_t lead = (uint32_t)(~starts & 1);                       // 1: there is such a tail
-        const uint32_t piece = (uint32_t)__popcll(starts & ((2ull << lane) - 1)) - 1 + lead;
+        const uint32_t piece = bits_below_lane(starts) + (uint32_t)is_start - 1 + lead;     // starts up to and including this lane
         const uint32_t n_pieces = (uint32_t)__popcll(starts) + lead;
         // global segment of piece q: the segments that start in this wave follow those counted before it
         const uint32_t seg0 = boff + pre[i * NW + wave] - lead;               // segment of piece 0
@@ -347,7 +360,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
             al = idx - r * in.d;
             cv = r + al;
         }
-        const bool is_start = (starts >> lane) & 1;
         if (live && seg < seg_cap) {
             if (is_start) {
                 segs[seg].tile = row >> 5;
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (live) {
-            const uint32_t bit = 1u << (row & 31);
+            const uint32_t bit = 1u << (row & 31);          // (a 32-bit shift: not the hazard above)
             uint32_t *t = &tbl[wave][piece][0];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -423,7 +435,7 @@ __device__ __forceinline__ X87 x87_mul(X87 a, uint64_t bm, int32_t be)
 // 43 us of latency for 35 000 windows whatever fetches the rows (a workgroup staging them through LDS: 68 us), so it
 // runs on the second stream beside the segment kernels, which need none of it
 // (src/ibd-math.c:55 factors of every P(D|G) of the window).
-__global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win, const unsigned long long *__restrict__ nck,
+__global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win, const WinRaw *__restrict__ nck,
                                                       WinConst *__restrict__ wconst, WinRaw *__restrict__ raw,
                                                       PrepInfo *__restrict__ info)
 {
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win,
     // product chain and go out together -- a thread's rows are 64 consecutive bytes
     for (uint32_t j = (uint32_t)b; j < e; j += 8) {
         uint32_t y[8];
-        uint64_t c[8];
+        WinRaw c[8];                    // the coefficients come normalised from the host: no 64-bit shift by a count here
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             y[u] = j + u < e ? in.rec_cov[j + u].y : 0u;      // offset 0 = no reads: coefficient 1, counts 0
@@ -454,10 +466,8 @@ __global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win,
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (c[u] > 1) {            // times 1 changes nothing (and c is never 0 for r <= cv)
-                const int z = __clzll((long long)c[u]);
-                K = x87_mul(K, c[u] << z, 64 - z);
-            }
+            if (c[u].e > 1)            // times 1 (= 2^63 / 2^64 x 2^1) changes nothing (and c is never 0 for r <= cv)
+                K = x87_mul(K, c[u].m, c[u].e);
     }
     raw[w].m = K.m;
     raw[w].e = K.e;

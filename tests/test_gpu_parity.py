@@ -757,6 +757,40 @@ def windows_numpy(nr, na, W):
     return first, last, ncov
 
 
+def covered_ranks_check(lib_path=None):
+    """Ranks of the covered rows (cov_site / rec_cov of the stage-A scatter kernel) at MORE than 256 workgroups of the
+    preparation kernels -- several per CU -- through the finest view the ABI gives of them: windows of 2 covered rows
+    (first / last site of every window = every covered row's rank), row indirection, zero-coverage rows of three
+    densities; and the per-row values the records produce.  Returns the number of workgroups of the scatter kernel."""
+    N = 3
+    L = 700_003                                   # 684 workgroups of 1024 rows
+    rng = np.random.default_rng(20261004)
+    alle = (rng.random((1500, 2 * N)) < 0.3).astype(np.uint8)
+    rows = np.sort(rng.integers(0, 1500, size=L)).astype(np.uint32)
+    for p_zero in (0.135, 0.7, 0.02):
+        cov = np.where(rng.random(L) < p_zero, 0, 1 + rng.integers(0, 5, size=L))
+        na = rng.binomial(cov, 0.3).astype(np.uint8)
+        nr = (cov - na).astype(np.uint8)
+        want_first, want_last, want_ncov = windows_numpy(nr, na, 2)
+        with E.Engine(lib_path=lib_path) as eng:
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(rows, nr, na, 2)
+            first, last, ncov = eng.windows()
+            assert len(first) == len(want_first)
+            bad = np.flatnonzero((first != want_first) | (last != want_last) | (ncov != want_ncov))
+            assert len(bad) == 0, (f"p_zero={p_zero}: {len(bad)} windows with wrong bounds, first at window {bad[0]} "
+                                   f"(site {want_first[bad[0]]}, scatter workgroup {want_first[bad[0]] // 1024})")
+            eng.run([1], ld=False)
+            site = eng.site_ll(0)
+            zero = (nr.astype(int) + na) == 0
+            assert (site[zero] == 1.0).all() and (site[~zero, 0] < 1.0).all()
+    return (L + 1023) // 1024
+
+
+def test_covered_row_ranks_at_several_workgroups_per_cu():
+    assert covered_ranks_check() > 256
+
+
 @pytest.mark.parametrize("L,W,cov_mean", [(20000, 100, 2.0), (9000, 3, 0.3), (4096, 4096, 1.0), (4097, 17, 5.0),
                                           (70000, 1000, 2.0)])
 def test_device_resident_inputs_identity_rows_and_pinned_arrays(oracle, L, W, cov_mean):

@@ -1,0 +1,73 @@
+// Micro-benchmark behind DESIGN.md s4.4 (round 4): is a 64-bit vector shift whose shift amount sits in the LAST VGPR of
+// the wave's allocation read wrongly on gfx950?  The site-preparation kernel that kept its rows' records in registers
+// (24 VGPRs, the lane number in v23) produced, in some waves of workgroups that share a CU with others,
+//     v_lshlrev_b64 v[0:1], v23, 1        ; 1 << lane
+//     v_lshlrev_b64 v[14:15], v23, -1     ; -1 << lane      <- came out as -1 << (low word of v[0:1])
+// i.e. the second shift took its amount from v0, the register "behind" v23 in a 24-register allocation (v24 wraps to v0).
+// This program runs exactly that pair with the amount in v23 (the allocation's last register: the kernel clobbers
+// nothing above it) and, as the control, in v22 with the same allocation; many workgroups per CU, optional barrier.
+//   hipcc --offload-arch=gfx950 -O2 -o shift64_top_vgpr tools/ubench/shift64_top_vgpr.hip && ./shift64_top_vgpr
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <int TOP, int BARRIER>
+__global__ __launch_bounds__(256) void k(unsigned long long *bad, unsigned long long *bad_like_v0, int iters)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long wrong = 0, like_v0 = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint64_t one, mask;
+        if (TOP)
+            asm volatile("v_mov_b32 v23, %2\n\t"
+                         "v_lshlrev_b64 v[0:1], v23, 1\n\t"
+                         "v_lshlrev_b64 %1, v23, -1\n\t"
+                         "v_mov_b64 %0, v[0:1]"
+                         : "=&v"(one), "=&v"(mask) : "v"(lane) : "v0", "v1", "v22", "v23");
+        else
+            asm volatile("v_mov_b32 v22, %2\n\t"
+                         "v_lshlrev_b64 v[0:1], v22, 1\n\t"
+                         "v_lshlrev_b64 %1, v22, -1\n\t"
+                         "v_mov_b64 %0, v[0:1]"
+                         : "=&v"(one), "=&v"(mask) : "v"(lane) : "v0", "v1", "v22", "v23");
+        if (mask != (~0ull << lane)) {
+            ++wrong;
+            if (mask == (~0ull << ((uint32_t)one & 63)))
+                ++like_v0;
+        }
+        if (BARRIER)
+            __syncthreads();
+    }
+    if (wrong) {
+        atomicAdd(bad, wrong);
+        atomicAdd(bad_like_v0, like_v0);
+    }
+}
+
+template <int TOP, int BARRIER>
+static void run(const char *what, unsigned long long *d)
+{
+    hipMemset(d, 0, 16);
+    int nv = 0;
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k<TOP, BARRIER>));
+    nv = fa.numRegs;
+    hipLaunchKernelGGL((k<TOP, BARRIER>), dim3(256 * 16), dim3(256), 0, 0, d, d + 1, 2000);
+    hipDeviceSynchronize();
+    unsigned long long h[2];
+    hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("%-44s VGPRs %d: %llu wrong masks of %llu (%llu of them = -1 << low6(v0))\n", what, nv, h[0],
+           256ull * 16 * 256 * 2000, h[1]);
+}
+
+int main()
+{
+    unsigned long long *d;
+    hipMalloc(&d, 16);
+    run<1, 0>("amount in v23 (last of the allocation)", d);
+    run<0, 0>("amount in v22 (control)", d);
+    run<1, 1>("amount in v23, barrier per turn", d);
+    run<0, 1>("amount in v22, barrier per turn (control)", d);
+    hipFree(d);
+    return 0;
+}
