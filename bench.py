@@ -849,6 +849,16 @@ def main():
     dt_host = time.perf_counter() - t0          # host time to queue the steps (reported only)
     barrier()
     dt = time.perf_counter() - t0
+    # what the closing barrier itself costs (it is inside the timed region above, after this rank's own steps): the same
+    # barrier again with nothing to wait for, best of 5
+    barrier_ms = None
+    if world > 1:
+        b_all = []
+        for _ in range(5):
+            tb = time.perf_counter()
+            barrier()
+            b_all.append((time.perf_counter() - tb) * 1e3)
+        barrier_ms = min(b_all)
     eng.set_option("async", 0)
     ms_all = [eng.run_ms(b) for b in range(min(args.steps, 32))]
     ms_ld = [m["ld"] for m in ms_all]
@@ -936,7 +946,28 @@ def main():
                           "values, stores them and multiplies them up -- nothing is read back; the AF column is made by "
                           "ibdg_get_site_af when asked for, not by the run); hbm_frac on the step clock, kernel_hbm_frac on "
                           "the kernel's own events"}
-    # BASELINE.json configs[4]'s shape on this rank's rows (not `value`): many comparison individuals in ONE ibdg_run
+    # BASELINE.json configs[4]'s shape over N ranks: every rank runs ITS window range against all the comparison individuals
+    # (one ibdg_run; windows are independent, src/ibdgem.c:558-570, and so are comparison individuals, :522 -- a 2-D split
+    # would change nothing per rank); device time and wall time per rank, gathered below
+    many_rank = None
+    if world > 1 and not args.no_many:
+        many_tr = [(args.target + 5 * i) % args.ids for i in range(args.many_targets)]
+        eng.set_option("site_results", 0)
+        eng.run(many_tr, ld=True)
+        eng.sync()
+        best_dev, best_wall = None, None
+        for _ in range(3):
+            barrier()
+            tw = time.perf_counter()
+            eng.run(many_tr, ld=True)
+            eng.sync()
+            wall = (time.perf_counter() - tw) * 1e3
+            dev_ms = eng.last_run_ms()["total"]
+            best_dev = dev_ms if best_dev is None else min(best_dev, dev_ms)
+            best_wall = wall if best_wall is None else min(best_wall, wall)
+        eng.set_option("site_results", 1)
+        many_rank = {"comparison_individuals": len(many_tr), "device_ms": best_dev, "wall_ms": best_wall,
+                     "ld_layout": eng.ld_layout(), "windowed_sites": int(n_cov)}
     many = None
     if world == 1 and not args.no_many:
         many_t = [(args.target + 5 * i) % args.ids for i in range(args.many_targets)]
@@ -1037,6 +1068,8 @@ def main():
 
     mine = {"rank": rank, "rows": int(n_rows), "windowed_sites": int(n_cov), "windows": int(eng.n_windows),
             "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
+            "step_device_ms": float(np.mean([m["total"] for m in ms_all])),      # the engine's own events: both streams of a step
+            "many_comparison_individuals": many_rank,
             "upload_sites_ms": up["pageable_ms"], "engine_clock_ms": engine_clock["ms"],
             "host_queue_ms_per_step": dt_host / args.steps * 1e3}
     per_rank = [mine]
@@ -1096,6 +1129,9 @@ def main():
             "engine_clock": engine_clock,
             "results_to_host": d2h,
             "per_rank": per_rank,
+            "barrier_ms": barrier_ms,
+            "barrier_note": None if world == 1 else "the closing barrier of the timed region (dist.barrier + device sync) with "
+                            "nothing left to wait for, best of 5: what it adds to `steps` x ms_per_step",
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "many_comparison_individuals": many,
             "sparse_pileup": sparse,
@@ -1104,6 +1140,20 @@ def main():
         }
         if many:
             many["vs_one_per_run"] = ms_step / many["ms_per_individual"]        # against the step of one comparison individual
+        if world > 1 and per_rank[0].get("many_comparison_individuals"):
+            pr = [p["many_comparison_individuals"] for p in per_rank]
+            T = pr[0]["comparison_individuals"]
+            wall = max(p["wall_ms"] for p in pr)
+            out["many_comparison_individuals"] = {
+                "comparison_individuals": T, "ranks": world,
+                "wall_ms_max_over_ranks": wall, "device_ms_max_over_ranks": max(p["device_ms"] for p in pr),
+                "ms_per_individual": wall / T,
+                "site_individual_pairs_per_s": sum(p["windowed_sites"] for p in pr) * T / (wall * 1e-3),
+                "per_rank": pr,
+                "note": "BASELINE.json configs[4]'s shape over the ranks: each rank its contiguous window range x all comparison "
+                        "individuals in one ibdg_run (no per-row results kept: window tables only), ranks started together "
+                        "(barrier), wall and device time per rank, best of 3; the job's rate = all (site, individual) pairs / the "
+                        "slowest rank's wall time"}
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed at N=1 only
             s = sample_rows
             eng.upload_sites(np.arange(s, dtype=np.uint32), n_ref[:s], n_alt[:s], args.window)

@@ -45,7 +45,7 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_itself():
 def test_gpus_2_self_launched_on_one_device():
     """Two self-launched ranks sharing device 0 over gloo (BENCH_FORCE_DEVICE / BENCH_BACKEND exist for this
     rehearsal only).  n_gpus, the per-rank block, and the shards add up to the one-rank run's rows."""
-    common = ["--steps", "20", "--warmup", "5", "--sites", "500000", "--no-cpu-baseline", "--no-e2e", "--no-many"]
+    common = ["--steps", "20", "--warmup", "5", "--sites", "500000", "--no-cpu-baseline", "--no-e2e", "--many-targets", "20"]
     exe = [sys.executable, os.path.join(REPO, "bench.py")]
     r1 = subprocess.run(exe + ["--gpus", "1"] + common, env=_clean_env(), capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
@@ -60,6 +60,16 @@ def test_gpus_2_self_launched_on_one_device():
     assert sum(p["windowed_sites"] for p in two["per_rank"]) == one["config"]["windowed_sites"]
     assert sum(p["windows"] for p in two["per_rank"]) == one["per_rank"][0]["windows"]
     assert two["clock"] == "step" and two["scaling"] == "strong"
+    # the closing barrier's own cost and the engine's event clock of a step, per rank
+    assert two["barrier_ms"] is not None and 0 < two["barrier_ms"] < 50
+    assert all(0 < p["step_device_ms"] <= p["ms_per_step"] * 1.5 for p in two["per_rank"])
+    # BASELINE configs[4]'s shape over the ranks: every rank its window range x all comparison individuals
+    many = two["many_comparison_individuals"]
+    assert many["comparison_individuals"] == 20 and many["ranks"] == 2 and len(many["per_rank"]) == 2
+    assert sum(p["windowed_sites"] for p in many["per_rank"]) == one["config"]["windowed_sites"]
+    assert all(p["device_ms"] > 0 and p["wall_ms"] >= p["device_ms"] * 0.9 for p in many["per_rank"])
+    assert many["wall_ms_max_over_ranks"] == max(p["wall_ms"] for p in many["per_rank"])
+    assert one["many_comparison_individuals"]["comparison_individuals"] == 20
     # both ranks share ONE device here, so the two-rank value says nothing about scaling; it must still be a
     # sane rate of the same code path (between a third of and 1.5x the one-rank value)
     assert one["value"] / 3 < two["value"] < one["value"] * 1.5
