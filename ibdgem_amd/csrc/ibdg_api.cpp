@@ -108,8 +108,8 @@ struct ibdg_ctx {
     DevBuf t32c;
     uint32_t n_pairs_c = 0;
     bool compact = false;
-    bool segs_clean = false;            // the segment array is still the zeros stage A left
     uint32_t first_row = 0, last_row = 0;   // panel rows of the first / last site of the upload
+    DevBuf seg_first;
     DevBuf t32, segs, wconst, wtarget, twords, wtarget_mt, twords_mt, pow1, pow2, pow3, partial;
     // many comparison individuals (k_ld_mfma): target operands of a batch of groups, window constants per slot,
     // partial sums per half chunk, background multiplicities without the comparison individual's exclusion
@@ -661,9 +661,6 @@ int build_segments(ibdg_ctx *c, bool compact)
     else if (last_row >= first_row)
         seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((last_row >> 5) - (first_row >> 5)) + 1);
     seg_cap = std::min<uint64_t>(seg_cap, c->seg_room);
-    if (!c->segs_clean)                    // a second layout for the same upload: the masks are OR-ed into zeros
-        HIP_TRY(c, hipMemsetAsync(c->segs.p, 0, c->seg_room * sizeof(ibdg::Seg), c->stream));
-    c->segs_clean = false;
     if (compact) {
         // the rows with reads, gathered and transposed into tiles that start with their window
         const uint64_t pairs = ((uint64_t)c->n_win * tpw + 1) / 2;
@@ -701,6 +698,7 @@ int build_segments(ibdg_ctx *c, bool compact)
     sa.max_cov = c->max_cov;
     sa.nck = (const ibdg::WinRaw *)c->nck_dev.p;
     sa.segs = (ibdg::Seg *)c->segs.p;
+    sa.seg_first = (uint32_t *)c->seg_first.p;
     sa.seg_cap = (uint32_t)seg_cap;
     sa.wconst = (ibdg::WinConst *)c->wconst.p;
     sa.raw = (ibdg::WinRaw *)c->wraw.p;
@@ -709,12 +707,6 @@ int build_segments(ibdg_ctx *c, bool compact)
     sa.mirror = c->info_h;
     sa.compact = compact ? 1u : 0u;
     c->prep_dirty = true;
-    // (stream2 is idle: ibdg_upload_sites drained both streams before it began; stage A has been waited for)
-    ibdg::launch_prep_segments(sa, c->stream, c->stream2);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_prep2, c->stream2));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep2, 0));      // before the control words' hand-over (ct_max) and K'
-
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
     if (!c->opt_guided && !c->opt_wpg_fixed) {
@@ -727,14 +719,22 @@ int build_segments(ibdg_ctx *c, bool compact)
             g = (uint32_t)g_fit;
     }
     const uint32_t NS = (uint32_t)c->opt_ring;
-    for (;; g = (g + 1) / 2) {
+    for (bool first_try = true;; g = (g + 1) / 2, first_try = false) {
         make_runs(c, g, c->runs_h);
         c->n_runs = (uint32_t)c->runs_h.size() - 1;
         if (ensure(c, c->runs, c->runs_h.size() * 4))
             return 1;
         // runs_h is a member: it outlives the copy (the next wait is wait_info below)
         HIP_TRY(c, hipMemcpyAsync(c->runs.p, c->runs_h.data(), c->runs_h.size() * 4, hipMemcpyHostToDevice, c->stream));
-        ibdg::launch_prep_seg_flags(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, ++c->prep_seq, c->stream);
+        if (first_try) {
+            // the run structure goes ahead of the segment kernels, whose last one makes the control words for it
+            // (stream2 is idle: ibdg_upload_sites drained both streams before it began; stage A has been waited for)
+            ibdg::launch_prep_segments(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, c->stream, c->stream2);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->ev_prep2, c->stream2));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep2, 0));      // before the hand-over (ct_max) and K'
+        }
+        ibdg::launch_prep_seg_flags(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, ++c->prep_seq, c->stream, !first_try);
         HIP_TRY(c, hipGetLastError());
         if (wait_info(c, c->prep_seq))
             return 1;
@@ -951,7 +951,7 @@ void ibdg_destroy(ibdg_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
-                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32, &c->t32c,
+                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32, &c->t32c, &c->seg_first,
                       &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
@@ -1054,7 +1054,7 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
         ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
         ensure(c, c->info_dev, sizeof(ibdg::PrepInfo)) ||
-        (c->pop_lut_ok && ensure(c, c->segs, seg_room * sizeof(ibdg::Seg))))
+        (c->pop_lut_ok && (ensure(c, c->segs, seg_room * sizeof(ibdg::Seg)) || ensure(c, c->seg_first, seg_room * 4))))
         return 1;
     if (fresh_info || c->prep_dirty) {
         // the device's PrepInfo starts clean; afterwards every upload leaves it so (k_prep_mirror) -- unless it
@@ -1068,7 +1068,6 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     }
     ++c->sites_gen;
     c->seg_room = c->pop_lut_ok ? seg_room : 0;
-    c->segs_clean = n_sites != 0;           // stage A's scatter kernel clears the array
     c->compact = false;
     if (n_sites) {
         c->prep_dirty = true;
@@ -1086,8 +1085,6 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
         pa.info = (ibdg::PrepInfo *)c->info_dev.p;
         pa.mirror = c->info_h;
         pa.seq = ++c->prep_seq;
-        pa.clear = c->pop_lut_ok ? c->segs.p : nullptr;
-        pa.clear_bytes = c->pop_lut_ok ? seg_room * sizeof(ibdg::Seg) : 0;
         ibdg::launch_prep_sites(pa, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (wait_info(c, c->prep_seq))

@@ -218,8 +218,6 @@ struct PrepSiteArgs {
     PrepInfo *info;             // device
     PrepInfo *mirror;           // host-mapped copy a one-wave kernel fills in at the end of the stage, then mirror->seq = seq
     uint32_t seq;
-    void *clear;                // the segment array, cleared here for stage B (16-byte units)
-    size_t clear_bytes;
 };
 
 struct PrepSegArgs {
@@ -227,6 +225,7 @@ struct PrepSegArgs {
     uint32_t n_cov, window, n_win, max_cov;
     const WinRaw *nck;          // [(max_cov+1)^2] binomial coefficients, normalised: C = m / 2^64 x 2^e, m in [2^63, 2^64)
     Seg *segs;                  // room for seg_cap segments
+    uint32_t *seg_first;        // [seg_cap] first covered row of every segment
     uint32_t seg_cap;           // segments beyond it are counted but not written (rows out of file order only)
     WinConst *wconst;           // [n_win + 1]
     WinRaw *raw;                // [n_win] K = prod C(cov, n_ref) per window
@@ -242,10 +241,13 @@ void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st);
 // stage B: segment masks (on st), per-window reads / alt reads / K (on st2, which must be idle and see stage A's
 // results: the caller has waited for stage A), info->{n_segs, ct_max, out_of_order}.  The caller makes st wait for st2
 // before it queues anything that reads the per-window constants.
-void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2);
-// control words for a given run structure, info->{max_seg, adv_overflow}; the mirror gets all of stage B with seq
+void launch_prep_segments(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, hipStream_t st,
+                          hipStream_t st2);
+// control words for ANOTHER run structure than the one given to launch_prep_segments, info->{max_seg, adv_overflow}; the mirror
+// gets all of stage B with seq
+// redo = false: the segment kernels have made the control words for this very run structure already, only the hand-over is queued
 void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, uint32_t seq,
-                           hipStream_t st);
+                           hipStream_t st, bool redo);
 // wconst[w].{mK, eK} = K * pow_1me[reads of w]
 void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st);
 void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t window, uint32_t n_win, uint32_t *first,

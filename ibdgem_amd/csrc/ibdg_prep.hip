@@ -222,14 +222,10 @@ struct SiteOut {
 };
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, const uint32_t *__restrict__ block_off,
-                                                                    SiteOut out, PrepInfo *__restrict__ info,
-                                                                    uint4 *__restrict__ clear, size_t clear_units)
+                                                                    SiteOut out, PrepInfo *__restrict__ info)
 {
     const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
     const uint32_t d = in.max_cov + 1;
-    // this workgroup's share of the segment array (stage B builds the masks with atomicOr)
-    for (size_t u = (size_t)blockIdx.x * PREP_THREADS + threadIdx.x; u < clear_units; u += (size_t)gridDim.x * PREP_THREADS)
-        clear[u] = make_uint4(0, 0, 0, 0);
     block_scatter(
         base, in.n_sites, block_off[blockIdx.x],
         [&](size_t s) {
@@ -301,104 +297,107 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_count(SegIn in, uint3
         block_cnt[blockIdx.x] = tot;
 }
 
-// Segment masks, row-parallel: every covered row is a lane.  The lanes of a wave (64 consecutive covered
-// rows) OR their bits into a wave-private LDS table of [piece][weight plane] words -- a piece = the rows of
-// one segment that fall into this wave's 64, so at most 64 pieces -- with ds_or (LDS atomics; a segment's
-// ~20 rows hit the same word, which the LDS serialises in a few tens of cycles), then one lane per piece
-// adds the piece's non-zero words to the segment in memory with atomicOr: a segment cut by a wave boundary
-// is simply two pieces.  segs[] is zeroed beforehand.  The first row of a segment writes tile and window,
-// its last row the end-of-window mark.
-__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_build(SegIn in, const uint32_t *__restrict__ block_off,
-                                                                 Seg *__restrict__ segs, uint32_t seg_cap,
-                                                                 WinConst *__restrict__ wconst)
+// Segments in two steps.  (1) k_prep_seg_scatter: every covered row that starts a segment writes its index to
+// seg_first[its segment's rank] (the scatter of stage A again, on the start flags); the first row of a window also leaves
+// the window's first segment in wconst.  (2) k_prep_seg_walk: a thread per segment walks the segment's rows -- at most
+// 32, consecutive in rec_cov, eight loads in flight at a time -- ORs their bits into the sixteen mask words in registers
+// and stores the whole 80-byte record.  Nothing is zeroed beforehand and no atomic is involved.  (Round 2/3 built the
+// masks row-parallel with LDS and global atomicOr into a zeroed array: 57 us at 4M rows, plus the 13 MB of zeros; a
+// thread per segment had been 400 us then with one dependent load per row.)
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_seg_scatter(SegIn in, const uint32_t *__restrict__ block_off,
+                                                                   uint32_t *__restrict__ seg_first, uint32_t seg_cap,
+                                                                   WinConst *__restrict__ wconst)
 {
-    constexpr int NW = PREP_THREADS / 64;
-    __shared__ uint32_t pre[PREP_ITEMS * NW];
-    __shared__ __attribute__((aligned(16))) uint32_t tbl[NW][64][16];
     const size_t base = (size_t)blockIdx.x * PREP_BLOCK;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pass 1: segment starts per (item, wave) -> exclusive prefix (the same ranks k_prep_seg_count counted)
-#pragma unroll 4
-    for (int i = 0; i < PREP_ITEMS; ++i) {
-        const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        const uint64_t b = __ballot(j < in.n_cov && seg_start(in, j));
-        if (lane == 0)
-            pre[i * NW + wave] = (uint32_t)__popcll(b);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t tot;
-        const uint32_t v = lane < PREP_ITEMS * NW ? pre[lane] : 0u;
-        const uint32_t x = wave_excl_scan(v, &tot);
-        if (lane < PREP_ITEMS * NW)
-            pre[lane] = x;
-    }
-    __syncthreads();
-    const uint32_t boff = block_off[blockIdx.x];
-    uint4 *my_row = reinterpret_cast<uint4 *>(&tbl[wave][lane][0]);
-#pragma unroll 1
-    for (int i = 0; i < PREP_ITEMS; ++i) {
-        const size_t j = base + (size_t)i * PREP_THREADS + threadIdx.x;
-        const bool live = j < in.n_cov;
-        if (!__any(live))
-            break;
-        const bool is_start = live && seg_start(in, j);
-        const uint64_t starts = __ballot(is_start);
-        // piece of this row within the wave: pieces are numbered from 0; when lane 0 does not start a
-        // segment, piece 0 is the tail of a segment that began in an earlier wave
-        const uint32_t lead = (uint32_t)(~starts & 1);                       // 1: there is such a tail
-        const uint32_t piece = bits_below_lane(starts) + (uint32_t)is_start - 1 + lead;     // starts up to and including this lane
-        const uint32_t n_pieces = (uint32_t)__popcll(starts) + lead;
-        // global segment of piece q: the segments that start in this wave follow those counted before it
-        const uint32_t seg0 = boff + pre[i * NW + wave] - lead;               // segment of piece 0
-        const uint32_t seg = seg0 + piece;
-        uint32_t row = 0, cv = 0, al = 0;
-        if (live) {
-            const uint2 rc = in.rec_cov[j];
-            const uint32_t idx = rc.y / 24u, r = idx / in.d;
-            row = in.win_rows ? seg_row(in, j) : rc.x;
-            al = idx - r * in.d;
-            cv = r + al;
-        }
-        if (live && seg < seg_cap) {
-            if (is_start) {
-                segs[seg].tile = row >> 5;
-                segs[seg].win = (uint32_t)(j / in.window);
-            }
-            // the segment's final row: the next row starts another one
-            if (j + 1 >= in.n_cov || seg_start(in, j + 1))
-                segs[seg].last = (j + 1 >= in.n_cov || (j + 1) % in.window == 0) ? 1u : 0u;
-        }
-        if (live && is_start && j % in.window == 0)
-            wconst[j / in.window].seg_begin = seg;
-        // the wave's table: clear, OR, read back (a wave's LDS operations execute in order)
-        my_row[0] = my_row[1] = my_row[2] = my_row[3] = make_uint4(0, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (live) {
-            const uint32_t bit = 1u << (row & 31);          // (a 32-bit shift: not the hazard above)
-            uint32_t *t = &tbl[wave][piece][0];
+    block_scatter(
+        base, in.n_cov, block_off[blockIdx.x], [&](size_t j) { return seg_start(in, j); },
+        [&](size_t j, uint32_t seg) {
+            if (seg < seg_cap)
+                seg_first[seg] = (uint32_t)j;
+            if (j % in.window == 0)
+                wconst[j / in.window].seg_begin = seg;
+        });
+}
+
+// The control word of the --LD loop (ibdg::Seg::flags) for the run structure the host has sent ahead is made here as
+// well: the neighbour's tile comes from its first row, the run's bounds from the windows' first segments (written by the
+// scatter kernel before this one); thread i < n_runs also reports its run's segment count.  (k_prep_seg_flags does the
+// same from the finished records when the host has to try shorter runs.)
+__global__ __launch_bounds__(256) void k_prep_seg_walk(SegIn in, const uint32_t *__restrict__ seg_first, Seg *__restrict__ segs,
+                                                       uint32_t seg_cap, const WinConst *__restrict__ wconst,
+                                                       const uint32_t *__restrict__ run_begin, uint32_t n_runs, uint32_t ring,
+                                                       PrepInfo *__restrict__ info)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_segs = info->n_segs;
+    if (s < n_runs)
+        atomicMax(&info->max_seg, wconst[run_begin[s + 1]].seg_begin - wconst[run_begin[s]].seg_begin);
+    if (s >= n_segs || n_segs > seg_cap)       // more segments than room: rows out of order, nothing to build
+        return;
+    const uint32_t j0 = seg_first[s], j1 = s + 1 < n_segs ? seg_first[s + 1] : in.n_cov;
+    uint32_t cov[8] = {0, 0, 0, 0, 0, 0, 0, 0}, alt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t j = j0; j < j1; j += 8) {
+        uint2 rc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            rc[u] = j + u < j1 ? in.rec_cov[j + u] : make_uint2(0, 0);          // offset 0 = no reads: no bit anywhere
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t idx = rc[u].y / 24u, r = idx / in.d, al = idx - r * in.d, cv = r + al;
+            const uint32_t row = in.win_rows ? seg_row(in, j + u) : rc[u].x;
+            const uint32_t bit = 1u << (row & 31);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if ((cv >> k) & 1) atomicOr(&t[k], bit);
-                if ((al >> k) & 1) atomicOr(&t[8 + k], bit);
+                cov[k] |= (0u - ((cv >> k) & 1u)) & bit;
+                alt[k] |= (0u - ((al >> k) & 1u)) & bit;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < n_pieces && seg0 + lane < seg_cap) {
-            Seg *sg = &segs[seg0 + lane];
-            const uint4 *src = reinterpret_cast<const uint4 *>(&tbl[wave][lane][0]);
-            const uint4 c0 = src[0], c1 = src[1], a0 = src[2], a1 = src[3];
-            const uint32_t w[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (w[k])
-                    atomicOr(k < 8 ? &sg->cov[k] : &sg->alt[k - 8], w[k]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
+    auto tile_of = [&](uint32_t seg) {
+        const uint32_t j = seg_first[seg];
+        return (in.win_rows ? seg_row(in, j) : in.rec_cov[j].x) >> 5;
+    };
+    const uint32_t row0 = in.win_rows ? seg_row(in, j0) : in.rec_cov[j0].x;
+    const uint32_t tile = row0 >> 5, win = (uint32_t)(j0 / in.window);
+    const uint32_t last = (j1 >= in.n_cov || j1 % in.window == 0) ? 1u : 0u;
+    uint32_t flags = 0;
+    {
+        // the run of the segment's window: last r with run_begin[r] <= win
+        uint32_t lo = 0, hi = n_runs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (run_begin[mid] <= win)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t s0 = wconst[run_begin[lo]].seg_begin, s1 = wconst[run_begin[lo + 1]].seg_begin;
+        uint32_t nc = 0, na = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (cov[k]) nc = k + 1;
+            if (alt[k]) na = k + 1;
+        }
+        uint32_t nslot = 0, nhalf = 0, adv = 0;
+        if (s + 1 < s1) {
+            const uint32_t tn = tile_of(s + 1), qn = tn >> 1;
+            adv = qn - (tile >> 1);
+            if (adv > 255) {
+                info->adv_overflow = 1;    // rows too far apart for the record format (or out of order)
+                adv = 255;
+            }
+            nslot = (qn - (tile_of(s0) >> 1)) % ring;
+            nhalf = tn & 1;
+        }
+        flags = nslot | (nhalf << 3) | (adv << 4) | ((nc > 3 || na > 2) ? 1u << 12 : 0u) | (last ? 1u << 13 : 0u) | (nc << 16) |
+                (na << 24);
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(&segs[s]);
+    o[0] = make_uint4(tile, win, last, flags);
+    o[1] = make_uint4(cov[0], cov[1], cov[2], cov[3]);
+    o[2] = make_uint4(cov[4], cov[5], cov[6], cov[7]);
+    o[3] = make_uint4(alt[0], alt[1], alt[2], alt[3]);
+    o[4] = make_uint4(alt[4], alt[5], alt[6], alt[7]);
 }
 
 // x = m / 2^64 * 2^e with m in [2^63, 2^64): a normalised x87 extended number
@@ -431,14 +430,28 @@ __device__ __forceinline__ X87 x87_mul(X87 a, uint64_t bm, int32_t be)
     return r;
 }
 
-// One thread per window: reads, alt reads and K = prod C(cov, n_ref) of its rows in row order -- a chain of roundings,
-// 43 us of latency for 35 000 windows whatever fetches the rows (a workgroup staging them through LDS: 68 us), so it
-// runs on the second stream beside the segment kernels, which need none of it
-// (src/ibd-math.c:55 factors of every P(D|G) of the window).
-__global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win, const WinRaw *__restrict__ nck,
-                                                      WinConst *__restrict__ wconst, WinRaw *__restrict__ raw,
-                                                      PrepInfo *__restrict__ info)
+// One thread per window: reads, alt reads and K = prod C(cov, n_ref) of its rows in row order -- a chain of roundings
+// (src/ibd-math.c:55 factors of every P(D|G) of the window).  What the thread waits for is memory, not the chain: per
+// eight rows one round trip for their records and, behind it, one for their coefficients (58 us at 35 000 windows in
+// round 3's form, as long as the three segment kernels beside it).  Now the coefficient table -- (max_cov + 1)^2 entries,
+// 7 KB at -M 20 -- is staged into LDS once per workgroup (LDS = true; larger tables stay in memory), and the records of
+// the next eight rows are requested before the products of these eight are taken.  Runs on the second stream beside
+// the segment kernels, which need none of it.
+template <bool LDS>
+__global__ __launch_bounds__(128) void k_prep_win_const(SegIn in, uint32_t n_win, const WinRaw *__restrict__ nck,
+                                                       WinConst *__restrict__ wconst, WinRaw *__restrict__ raw,
+                                                       PrepInfo *__restrict__ info)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_wc[];
+    const WinRaw *tab = nck;
+    if (LDS) {
+        uint4 *dst = reinterpret_cast<uint4 *>(smem_wc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(nck);
+        for (uint32_t i = threadIdx.x; i < in.d * in.d; i += blockDim.x)
+            dst[i] = src[i];
+        __syncthreads();
+        tab = reinterpret_cast<const WinRaw *>(smem_wc);
+    }
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_win)                    // (the entry behind the last window, seg_begin = n_segs, is the scan's)
         return;
@@ -449,25 +462,29 @@ __global__ __launch_bounds__(64) void k_prep_win_const(SegIn in, uint32_t n_win,
     K.m = 1ull << 63;                  // 1.0 = 0.5 * 2^1
     K.e = 1;
     uint32_t ct = 0, at = 0;
-    // eight rows per turn: their loads (and the coefficient look-ups behind them) are independent of the
-    // product chain and go out together -- a thread's rows are 64 consecutive bytes
+    uint32_t y[8], yn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        y[u] = (uint32_t)b + u < e ? in.rec_cov[(uint32_t)b + u].y : 0u;      // offset 0 = no reads: coefficient 1, counts 0
     for (uint32_t j = (uint32_t)b; j < e; j += 8) {
-        uint32_t y[8];
-        WinRaw c[8];                    // the coefficients come normalised from the host: no 64-bit shift by a count here
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            y[u] = j + u < e ? in.rec_cov[j + u].y : 0u;      // offset 0 = no reads: coefficient 1, counts 0
+            yn[u] = j + 8 + u < e ? in.rec_cov[j + 8 + u].y : 0u;             // the next turn's, in flight under this turn's products
+        WinRaw c[8];                   // the coefficients come normalised from the host: no 64-bit shift by a count here
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const uint32_t idx = y[u] / 24u, r = idx / in.d, a = idx - r * in.d, cv = r + a;
             ct += cv;
             at += a;
-            c[u] = nck[(size_t)cv * in.d + r];
+            c[u] = tab[(size_t)cv * in.d + r];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (c[u].e > 1)            // times 1 (= 2^63 / 2^64 x 2^1) changes nothing (and c is never 0 for r <= cv)
                 K = x87_mul(K, c[u].m, c[u].e);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            y[u] = yn[u];
     }
     raw[w].m = K.m;
     raw[w].e = K.e;
@@ -580,12 +597,12 @@ void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st)
     const unsigned nb = blocks_for(a.n_sites);
     hipLaunchKernelGGL(k_prep_site_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_cov, (WinConst *)nullptr);
-    hipLaunchKernelGGL(k_prep_site_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, out, a.info,
-                       reinterpret_cast<uint4 *>(a.clear), a.clear_bytes / 16);
+    hipLaunchKernelGGL(k_prep_site_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, out, a.info);
     hipLaunchKernelGGL(k_prep_mirror, dim3(1), dim3(64), 0, st, a.info, a.mirror, a.seq, 0);
 }
 
-void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2)
+void launch_prep_segments(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, hipStream_t st,
+                          hipStream_t st2)
 {
     if (a.n_cov == 0)
         return;
@@ -597,19 +614,29 @@ void launch_prep_segments(const PrepSegArgs &a, hipStream_t st, hipStream_t st2)
     in.win_rows = a.compact ? 32u * ((a.window + 31) / 32) : 0u;
     const unsigned nb = blocks_for(a.n_cov);
     // the per-window constants on the second stream, beside the three segment kernels
-    hipLaunchKernelGGL(k_prep_win_const, dim3((a.n_win + 63) / 64), dim3(64), 0, st2, in, a.n_win, a.nck, a.wconst, a.raw,
-                       a.info);
+    {
+        const size_t tab_bytes = (size_t)in.d * in.d * sizeof(WinRaw);
+        const dim3 grid((a.n_win + 127) / 128), block(128);
+        if (tab_bytes <= 32 * 1024)
+            hipLaunchKernelGGL(k_prep_win_const<true>, grid, block, (uint32_t)tab_bytes, st2, in, a.n_win, a.nck, a.wconst, a.raw,
+                               a.info);
+        else
+            hipLaunchKernelGGL(k_prep_win_const<false>, grid, block, 0, st2, in, a.n_win, a.nck, a.wconst, a.raw, a.info);
+    }
     hipLaunchKernelGGL(k_prep_seg_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs, a.wconst + a.n_win);
-    hipLaunchKernelGGL(k_prep_seg_build, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.segs, a.seg_cap,
+    hipLaunchKernelGGL(k_prep_seg_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.seg_first, a.seg_cap,
                        a.wconst);
+    if (a.seg_cap)
+        hipLaunchKernelGGL(k_prep_seg_walk, dim3((a.seg_cap + 255) / 256), dim3(256), 0, st, in, a.seg_first, a.segs, a.seg_cap,
+                           a.wconst, run_begin, n_runs, ring, a.info);
 }
 
 void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, uint32_t seq,
-                           hipStream_t st)
+                           hipStream_t st, bool redo)
 {
     const uint32_t n = a.seg_cap > n_runs ? a.seg_cap : n_runs;
-    if (n)
+    if (n && redo)
         hipLaunchKernelGGL(k_prep_seg_flags, dim3((n + 255) / 256), dim3(256), 0, st, a.segs, a.wconst, run_begin, n_runs,
                            ring, a.seg_cap, a.info);
     hipLaunchKernelGGL(k_prep_mirror, dim3(1), dim3(64), 0, st, a.info, a.mirror, seq, 1);
