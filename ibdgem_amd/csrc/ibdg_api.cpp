@@ -141,6 +141,7 @@ struct ibdg_ctx {
 
     // run state / results
     DevBuf targets, weight, nrefpanel, af, site_ll, win_ll;
+    DevBuf row_tab;                     // [n_sites][4]: the rows' values of an --LD run over several comparison individuals (k_row_table)
     size_t n_targets = 0;
     bool have_results = false;
 
@@ -951,7 +952,7 @@ void ibdg_destroy(ibdg_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
-                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->t32, &c->t32c, &c->seg_first,
+                      &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->row_tab, &c->t32, &c->t32c, &c->seg_first,
                       &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
@@ -1287,8 +1288,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
 
     const size_t lanes = (size_t)c->n_groups * c->cpw * 64;
     const bool want_ll = c->opt_site_results != 0;
-    if (ensure(c, c->targets, T * 4) || (want_ll && ensure(c, c->site_ll, T * c->n_sites * 24)) ||
-        ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
+    // --LD over several comparison individuals: one table of the rows' values for all of them (they differ by the genotype
+    // picked), an individual's per-site table is put together when it is fetched (k_row_table / k_site_expand)
+    const bool row_table = want_ll && ld_mode && T > 1;
+    if (ensure(c, c->targets, T * 4) || (want_ll && ensure(c, c->site_ll, (row_table ? 1 : T) * c->n_sites * 24)) ||
+        (row_table && ensure(c, c->row_tab, c->n_sites * 32)) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
     // targets / background weights change rarely between calls (a loop over windows sizes, repeated
     // timing steps): their device copies are rebuilt only when the inputs differ
@@ -1409,7 +1413,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.n_win = c->n_win;
     sa.ld_mode = ld_mode ? 1 : 0;
     sa.af = nullptr;
-    sa.site_ll = want_ll ? (double *)c->site_ll.p : nullptr;
+    sa.site_ll = want_ll && !row_table ? (double *)c->site_ll.p : nullptr;
+    sa.row_tab = row_table ? (double *)c->row_tab.p : nullptr;
     sa.win_ll = (double *)c->win_ll.p;
 
     if (use_pop) {
@@ -1673,6 +1678,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         unsigned row_blocks = 0;
         if (shadow && c->opt_site_blocks > 0)
             row_blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_site_blocks / T));
+        if (row_table)
+            ibdg::launch_row_table(sa, c->stream2);
         ibdg::launch_rows_windows(sa, (unsigned)T, c->stream2, row_blocks);
         HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
         c->last_s2 = E.s2[2];
@@ -1686,7 +1693,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         return 1;
     c->n_targets = T;
     c->have_results = true;
-    c->res_site_mode = (int)c->opt_site_results;
+    c->res_site_mode = row_table ? 2 : (int)c->opt_site_results;
     return 0;
 }
 
@@ -1725,6 +1732,25 @@ int ibdg_get_site_ll(ibdg_ctx *c, size_t t, double *out)
     if (!c) return 1;
     if (!c->have_results || t >= c->n_targets) return fail(c, "[::] ERROR in ibdg_get_site_ll: no results for target %zu", t);
     if (c->res_site_mode == 0) return fail(c, "[::] ERROR in ibdg_get_site_ll: the run kept no per-site results (option site_results)");
+    if (c->res_site_mode == 2) {
+        // the run kept one table of the rows' values for all its comparison individuals: this one's per-site table from it
+        if (t >= c->prev_targets.size()) return fail(c, "[::] ERROR in ibdg_get_site_ll: no results for target %zu", t);
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (join_streams(c)) return 1;
+        ibdg::RowsArgs ra = {};
+        ra.panel = (const uint64_t *)c->panel.p;
+        ra.stride = c->stride;
+        ra.n_ids = c->n_ids;
+        ra.rec_all = (const uint2 *)c->rec_all.p;
+        ra.n_sites = c->n_sites;
+        ra.lut = (const double *)c->lut.p;
+        ra.t32 = c->pop_lut_ok ? (const uint4 *)c->t32.p : nullptr;
+        ra.n_pairs = c->n_pairs;
+        ra.row_tab = (double *)c->row_tab.p;
+        ibdg::launch_site_expand(ra, c->prev_targets[t], (double *)c->site_ll.p, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        return fetch(c, out, c->site_ll.p, c->n_sites * 24);
+    }
     return fetch(c, out, (const char *)c->site_ll.p + t * c->n_sites * 24, c->n_sites * 24);
 }
 

@@ -28,6 +28,7 @@ struct RowsArgs {
     int ld_mode;                // 1: of the window products only LIBD2 is written
     double *af;                 // [n_sites]: written by k_site_af only (ibdg_get_site_af)
     double *site_ll;            // [T][n_sites][3], or NULL: per-site results not wanted
+    double *row_tab;            // [n_sites][4] {LIBD0, LIBD1 under genotype 0, 1, 2}: k_row_table / k_site_expand only
     double *win_ll;             // [T][n_win][3]
 };
 
@@ -262,6 +263,9 @@ void launch_alt_count(const uint64_t *panel, uint32_t stride, size_t n_rows, uin
 void launch_rows_windows(const RowsArgs &a, unsigned n_targets, hipStream_t st, unsigned max_blocks = 0);
 // af[s] of every site (k_site_af)
 void launch_site_af(const RowsArgs &a, hipStream_t st);
+// the row table of a run over several comparison individuals, and one individual's per-site table from it
+void launch_row_table(const RowsArgs &a, hipStream_t st);
+void launch_site_expand(const RowsArgs &a, uint32_t tgt, double *out, hipStream_t st);
 int launch_ld(const LdArgs &a, unsigned n_targets, int cpw, unsigned waves, hipStream_t st);
 
 }  // namespace ibdg

@@ -504,6 +504,95 @@ __global__ __launch_bounds__(256) void k_site_af(RowsArgs a)
     a.af[s] = f;
 }
 
+// ---------------------------------------------------------------------------
+// Several comparison individuals over one site list (--LD runs): a row's three values depend on the comparison
+// individual through its genotype at the row only -- LIBD0 not at all (find_pDgf, src/ibd-math.c:84-101), LIBD1 through
+// the three branches of find_pDgIBD1 (:104-142), LIBD2 = P(D|G) of the genotype (src/ibdgem.c:643-651).  So a run over T
+// individuals keeps ONE table per row, {LIBD0, LIBD1 under genotype 0, 1, 2} (k_row_table, the arithmetic of rows_turn
+// operation for operation), and the per-site table of individual t is put together when somebody asks for it
+// (k_site_expand, ibdg_get_site_ll): T x rows x 24 bytes of stores and of device memory become rows x 32 bytes --
+// 5.8 GB per 60 individuals at 4M rows, which cost the matrix-core kernel beside it a sixth of its time.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_table(RowsArgs a)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sites)
+        return;
+    const uint2 rc = a.rec_all[s];
+    const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc.y);
+    const double p00 = L[0], p01 = L[1], p11 = L[2];
+    const uint32_t k = a.alt_count[rc.x];
+    double f = (double)k / (double)(int)(2u * a.n_ids);       // src/ibd-parse.c:98
+    double pw1 = a.pow_tab[2 * k], pw2 = a.pow_tab[2 * k + 1];
+    if (a.fo) {
+        const double o = a.fo[3 * s];
+        if (o == o) {                      // not NaN: -A override (src/ibdgem.c:609-614)
+            f = o;
+            pw1 = a.fo[3 * s + 1];
+            pw2 = a.fo[3 * s + 2];
+        }
+    }
+    const double omf = 1 - f;
+    double ibd0 = 1.0;
+    if (!(p00 == 1 || p01 == 1 || p11 == 1)) {
+        const double t1 = pw1 * p00;
+        const double t2 = ((2 * omf) * f) * p01;
+        const double t3 = pw2 * p11;
+        ibd0 = (t1 + t2) + t3;
+        if (ibd0 == 0.0)
+            ibd0 = 2.2250738585072014e-308;      // DBL_MIN
+    }
+    double g0 = (f * p01) + (omf * p00);
+    double g1 = ((0.5 * p01) + ((0.5 * omf) * p00)) + ((0.5 * f) * p11);
+    double g2 = (omf * p01) + (f * p11);
+    if (g0 == 0.0) g0 = 2.2250738585072014e-308;
+    if (g1 == 0.0) g1 = 2.2250738585072014e-308;
+    if (g2 == 0.0) g2 = 2.2250738585072014e-308;
+    double4 *o = reinterpret_cast<double4 *>(a.row_tab) + s;
+    *o = make_double4(ibd0, g0, g1, g2);
+}
+
+// the per-site table of comparison individual `tgt` from the row table: out[s] = {LIBD0, LIBD1[g], P(D|G = g)}
+__global__ __launch_bounds__(256) void k_site_expand(RowsArgs a, uint32_t tgt, double *__restrict__ out)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sites)
+        return;
+    const uint2 rc = a.rec_all[s];
+    unsigned A0, A1;
+    if (a.t32) {
+        const uint2 *p = reinterpret_cast<const uint2 *>(a.t32 + ((size_t)(tgt >> 6) * a.n_pairs + (rc.x >> 6)) * 64 + (tgt & 63));
+        const uint2 tw = p[(rc.x >> 5) & 1];
+        A0 = (tw.x >> (rc.x & 31)) & 1u;
+        A1 = (tw.y >> (rc.x & 31)) & 1u;
+    } else {
+        const uint64_t *row = a.panel + (size_t)rc.x * a.stride;
+        A0 = (unsigned)((row[2 * (tgt >> 6)] >> (tgt & 63)) & 1u);
+        A1 = (unsigned)((row[2 * (tgt >> 6) + 1] >> (tgt & 63)) & 1u);
+    }
+    const unsigned g = A0 + A1;
+    const double4 v = reinterpret_cast<const double4 *>(a.row_tab)[s];
+    const double *L = reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.lut) + rc.y);
+    double *o = out + 3 * s;
+    o[0] = v.x;
+    o[1] = g == 0 ? v.y : (g == 1 ? v.z : v.w);
+    o[2] = L[g];
+}
+
+void launch_row_table(const RowsArgs &a, hipStream_t st)
+{
+    if (a.n_sites == 0)
+        return;
+    hipLaunchKernelGGL(k_row_table, dim3((unsigned)((a.n_sites + 255) / 256)), dim3(256), 0, st, a);
+}
+
+void launch_site_expand(const RowsArgs &a, uint32_t tgt, double *out, hipStream_t st)
+{
+    if (a.n_sites == 0)
+        return;
+    hipLaunchKernelGGL(k_site_expand, dim3((unsigned)((a.n_sites + 255) / 256)), dim3(256), 0, st, a, tgt, out);
+}
+
 void launch_site_af(const RowsArgs &a, hipStream_t st)
 {
     if (a.n_sites == 0)
