@@ -1428,7 +1428,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const size_t TGs = IBDG_TG;
         size_t n_gg = 0, T_g = 0;
         // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
-        const size_t group_bytes = (size_t)c->n_win * c->n_chunks * 32 * TGs + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
+        const size_t group_bytes = (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128) + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
         if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && (c->compact ? c->n_pairs_c : c->n_pairs) < (1u << 23) &&
             group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
@@ -1447,12 +1447,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         if (n_gg) {
             const size_t per_group = (size_t)c->n_segs * 1024;
             size_t fit = per_group ? ((size_t)1 << 30) / per_group : n_gg;
-            const size_t fit_p = ((size_t)4 << 30) / ((size_t)c->n_win * c->n_chunks * 32 * TGs + 1);     // partial sums
+            const size_t fit_p = ((size_t)4 << 30) / ((size_t)c->n_win * (c->n_chunks * 2 * 136 + 128) + 1);     // partial sums
             fit = fit < fit_p ? fit : fit_p;
             fit = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
             gg_batch = fit < n_gg ? fit : n_gg;
         }
-        const size_t T_batch = gg_batch * TGs < T_g ? gg_batch * TGs : T_g;
         if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, T_one * (size_t)c->n_segs * 32) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
@@ -1460,7 +1459,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
             ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
             ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 512) ||
-            ensure(c, c->partial_h, T_batch * (size_t)c->n_win * c->n_chunks * 32))
+            ensure(c, c->partial_h, gg_batch * (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128)))
             return 1;
         ibdg::PopArgs pa;
         pa.t32 = (const uint32_t *)(c->compact ? c->t32c.p : c->t32.p);
@@ -1516,21 +1515,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.tab_len = pa.tab_len;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
-            ibdg::PopFinalArgs fh;
-            fh.wconst = pa.wconst;
-            fh.n_win = c->n_win;
-            fh.n_chunks = c->n_chunks;
-            fh.n_refpanel = (const int *)c->nrefpanel.p;
-            fh.win_ll = (double *)c->win_ll.p;
-            fh.halves = 1;
+            {
+                // one batch's partial sums: t1 [groups][windows][half chunks][16], t0 [groups][windows][half chunks], ov [groups][windows][16]
+                const size_t nh = (size_t)c->n_chunks * 2;
+                ma.part_t1 = (double *)c->partial_h.p;
+                ma.part_t0 = ma.part_t1 + gg_batch * (size_t)c->n_win * nh * 16;
+                ma.part_ov = ma.part_t0 + gg_batch * (size_t)c->n_win * nh;
+            }
             for (size_t g0 = 0; g0 < n_gg; g0 += gg_batch) {
                 const size_t nb = n_gg - g0 < gg_batch ? n_gg - g0 : gg_batch;
                 ma.t_base = (uint32_t)(g0 * TGs);
                 ma.n_targets = (uint32_t)((T_g - g0 * TGs) < nb * TGs ? (T_g - g0 * TGs) : nb * TGs);
-                ma.partial = (double *)c->partial_h.p;          // the batch's individuals, the first one first
-                fh.partial = ma.partial;
-                fh.t_base = ma.t_base;
-                fh.p_t0 = ma.t_base;
                 ibdg::launch_win_target_g(ma, (unsigned)nb, c->stream);
                 if (g0 == 0) {
                     // the second stream (per-site values, window products; high priority) starts behind these
@@ -1540,7 +1535,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 }
                 if (ibdg::launch_ld_mfma(ma, (unsigned)nb, c->stream, ibdg::KernelEvents()))
                     return fail(c, "[::] ERROR in ibdg_run: the matrix-core --LD kernel could not be launched");
-                ibdg::launch_ld_finalize(fh, ma.n_targets, c->stream, ibdg::KernelEvents());
+                ibdg::launch_ld_finalize_g(ma, (unsigned)nb, (const int *)c->nrefpanel.p, (double *)c->win_ll.p, c->stream);
             }
         }
         // k_ld_mfma (4 waves per SIMD) leaves wave slots to the second stream: its kernels run in their fast forms

@@ -161,11 +161,16 @@ struct MfmaArgs {
     uint32_t t_base;            // first comparison individual of group 0 of this launch
     uint32_t n_targets;         // comparison individuals of this launch (groups of IBDG_TG, the last may be short)
     const double *base_weight;  // [lanes] background multiplicity without the comparison individual's exclusion
-    double *partial;            // [individuals of this launch][n_win][2 * n_chunks][2], individual t_base first
+    // partial sums of the launch's groups per window and half chunk (2 * n_chunks of them), see k_ld_mfma:
+    double *part_t1;            // [groups][n_win][2 * n_chunks][16 slots]  IBD1 sums
+    double *part_t0;            // [groups][n_win][2 * n_chunks]            IBD0 sum, common to the slots
+    double *part_ov;            // [groups][n_win][16 slots]                IBD0 sum of the half chunk that holds the slot's own individual
 };
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st);
 int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev);
+// win_ll[t][w][0..1] of the launch's comparison individuals from those partial sums (src/ibdgem.c:751-752)
+void launch_ld_finalize_g(const MfmaArgs &a, unsigned n_groups, const int *n_refpanel, double *win_ll, hipStream_t st);
 
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
                         uint32_t n_pairs, uint32_t *t32, hipStream_t st);

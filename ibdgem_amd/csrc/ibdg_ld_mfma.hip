@@ -406,9 +406,23 @@ void k_ld_mfma(MfmaArgs a)
     const uint32_t st_q = (lane >> 2) & 7;
     const bool st_lane = (lane & 35) == 0;                          // p = 0, h = 0
     const bool st_ok0 = st_lane && st_q < cnt, st_ok1 = st_lane && st_q + 8 < cnt;      // (slot 15 never: cnt <= 15)
-    const size_t st_row0 = (((size_t)(grp * TG + st_q) * a.n_win) * n_half + hc) * 2;    // window 0
-    const size_t st_row1 = (((size_t)(grp * TG + st_q + 8) * a.n_win) * n_half + hc) * 2;
+    // Partial sums of this wave (half chunk hc) per window, for k_ld_finalize_g:
+    //   t1[group][window][hc][16 slots]  the IBD1 sums -- the eight storing lanes of a turn write 64 consecutive bytes;
+    //   t0[group][window][hc]            the IBD0 sum over the wave's individuals, the same for every slot ...
+    //   ov[group][window][16 slots]      ... except the slot whose comparison individual sits in this wave (no individual
+    //                                    is in its own background, ibdgem.c:714): that slot's sum without it, in place of t0
+    // (round 3 stored {t0, t1} per slot and half chunk, 16 bytes each at a stride of 1280: 2.7 GB per 60 comparison
+    // individuals written in 16-byte pieces and read back by the finalising kernel -- a tenth of the run.)
+    double *const t1_row = a.part_t1 + (((size_t)grp * a.n_win) * n_half + hc) * 16 + st_q;          // + window * n_half * 16 (+ 8 per turn)
+    double *const t0_row = a.part_t0 + ((size_t)grp * a.n_win) * n_half + hc;                        // + window * n_half
+    double *const ov_row = a.part_ov + ((size_t)grp * a.n_win) * 16 + (lane >> 2);                   // + window * 16
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
+    uint32_t ex_slots = 0;                                           // slots whose comparison individual is one of the wave's lanes
+    if (any_excl)
+        for (uint32_t q = 0; q < cnt; ++q)
+            if (__builtin_amdgcn_ballot_w64((excl >> q) & 1) != 0)
+                ex_slots |= 1u << q;
+    const bool ov_ok = (lane & 3) == 0 && ((ex_slots >> (lane >> 2)) & 1);
     const uint32_t n_quads = (cnt + 3) / 4;                          // groups of four slots that hold comparison individuals
     const uint32_t wcs_base = (uint32_t)(uintptr_t)(lds_void *)wcs;
     const uint32_t eu_lane = wcs_base + 64 * h;                      // + 512 per window: the exponents of U_t(h) of slots 0..15
@@ -519,6 +533,11 @@ void k_ld_mfma(MfmaArgs a)
         // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
         auto window_end = [&](auto with_excl) {
             constexpr bool EX = decltype(with_excl)::value;
+            // The operands of the next two segments were requested during the window's last segments and have landed by
+            // now; saying so here (vmcnt(0), a wait hipcc's counter understands) keeps it from draining the memory queue
+            // at the next window's first segment instead -- behind the stores of this window end, whose number it cannot
+            // count (they sit under conditions) and whose latency the wave would then sit out once per window.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             double t0lo = 0.0, t0hi = 0.0;
             if (!EX) {
                 // the IBD0 addends are the same for all comparison individuals: with more than eight of them the sum rides in
@@ -531,6 +550,8 @@ void k_ld_mfma(MfmaArgs a)
                     s0 = swz_add<8>(s0);
                     s0 = swz_add<16>(s0);
                     t0lo = t0hi = s0;
+                    if (lane == 0)
+                        t0_row[(size_t)w * n_half] = s0;
                 }
             } else {
                 // the IBD0 addend of a lane counts for all comparison individuals but itself: one turn of the strip, half h
@@ -538,10 +559,13 @@ void k_ld_mfma(MfmaArgs a)
 #define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> (8 * h + I)) & 1 ? 0.0 : wP2);
                 IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
 #undef IBDG_PUT0
-                const double t = strip_sum(get_addr);          // quad s: slot s
-                t0lo = t;                                      // lanes 0..31: slots 0..7
-                const uint32_t lo = from_upper_half((uint32_t)__double2loint(t)), hi = from_upper_half((uint32_t)__double2hiint(t));
-                t0hi = __hiloint2double((int)hi, (int)lo);     // slots 8..15 in the lanes that store them
+                const double t = strip_sum(get_addr);          // quad s: slot s; slot 15 holds no individual: the sum over all lanes
+                if (ov_ok)
+                    ov_row[(size_t)w * 16] = t;
+                if (lane == 60)
+                    t0_row[(size_t)w * n_half] = t;
+                (void)t0lo;
+                (void)t0hi;
             }
 #define IBDG_QUAD(R0, EU)                                                                                    \
             {                                                                                                \
@@ -560,21 +584,17 @@ void k_ld_mfma(MfmaArgs a)
             }
             // a turn's sums: quad s of half h holds S_h of slot (s & 7) + 8 turn; the lanes that store add the two haplotypes:
             // mU_t0 S_0 + mU_t1 S_1 (the reference's ((Q00 + Q01) + Q10) + Q11 up to the association)
-#define IBDG_TURN_END(TURN, OK, ROW, T0)                                                                     \
+#define IBDG_TURN_END(TURN, OK)                                                                              \
             {                                                                                                \
                 double mu;                                                                                   \
                 const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, mu);                           \
-                if (!EX && TURN == 1) {                    /* row 7 = the IBD0 sum over the half: quad 7 has it */ \
-                    const int lo = __builtin_amdgcn_readlane(__double2loint(S), 28);                         \
-                    const int hi = __builtin_amdgcn_readlane(__double2hiint(S), 28);                         \
-                    t0lo = t0hi = __hiloint2double(hi, lo);                                                  \
-                }                                                                                            \
+                if (!EX && TURN == 1 && lane == 28)        /* row 7 = the IBD0 sum over the half: quad 7 has it */ \
+                    t0_row[(size_t)w * n_half] = S;                                                          \
                 const double part = mu * S;                                                                  \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
                 const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
                 if (OK)                                                                                      \
-                    *reinterpret_cast<double2 *>(a.partial + ROW + (size_t)w * n_half * 2) =                 \
-                        make_double2(T0, part + __hiloint2double((int)phi, (int)plo));                       \
+                    t1_row[(size_t)w * n_half * 16 + 8 * TURN] = part + __hiloint2double((int)phi, (int)plo); \
             }
             if (n_quads > 2) {                         // slots 8..15 first (their turn brings the IBD0 sum along)
                 IBDG_QUAD(8, eu_addr)
@@ -582,13 +602,13 @@ void k_ld_mfma(MfmaArgs a)
                     IBDG_QUAD(12, eu_addr)
                 if (!EX)
                     strip_put<7>(put_addr, wP2);
-                IBDG_TURN_END(1, st_ok1, st_row1, t0hi)
+                IBDG_TURN_END(1, st_ok1)
             }
             {
                 IBDG_QUAD(0, eu_addr)
                 if (n_quads > 1)
                     IBDG_QUAD(4, eu_addr)
-                IBDG_TURN_END(0, st_ok0, st_row0, t0lo)
+                IBDG_TURN_END(0, st_ok0)
             }
 #undef IBDG_QUAD
 #undef IBDG_TURN_END
@@ -614,6 +634,7 @@ void k_ld_mfma(MfmaArgs a)
         window_end_all();
         return !(n_more & 1);
     };
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // (vmcnt(0): the first two segments' operands, so that the loop's first wait is a counted one on every path into it)
     while (w < w1) {
         if (window(xq0, aq0, xq1, aq1)) {
             // from slot 1 until another odd window brings the run back to slot 0
@@ -621,6 +642,55 @@ void k_ld_mfma(MfmaArgs a)
             }
         }
     }
+}
+
+// The window averages of a group's comparison individuals from the half chunks' partial sums (src/ibdgem.c:736-753):
+// a wave per (window, group).  IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four
+// part sums of a slot meet as ((j0 + j1) + j2) + j3.  IBD0: lane q < 16 adds t0[hc] over all half chunks in order, with the
+// slot's own value ov[q] in place of the half chunk its comparison individual sits in.  Fixed orders: the same bits every run.
+__global__ __launch_bounds__(64) void k_ld_finalize_g(MfmaArgs a, const int *__restrict__ n_refpanel, double *__restrict__ win_ll)
+{
+    __shared__ double t0s[256];
+    const uint32_t w = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
+    const uint32_t n_half = 2 * a.n_chunks, q = lane & 15, j = lane >> 4;
+    const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
+    const double *t1 = a.part_t1 + (((size_t)grp * a.n_win + w) * n_half) * 16;
+    const double *t0 = a.part_t0 + ((size_t)grp * a.n_win + w) * n_half;
+    double acc = 0.0;
+    for (uint32_t hc = j; hc < n_half; hc += 4)
+        acc += t1[(size_t)hc * 16 + q];
+    const double a1 = __shfl(acc, q + 16), a2 = __shfl(acc, q + 32), a3 = __shfl(acc, q + 48);
+    const double s1 = ((acc + a1) + a2) + a3;                  // (lanes 0..15 hold the totals)
+    double s0 = 0.0;
+    const bool real = lane < cnt;
+    const uint32_t tgt = real ? a.targets[a.t_base + grp * TG + lane] : 0u;
+    const uint32_t hc_own = tgt >> 5;                            // the half chunk (32 individuals) the slot's own individual sits in
+    const double ov = real ? a.part_ov[((size_t)grp * a.n_win + w) * 16 + lane] : 0.0;
+    for (uint32_t base = 0; base < n_half; base += 256) {      // (2 x chunks half chunks: 80 at 2504 individuals)
+        const uint32_t n = n_half - base < 256 ? n_half - base : 256;
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64)
+            t0s[i] = t0[base + i];
+        __syncthreads();
+        if (real)
+            for (uint32_t i = 0; i < n; ++i)
+                s0 += base + i == hc_own ? ov : t0s[i];
+    }
+    if (real) {
+        const uint32_t t = a.t_base + grp * TG + lane;
+        const int nref = n_refpanel[t];
+        const double mK = a.wconst[w].mK;             // mantissa of K' (its exponent went into every term)
+        double *o = win_ll + ((size_t)t * a.n_win + w) * 3;
+        o[0] = (s0 * mK) / (double)nref;
+        o[1] = (s1 * mK) / (double)(nref * 4);
+    }
+}
+
+void launch_ld_finalize_g(const MfmaArgs &a, unsigned n_groups, const int *n_refpanel, double *win_ll, hipStream_t st)
+{
+    if (a.n_win == 0 || n_groups == 0)
+        return;
+    hipLaunchKernelGGL(k_ld_finalize_g, dim3(a.n_win, n_groups), dim3(64), 0, st, a, n_refpanel, win_ll);
 }
 
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st)
