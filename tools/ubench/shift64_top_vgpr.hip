@@ -44,6 +44,42 @@ __global__ __launch_bounds__(256) void k2(unsigned long long *bad, unsigned long
     }
 }
 
+// the siblings: v_lshrrev_b64 / v_ashrrev_i64 of the constant 0x8000000000000000 by the lane number held in v23 (last of 24)
+template <int ARITH>
+__global__ __launch_bounds__(256) void k3(unsigned long long *bad, unsigned long long *bad_like_v0, int iters)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long wrong = 0, like_v0 = 0;
+    const uint64_t top = 0x8000000000000000ull;
+    for (int it = 0; it < iters; ++it) {
+        uint64_t one, res;
+        if (ARITH)
+            asm volatile("v_mov_b32 v23, %2\n\t"
+                         "v_lshlrev_b64 v[0:1], v23, 1\n\t"
+                         "v_ashrrev_i64 %1, v23, %3\n\t"
+                         "v_mov_b64 %0, v[0:1]"
+                         : "=&v"(one), "=&v"(res) : "v"(lane), "v"(top) : "v0", "v1", "v22", "v23");
+        else
+            asm volatile("v_mov_b32 v23, %2\n\t"
+                         "v_lshlrev_b64 v[0:1], v23, 1\n\t"
+                         "v_lshrrev_b64 %1, v23, %3\n\t"
+                         "v_mov_b64 %0, v[0:1]"
+                         : "=&v"(one), "=&v"(res) : "v"(lane), "v"(top) : "v0", "v1", "v22", "v23");
+        const uint64_t want = ARITH ? (uint64_t)((int64_t)top >> lane) : top >> lane;
+        const uint32_t a0 = (uint32_t)one & 63;
+        const uint64_t v0way = ARITH ? (uint64_t)((int64_t)top >> a0) : top >> a0;
+        if (res != want) {
+            ++wrong;
+            if (res == v0way)
+                ++like_v0;
+        }
+    }
+    if (wrong) {
+        atomicAdd(bad, wrong);
+        atomicAdd(bad_like_v0, like_v0);
+    }
+}
+
 template <int TOP, int BARRIER>
 __global__ __launch_bounds__(256) void k(unsigned long long *bad, unsigned long long *bad_like_v0, int iters)
 {
@@ -107,6 +143,20 @@ static void run2(const char *what, unsigned long long *d)
            256ull * 16 * 256 * 2000, h[1]);
 }
 
+template <int ARITH>
+static void run3(const char *what, unsigned long long *d)
+{
+    (void)hipMemset(d, 0, 16);
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k3<ARITH>));
+    hipLaunchKernelGGL((k3<ARITH>), dim3(256 * 16), dim3(256), 0, 0, d, d + 1, 2000);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[2];
+    (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("%-44s VGPRs %d: %llu wrong results of %llu (%llu of them = shifted by low6(v0))\n", what, fa.numRegs, h[0],
+           256ull * 16 * 256 * 2000, h[1]);
+}
+
 int main()
 {
     unsigned long long *d;
@@ -117,6 +167,8 @@ int main()
     run<0, 1>("amount in v22, barrier per turn (control)", d);
     run2<0>("amount in v15, 24 registers allocated", d);
     run2<1>("amount in v23, 32 registers allocated", d);
+    run3<0>("v_lshrrev_b64, amount in v23 (last of 24)", d);
+    run3<1>("v_ashrrev_i64, amount in v23 (last of 24)", d);
     (void)hipFree(d);
     return 0;
 }
