@@ -624,6 +624,29 @@ def test_sparse_pileup_rows_far_apart(oracle):
     assert_bits(got[0, 0], got[2, 0], "auto = compacted")
 
 
+def test_rows_tens_of_thousands_of_panel_rows_apart(oracle):
+    """A handful of sites whose panel rows lie further apart than the control words of the panel's own tiles can say (more
+    than 255 tile pairs between two segments of a run): the compacted tiles take them; with those forbidden, the strict
+    kernel -- never an error, never a wrong window."""
+    N, Lp = 70, 130000
+    rng = np.random.default_rng(17)
+    alle = (rng.random((Lp, 2 * N)) < 0.3).astype(np.uint8)
+    keep = np.array([10, 11, 40000, 40001, 40002, 90000, 129998, 129999], dtype=np.uint32)
+    nr = rng.integers(1, 4, size=len(keep)).astype(np.uint8)
+    na = rng.integers(0, 3, size=len(keep)).astype(np.uint8)
+    res = oracle.compare(alle[keep], nr, na, 5, window=3, ld=True)
+    for tiles, variant, layout in ((0, 2, 2), (-1, 1, 0)):
+        with E.Engine() as eng:
+            eng.set_option("compact_tiles", tiles)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(keep, nr, na, 3)
+            eng.run([5], ld=True)
+            assert eng.last_ld_variant() == variant and eng.ld_layout() == layout
+            assert_bits(eng.site_ll(0), res["site"], "site")
+            assert_bits(eng.window_ll(0)[:, 2], res["win"][:, 2], "LIBD2")
+            assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"tiles={tiles}")
+
+
 @pytest.mark.parametrize("N,L,W,M,cov,T", [(150, 2600, 100, 20, 2.0, 1), (70, 900, 2, 20, 2.0, 2), (131, 1700, 33, 3, 1.0, 4),
                                             (300, 3000, 64, 20, 0.4, 9), (700, 5000, 257, 40, 9.0, 17), (64, 640, 32, 20, 2.0, 5),
                                             (2504, 1300, 100, 20, 2.0, 3), (130, 4000, 31, 20, 5.0, 31)])
