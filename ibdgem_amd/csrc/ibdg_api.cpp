@@ -163,6 +163,7 @@ struct ibdg_ctx {
     bool opt_wpg_fixed = false;
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
     long opt_mfma_targets = 1;   // 5 or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma)
+    long opt_mfma_plain_tau = 1; // k_ld_mfma looks tau^G up as a plain double where a window's powers allow it (same bits, half the LDS bytes)
     long opt_mfma_min = 3;       // smallest (last) group worth a launch of its own (round 4: a group of 3 takes 2.15 ms, three single runs 2.5; of 4: 2.09 against 2.30 through k_ld_popcount_mt; of 2: 2.13 against 1.76)
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
@@ -1513,6 +1514,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.pow_eps = pa.pow_eps;
             ma.pow_tau = (const ibdg::PowEntry *)c->pow3.p;
             ma.tab_len = pa.tab_len;
+            ma.plain_tau = c->opt_mfma_plain_tau ? 1u : 0u;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
             {
@@ -1827,6 +1829,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "count_in_run")) { c->opt_count_in_run = value != 0; return 0; }
     if (!strcmp(name, "multi_target")) { c->opt_multi_target = value != 0; return 0; }
     if (!strcmp(name, "mfma_targets")) { c->opt_mfma_targets = value != 0; return 0; }
+    if (!strcmp(name, "mfma_plain_tau")) { c->opt_mfma_plain_tau = value != 0; return 0; }
     if (!strcmp(name, "mfma_min")) {
         if (value < 1 || value > IBDG_TG) return fail(c, "[::] ERROR in ibdg_set_option: mfma_min must be 1..%d", IBDG_TG);
         c->opt_mfma_min = value;

@@ -157,6 +157,7 @@ struct MfmaArgs {
                                 // (U_t = rho^-<t,alt> sigma^<t,cov>)
     const PowEntry *pow_1me, *pow_eps, *pow_tau;    // rho^n, sigma^n, tau^n = (rho / sigma^2)^n
     uint32_t tab_len;
+    uint32_t plain_tau;         // 1: windows whose powers tau^G are all ordinary doubles look them up as such (8 bytes); 0: never
     const uint32_t *targets;    // [T]
     uint32_t t_base;            // first comparison individual of group 0 of this launch
     uint32_t n_targets;         // comparison individuals of this launch (groups of IBDG_TG, the last may be short)

@@ -28,7 +28,8 @@
 //     result register r of lane half h holds G(x, t_h) of comparison individual r for the lane's background
 //     individual: a lane finishes its individual against ONE haplotype of all 16 slots, the two halves of the wave
 //     the two haplotypes.  The B operand carries 16 for a set bit, so a register IS 16 G(x,t) -- the byte offset of
-//     tau^G in a table of 16-byte entries that sits at LDS address 0: no instruction forms a look-up address.
+//     tau^G in a table of plain doubles that sits at LDS address 0: no instruction forms a look-up address (a window whose
+//     powers leave the double range takes the {mantissa, exponent} table beside it).
 //     The exponents of a product are (header of ibdg_ld_popcount.hip)
 //         E2 = AT - <t,alt> - A(x) + G(x,t),   E3 = <t,cov> + C(x) - 2 G(x,t),
 //     so with tau = rho / sigma^2 = 4 eps (1-eps) the product factors into three parts,
@@ -227,14 +228,17 @@ __device__ __forceinline__ void slots_swap(uint2 &x0, uint4 &a0, uint2 &x1, uint
 // reference's Q(x0,t) + Q(x1,t) of ibdgem.c:716-719 without the mantissa of U_t (applied after the sum over the
 // background, which it does not depend on).
 template <int R0>
-__device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mV0, double mV1, int eV0,
-                                          int eV1, double (&out)[4])
+__device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, uint32_t tau16, double mV0,
+                                          double mV1, int eV0, int eV1, double (&out)[4])
 {
+    // the general form: tau^G as {mantissa, exponent}, 16 bytes per entry at tau16 + 2 x (8 G)
     uint4 p[8], eu;              // eu: the exponents of U of the four slots (wave-half uniform address: a broadcast read)
-#ifdef IBDG_EXP_NOTAU
-    for (int i = 0; i < 8; ++i) p[i] = make_uint4((uint32_t)acc0[R0 + (i >> 1)], 0x3fe00000u, (uint32_t)acc1[R0 + (i >> 1)] & 3, 0);
-    eu = make_uint4(eu_addr & 1, 0, 1, 0);
-#else
+    uint32_t ad[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(ad[2 * j]) : "v"(acc0[R0 + j]), "s"(tau16));
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(ad[2 * j + 1]) : "v"(acc1[R0 + j]), "s"(tau16));
+    }
     asm volatile("ds_read_b128 %0, %9\n\t"
                  "ds_read_b128 %1, %10\n\t"
                  "ds_read_b128 %2, %11\n\t"
@@ -246,16 +250,48 @@ __device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, ui
                  "ds_read_b128 %8, %17 offset:%18\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(eu)
-                 : "v"(acc0[R0]), "v"(acc1[R0]), "v"(acc0[R0 + 1]), "v"(acc1[R0 + 1]), "v"(acc0[R0 + 2]), "v"(acc1[R0 + 2]),
-                   "v"(acc0[R0 + 3]), "v"(acc1[R0 + 3]), "v"(eu_addr), "n"(4 * R0)
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "v"(eu_addr),
+                   "n"(4 * R0)
                  : "memory");
-#endif
     const int e[4] = {(int)eu.x, (int)eu.y, (int)eu.z, (int)eu.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint4 &p0 = p[2 * j], &p1 = p[2 * j + 1];
         const double q0 = __builtin_ldexp(mV0 * __hiloint2double((int)p0.y, (int)p0.x), eV0 + (int)p0.z + e[j]);
         const double q1 = __builtin_ldexp(mV1 * __hiloint2double((int)p1.y, (int)p1.x), eV1 + (int)p1.z + e[j]);
+        out[j] = q0 + q1;
+    }
+}
+
+// The same for a window all of whose powers tau^G are ordinary doubles (G <= the window's reads, and tau^reads has not
+// left the double range: nearly every window): the look-up is 8 bytes at LDS address 8 G -- the accumulator itself -- and
+// the product's exponent is the lane's and the slot's alone.  mV tau^G = (mV mtau) 2^etau exactly, so the values are the
+// bits of the general form; the LDS port, the busiest unit of this kernel, moves half the bytes.
+template <int R0>
+__device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mV0, double mV1,
+                                               int eV0, int eV1, double (&out)[4])
+{
+    double p[8];
+    uint4 eu;
+    asm volatile("ds_read_b64 %0, %9\n\t"
+                 "ds_read_b64 %1, %10\n\t"
+                 "ds_read_b64 %2, %11\n\t"
+                 "ds_read_b64 %3, %12\n\t"
+                 "ds_read_b64 %4, %13\n\t"
+                 "ds_read_b64 %5, %14\n\t"
+                 "ds_read_b64 %6, %15\n\t"
+                 "ds_read_b64 %7, %16\n\t"
+                 "ds_read_b128 %8, %17 offset:%18\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(eu)
+                 : "v"(acc0[R0]), "v"(acc1[R0]), "v"(acc0[R0 + 1]), "v"(acc1[R0 + 1]), "v"(acc0[R0 + 2]), "v"(acc1[R0 + 2]),
+                   "v"(acc0[R0 + 3]), "v"(acc1[R0 + 3]), "v"(eu_addr), "n"(4 * R0)
+                 : "memory");
+    const int e[4] = {(int)eu.x, (int)eu.y, (int)eu.z, (int)eu.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double q0 = __builtin_ldexp(mV0 * p[2 * j], eV0 + e[j]);
+        const double q1 = __builtin_ldexp(mV1 * p[2 * j + 1], eV1 + e[j]);
         out[j] = q0 + q1;
     }
 }
@@ -322,7 +358,7 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 // the run's segment records, a reduction strip per wave
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
 {
-    return (size_t)win_per_group * 33 * 16 + (size_t)tab_len * 48 + ((size_t)max_seg + 1) * 32 +
+    return (size_t)win_per_group * 33 * 16 + (size_t)tab_len * 56 + 16 + ((size_t)max_seg + 1) * 32 +
            (size_t)IBDG_MFMA_WAVES * 16 * SS * 8;
 }
 
@@ -344,18 +380,22 @@ void k_ld_mfma(MfmaArgs a)
         return;
 
     // The tau table comes first: the kernel has no static LDS, so the table sits at LDS address 0 and the accumulators --
-    // 16 G -- are its entries' addresses as they are (hipcc itself folds the table's address to the constant 0; every
+    // 8 G -- are its entries' addresses as they are (hipcc itself folds the table's address to the constant 0; every
     // parity test of this kernel would fail if that ever changed).
-    uint4 *tau = reinterpret_cast<uint4 *>(smem);                  // tau^n
-    uint4 *wcc = tau + a.tab_len;                                   // [win_per_group] eK, 16 AT + rho table, sigma table, segment end
+    double *taud = reinterpret_cast<double *>(smem);               // tau^n as plain doubles (0 where it has left their range): LDS address 8 n
+    uint4 *tau = reinterpret_cast<uint4 *>(taud + ((a.tab_len + 1) & ~1u));      // tau^n as {mantissa, exponent}
+    uint4 *wcc = tau + a.tab_len;                                   // [win_per_group] eK, 16 AT + rho table, sigma table, segment end | all powers plain
     uint4 *wcs = wcc + a.win_per_group;                             // [win_per_group][32]: exponents of U_t0 (4), of U_t1 (4), 16 x two mantissas
     uint4 *tab = wcs + (size_t)a.win_per_group * 32;                // rho^n, sigma^n
     uint4 *rec = tab + 2 * (size_t)a.tab_len;              // [max_seg][2] tile, cov planes | the first six cov masks
     double *strip = reinterpret_cast<double *>(rec + 2 * ((size_t)a.max_seg + 1)) + (size_t)wave * 16 * SS;   // this wave's
     const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab, tab2 = tab1 + a.tab_len * 16;
+    const uint32_t tau16 = (uint32_t)(uintptr_t)(lds_void *)tau;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
-        wcc[i] = make_uint4((uint32_t)W.eK, 16 * W.alt_total + tab1, tab2, a.wconst[w0 + i + 1].seg_begin);
+        // (no G(x,t) of the window exceeds its reads: when tau^reads is still an ordinary double, all its look-ups are)
+        const uint32_t plain = a.plain_tau && a.pow_tau[W.cov_total].e >= -1000 ? 1u << 31 : 0u;
+        wcc[i] = make_uint4((uint32_t)W.eK, 16 * W.alt_total + tab1, tab2, a.wconst[w0 + i + 1].seg_begin | plain);
     }
     {
         const uint4 *src = a.wc_slot + ((size_t)grp * a.n_win + w0) * 32;
@@ -364,6 +404,7 @@ void k_ld_mfma(MfmaArgs a)
     }
     for (uint32_t i = threadIdx.x; i < a.tab_len; i += blockDim.x) {
         tau[i] = reinterpret_cast<const uint4 *>(a.pow_tau)[i];
+        taud[i] = a.pow_tau[i].e >= -1000 ? __builtin_ldexp(a.pow_tau[i].m, a.pow_tau[i].e) : 0.0;
         tab[i] = reinterpret_cast<const uint4 *>(a.pow_1me)[i];
         tab[a.tab_len + i] = reinterpret_cast<const uint4 *>(a.pow_eps)[i];
     }
@@ -395,9 +436,10 @@ void k_ld_mfma(MfmaArgs a)
             excl |= 1u << q;
     const uint4 *xt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64 + 32 * (hc & 1) + n;   // + pair * 64
     const uint4 *ai = a.aimg + (size_t)grp * a.n_segs * 64 + lane;                                              // + segment * 64
-    // B operand: 16 where the individual carries the alt allele on tile row 4 h + d + 8 j (byte j of dword d of lane
-    // half h): y = x << (4 - 4 h) has that bit at 4 + d + 8 j, so dword d = (y >> d) & 0x10101010
-    const uint32_t sh = 4 - 4 * h;
+    // B operand: 8 where the individual carries the alt allele on tile row 4 h + d + 8 j (byte j of dword d of lane
+    // half h): y = x rotated so that that bit sits at 3 + d + 8 j (left by 3 in the lower half of the wave, right by 1
+    // in the upper; what wraps around lands where no mask looks), so dword d = (y >> d) & 0x08080808
+    const uint32_t rot = h ? 1u : 29u;
 
     // the reduction strip: lane (h, n) puts its addend I of a turn at row 8 h + I, column n; lane L = 4 s + p reads row s
     const uint32_t put_addr = (uint32_t)(uintptr_t)(lds_void *)strip + (8 * h * SS + n) * 8;
@@ -462,11 +504,11 @@ void k_ld_mfma(MfmaArgs a)
         r_cur = rec_p[2];                    // (behind the run's last record: a spare one, never used)
         const uint2 x = xq;
         const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
-        const uint32_t b0 = x.x << sh, b1 = x.y << sh;
-        const v4i B0 = {(int)(b0 & 0x10101010u), (int)((b0 >> 1) & 0x10101010u), (int)((b0 >> 2) & 0x10101010u),
-                        (int)((b0 >> 3) & 0x10101010u)};
-        const v4i B1 = {(int)(b1 & 0x10101010u), (int)((b1 >> 1) & 0x10101010u), (int)((b1 >> 2) & 0x10101010u),
-                        (int)((b1 >> 3) & 0x10101010u)};
+        const uint32_t b0 = __builtin_amdgcn_alignbit(x.x, x.x, rot), b1 = __builtin_amdgcn_alignbit(x.y, x.y, rot);
+        const v4i B0 = {(int)(b0 & 0x08080808u), (int)((b0 >> 1) & 0x08080808u), (int)((b0 >> 2) & 0x08080808u),
+                        (int)((b0 >> 3) & 0x08080808u)};
+        const v4i B1 = {(int)(b1 & 0x08080808u), (int)((b1 >> 1) & 0x08080808u), (int)((b1 >> 2) & 0x08080808u),
+                        (int)((b1 >> 3) & 0x08080808u)};
         const uint32_t hom = x.x & x.y;
         uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
         if (ctl & (1u << 24)) {              // deep rows (cov >= 8): max_cov < 128, seven planes at most
@@ -498,7 +540,8 @@ void k_ld_mfma(MfmaArgs a)
         // register 15 = the weights' own rows: 16 C(x) in the lower half of the wave, 16 A(x) in the upper
         const auto w0s = __builtin_amdgcn_permlane32_swap((uint32_t)acc0[15], (uint32_t)acc0[15], false, false);
         const auto w1s = __builtin_amdgcn_permlane32_swap((uint32_t)acc1[15], (uint32_t)acc1[15], false, false);
-        const uint32_t C0s = w0s[0], A0s = w0s[1], C1s = w1s[0], A1s = w1s[1];        // 16 C(x0), 16 A(x0), 16 C(x1), 16 A(x1)
+        const uint32_t C0s = 2 * w0s[0], A0s = 2 * w0s[1], C1s = 2 * w1s[0], A1s = 2 * w1s[1];   // 16 C(x0), 16 A(x0), 16 C(x1), 16 A(x1)
+        const bool plain = (__builtin_amdgcn_readfirstlane(kc.w) >> 31) != 0;
         const int eK = (int)kc.x;
         double wP2, mV0, mV1;
         int eV0, eV1;
@@ -570,7 +613,10 @@ void k_ld_mfma(MfmaArgs a)
 #define IBDG_QUAD(R0, EU)                                                                                    \
             {                                                                                                \
                 double v[4];                                                                                 \
-                comp_quad<R0>(acc0, acc1, EU, mV0, mV1, eV0, eV1, v);                                        \
+                if (plain)                                                                                   \
+                    comp_quad_fast<R0>(acc0, acc1, EU, mV0, mV1, eV0, eV1, v);                               \
+                else                                                                                         \
+                    comp_quad<R0>(acc0, acc1, EU, tau16, mV0, mV1, eV0, eV1, v);                             \
                 if (EX) {                                                                                    \
                     v[0] = (excl >> (R0)) & 1 ? 0.0 : v[0];                                                  \
                     v[1] = (excl >> (R0 + 1)) & 1 ? 0.0 : v[1];                                              \
@@ -623,7 +669,7 @@ void k_ld_mfma(MfmaArgs a)
     // whether it had an odd number of segments: the next window then starts from the other slot -- the same code with the
     // slots' roles exchanged (nothing moves: the loads in flight land where the next segments look for them).
     auto window = [&](uint2 &xa, uint4 &aa, uint2 &xb, uint4 &ab) -> bool {
-        const uint32_t n_more = __builtin_amdgcn_readfirstlane(wcc[w - w0].w) - s - 1;     // segments behind the first
+        const uint32_t n_more = (__builtin_amdgcn_readfirstlane(wcc[w - w0].w) & 0x7fffffffu) - s - 1;     // segments behind the first
         segment(xa, aa, std::true_type());
         for (uint32_t i = n_more >> 1; i > 0; --i) {
             segment(xb, ab, std::false_type());

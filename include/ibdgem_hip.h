@@ -242,7 +242,9 @@ int ibdg_ld_layout(const ibdg_ctx *ctx);
  * the exponent-counting kernel -- same results, ~1.4x the throughput); "mfma_targets" (0/1,
  * default 1: with "mfma_min" (1..15, default 3) or more comparison individuals in one ibdg_run,
  * groups of 15 go through the matrix-core kernel -- the sums that depend on the comparison
- * individual as integer matrix products; same results, ~2.5x the throughput of single runs).
+ * individual as integer matrix products; same results, ~2.5x the throughput of single runs; "mfma_plain_tau"
+ * (0/1, default 1: that kernel looks the powers tau^G of a window up as plain doubles where none of them leaves the
+ * double range -- the same bits as the {mantissa, exponent} table it uses otherwise, half the LDS traffic)).
  * Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
 

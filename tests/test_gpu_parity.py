@@ -679,6 +679,32 @@ def test_compacted_tiles_give_the_bits_of_the_panel_tiles(oracle, N, L, W, M, co
         assert_ld_close(out[1][i][1][:, :2], res["win"][:, :2], f"compacted tiles t={targets[i]}")
 
 
+@pytest.mark.parametrize("eps,M,cov", [(0.02, 20, 2.0), (0.001, 40, 9.0), (0.3, 20, 6.0)])
+def test_plain_double_powers_in_the_matrix_core_kernel_change_no_bit(eps, M, cov):
+    """k_ld_mfma looks tau^G up as a plain double (8 bytes) in windows none of whose powers leaves the double range, and
+    as {mantissa, exponent} (16 bytes) otherwise: mV tau^G = (mV mtau) 2^etau exactly, so the two forms give the same
+    bits -- with a tiny error rate (tau = 4e-3: the plain form covers windows of up to ~125 reads only) both run in one launch."""
+    N, L, T = 150, 2600, 17
+    rng = np.random.default_rng(int(eps * 1000) + M)
+    f = rng.beta(0.4, 1.0, size=L).clip(1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
+    got = {}
+    for plain in (1, 0):
+        with E.Engine(0, eps, M) as eng:
+            eng.set_option("mfma_plain_tau", plain)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, 100)
+            eng.run(targets, ld=True)
+            assert eng.last_ld_variant() == 2
+            got[plain] = [eng.window_ll(i) for i in range(T)]
+    for i in range(T):
+        assert_bits(got[1][i], got[0][i], f"target {targets[i]}")
+
+
 def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
     """A run with "compact_targets" or more comparison individuals re-lays the site list out once (the site list belongs
     to the pileup, src/ibdgem.c:522); later runs on the same upload keep the compacted tiles; results unchanged."""
