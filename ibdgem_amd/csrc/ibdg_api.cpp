@@ -175,7 +175,8 @@ struct ibdg_ctx {
     long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
-    long opt_compact_density = 3;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
+    long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
+                                     // (tools/density_sweep.py: one comparison at 1 row in 3: 0.82 ms in place, 0.94 compacted; in 4: 0.76 / 0.76; in 5: 0.79 / 0.65)
     long opt_compact_targets = 256;  // ... or when a run has at least this many comparison individuals (the re-layout is paid once)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
@@ -783,7 +784,7 @@ int build_segments(ibdg_ctx *c, bool compact)
 // Sparse coverage: on the panel's own tiles the exponent-counting kernels stream every 32-row tile between a
 // window's first and last row, whether its rows carry reads or not; on the compacted tiles a window costs
 // ceil(window / 32) tile words whatever the density, plus its share of the gather (~6 tile words' worth of time per
-// 100 rows).  Below about one covered row in three the compacted layout is the faster one for a single run.
+// 100 rows).  Below about one covered row in four the compacted layout is the faster one for a single run.
 bool sparse_sites(const ibdg_ctx *c)
 {
     if (c->last_row < c->first_row)

@@ -231,7 +231,7 @@ int ibdg_ld_layout(const ibdg_ctx *ctx);
  * 1 = strict, 2 = exponent counting, an error if not applicable, 3 = reference
  * order);
  * "compact_tiles" (set before ibdg_upload_sites: 0, the default = the compacted tiles of ibdg_ld_layout when fewer than
- * one panel row in "compact_density" (default 3) between the first and the last site carries reads, when the rows
+ * one panel row in "compact_density" (default 4) between the first and the last site carries reads, when the rows
  * are not in file order, or when a run has "compact_targets" (default 256) or more comparison individuals, the panel's
  * own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
