@@ -9,6 +9,10 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 dev = torch.device("cuda", 0)
 panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
 eng = ibdgem_amd.Engine(0, 0.02, 20, lib_path=os.environ.get("IBDG_LIB") or None)
+for kv in os.environ.get("IBDG_OPTS", "").split(","):          # e.g. IBDG_OPTS=compact_tiles=1: the re-layout inside every upload
+    if kv:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 eng.upload_panel_dev(panel.data_ptr(), rows, 2504)
 del panel
 torch.cuda.empty_cache()
