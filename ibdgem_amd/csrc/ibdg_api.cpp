@@ -1431,7 +1431,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         size_t n_gg = 0, T_g = 0;
         // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
         const size_t group_bytes = (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128) + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
-        if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && (c->compact ? c->n_pairs_c : c->n_pairs) < (1u << 23) &&
+        if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && (c->compact ? c->n_pairs_c : c->n_pairs) < (1u << 21) && c->n_segs < (1u << 21) &&     // (32-bit byte offsets of its buffer loads)
             group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
             n_gg = T / TGs;

@@ -434,8 +434,16 @@ void k_ld_mfma(MfmaArgs a)
     for (uint32_t q = 0; q < cnt; ++q)
         if (a.targets[a.t_base + grp * TG + q] == indiv)
             excl |= 1u << q;
-    const uint4 *xt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64 + 32 * (hc & 1) + n;   // + pair * 64
-    const uint4 *ai = a.aimg + (size_t)grp * a.n_segs * 64 + lane;                                              // + segment * 64
+    // The operand loads go through buffer instructions: wave-uniform base (a resource descriptor in scalar registers: this
+    // wave's chunk of the tiles, this group's target image), a scalar byte offset per segment, a constant 32-bit offset
+    // per lane -- no vector instruction forms an address (a per-lane 64-bit pointer cost three 64-bit vector additions
+    // per segment).  The offsets stay below 2^31: n_pairs < 2^21 tile pairs per chunk, n_segs < 2^21 segments per group
+    // (checked by the host before it picks this kernel).
+    const __amdgpu_buffer_rsrc_t xt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(reinterpret_cast<const uint4 *>(a.t32) + (size_t)c * a.n_pairs * 64), 0, 0x7fffffff, 0x00020000);
+    const uint32_t x_lane = (32 * (hc & 1) + n) * 16;
+    const __amdgpu_buffer_rsrc_t ai_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aimg + (size_t)grp * a.n_segs * 64, 0, 0x7fffffff, 0x00020000);
+    const uint32_t a_lane = lane * 16;
     // B operand: 8 where the individual carries the alt allele on tile row 4 h + d + 8 j (byte j of dword d of lane
     // half h): y = x rotated so that that bit sits at 3 + d + 8 j (left by 3 in the lower half of the wave, right by 1
     // in the upper; what wraps around lands where no mask looks), so dword d = (y >> d) & 0x08080808
@@ -481,8 +489,10 @@ void k_ld_mfma(MfmaArgs a)
     uint2 xq0, xq1;
     uint4 aq0, aq1;
     auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
-        xq = reinterpret_cast<const uint2 *>(xt + (size_t)(tile >> 1) * 64)[tile & 1];
-        aq = ai[(size_t)seg * 64];
+        const auto xv = __builtin_amdgcn_raw_buffer_load_b64(xt_rsrc, x_lane, (tile >> 1) * 1024 + (tile & 1) * 8, 0);
+        const auto av = __builtin_amdgcn_raw_buffer_load_b128(ai_rsrc, a_lane, seg * 1024, 0);
+        xq = make_uint2(xv[0], xv[1]);
+        aq = make_uint4(av[0], av[1], av[2], av[3]);
     };
     {
         const uint32_t t0 = a.segs[seg0].tile, s1 = seg0 + 1 < seg1 ? seg0 + 1 : seg0, t1 = a.segs[s1].tile;
