@@ -267,9 +267,15 @@ __device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, ui
 // left the double range: nearly every window): the look-up is 8 bytes at LDS address 8 G -- the accumulator itself -- and
 // the product's exponent is the lane's and the slot's alone.  mV tau^G = (mV mtau) 2^etau exactly, so the values are the
 // bits of the general form; the LDS port, the busiest unit of this kernel, moves half the bytes.
+// The lane's two haplotypes share the slot's exponent, so they are brought to ONE exponent first (mVa = mV0 2^(eV0 - eR),
+// mVb = mV1 2^(eV1 - eR), eR the larger of eV0, eV1: what falls out of the double range on the way is < 2^-1000 of the
+// other addend) and a slot costs two products, one addition and one ldexp -- 5 vector instructions where two separately
+// scaled products cost 7.  Safe: the addend of the larger exponent keeps its mantissa (>= 1/4) and every plain power is
+// >= 2^-1000, so that product is >= 2^-1002; whatever the other product loses to the double range on its way down is
+// < 2^-1074, i.e. < 2^-72 of the sum.  (The rounding differs from the general form's in the last place; the bar is 1e-10.)
 template <int R0>
-__device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mV0, double mV1,
-                                               int eV0, int eV1, double (&out)[4])
+__device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mVa, double mVb,
+                                               int eR, double (&out)[4])
 {
     double p[8];
     uint4 eu;
@@ -289,11 +295,8 @@ __device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc
                  : "memory");
     const int e[4] = {(int)eu.x, (int)eu.y, (int)eu.z, (int)eu.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double q0 = __builtin_ldexp(mV0 * p[2 * j], eV0 + e[j]);
-        const double q1 = __builtin_ldexp(mV1 * p[2 * j + 1], eV1 + e[j]);
-        out[j] = q0 + q1;
-    }
+    for (int j = 0; j < 4; ++j)
+        out[j] = __builtin_ldexp(mVa * p[2 * j] + mVb * p[2 * j + 1], eR + e[j]);
 }
 
 // addend I of the lane into the wave's reduction strip: row (8 h + I), column n
@@ -581,6 +584,8 @@ void k_ld_mfma(MfmaArgs a)
             eV1 = eK + (int)r1.z + (int)s1.z;
         }
         const uint32_t eu_addr = eu_lane + (w - w0) * 512, mu_addr = mu_lane + (w - w0) * 512;
+        const int eR = eV0 > eV1 ? eV0 : eV1;
+        const double mVa = __builtin_ldexp(mV0, eV0 - eR), mVb = __builtin_ldexp(mV1, eV1 - eR);
         // The IBD1 addends of the lane's slots (:744-745) go to the strip, eight slots per turn (a short group occupies the
         // first registers only).  In the few waves that hold one of the group's comparison individuals, that lane's
         // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
@@ -624,7 +629,7 @@ void k_ld_mfma(MfmaArgs a)
             {                                                                                                \
                 double v[4];                                                                                 \
                 if (plain)                                                                                   \
-                    comp_quad_fast<R0>(acc0, acc1, EU, mV0, mV1, eV0, eV1, v);                               \
+                    comp_quad_fast<R0>(acc0, acc1, EU, mVa, mVb, eR, v);                                     \
                 else                                                                                         \
                     comp_quad<R0>(acc0, acc1, EU, tau16, mV0, mV1, eV0, eV1, v);                             \
                 if (EX) {                                                                                    \

@@ -680,10 +680,11 @@ def test_compacted_tiles_give_the_bits_of_the_panel_tiles(oracle, N, L, W, M, co
 
 
 @pytest.mark.parametrize("eps,M,cov", [(0.02, 20, 2.0), (0.001, 40, 9.0), (0.3, 20, 6.0)])
-def test_plain_double_powers_in_the_matrix_core_kernel_change_no_bit(eps, M, cov):
+def test_plain_double_powers_in_the_matrix_core_kernel(eps, M, cov):
     """k_ld_mfma looks tau^G up as a plain double (8 bytes) in windows none of whose powers leaves the double range, and
-    as {mantissa, exponent} (16 bytes) otherwise: mV tau^G = (mV mtau) 2^etau exactly, so the two forms give the same
-    bits -- with a tiny error rate (tau = 4e-3: the plain form covers windows of up to ~125 reads only) both run in one launch."""
+    as {mantissa, exponent} (16 bytes) otherwise: the same value, mV tau^G = (mV mtau) 2^etau; the plain form adds a lane's
+    two haplotypes before it scales them, so the two forms agree to the last place or two, not bit for bit -- with a tiny
+    error rate (tau = 4e-3: the plain form covers windows of up to ~125 reads only) both run in one launch."""
     N, L, T = 150, 2600, 17
     rng = np.random.default_rng(int(eps * 1000) + M)
     f = rng.beta(0.4, 1.0, size=L).clip(1e-3, 0.999)
@@ -702,7 +703,9 @@ def test_plain_double_powers_in_the_matrix_core_kernel_change_no_bit(eps, M, cov
             assert eng.last_ld_variant() == 2
             got[plain] = [eng.window_ll(i) for i in range(T)]
     for i in range(T):
-        assert_bits(got[1][i], got[0][i], f"target {targets[i]}")
+        assert_bits(got[1][i][:, 2], got[0][i][:, 2], f"target {targets[i]} LIBD2")
+        rel = assert_ld_close(got[1][i][:, :2], got[0][i][:, :2], f"target {targets[i]}")
+        assert rel <= 1e-13, rel          # the two forms round differently in the last place, no more
 
 
 def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
