@@ -816,7 +816,9 @@ def main():
     cov_rows = np.flatnonzero((n_ref.astype(np.int32) + n_alt) > 0)
     seg_start = (np.arange(len(cov_rows)) % args.window == 0)
     seg_start[1:] |= (cov_rows[1:] >> 5) != (cov_rows[:-1] >> 5)
-    n_segments = int(seg_start.sum())
+    n_segments_in_place = int(seg_start.sum())
+    # ... and on the compacted tiles: every window starts a tile
+    n_segments_compact = (len(cov_rows) // args.window) * ((args.window + 31) // 32) + (len(cov_rows) % args.window + 31) // 32
     del cov_rows, seg_start
     targets = [args.target]
 
@@ -826,6 +828,21 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    # The engine re-lays a site list out into compacted, window-aligned tiles once the runs on it have added up to what
+    # the gather costs (16 runs of one comparison individual; DESIGN s4.1b -- the reference's own loop runs every
+    # individual of the panel over the same rows, src/ibdgem.c:522).  That happens here, untimed and reported: the
+    # timed steps below are steps of a site list in use, `in_place_tiles` further down is the same step before it.
+    relayout = {"after_runs": None, "run_ms": None}
+    layout0 = eng.ld_layout()
+    for k in range(40):
+        if eng.ld_layout() != layout0:
+            break
+        t_r = time.perf_counter()
+        eng.run(targets, ld=True)
+        eng.sync()
+        relayout = {"after_runs": k + 1, "run_ms": (time.perf_counter() - t_r) * 1e3}
+    if eng.ld_layout() == layout0:
+        relayout = {"after_runs": None, "run_ms": None}
     # clock settling (untimed, before the W warm-up steps of the contract): queued steps for --prewarm-ms of wall time
     eng.set_option("async", 1)
     t_pw = time.perf_counter()
@@ -862,12 +879,14 @@ def main():
     eng.set_option("async", 0)
     ms_all = [eng.run_ms(b) for b in range(min(args.steps, 32))]
     ms_ld = [m["ld"] for m in ms_all]
+    layout_timed = eng.ld_layout()
 
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"metric": "SNP-sites/sec in --LD mode, chr1, 2504-indiv panel", "value": n_cov / (dt / args.steps),
                               "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
+                              "ld_layout": layout_timed, "relayout": relayout,
                               "note": "--timed-only: this rank's clock, no other legs"}))
         eng.close()
         if world > 1:
@@ -910,6 +929,31 @@ def main():
         pass                                 # strict kernel: no such figure
     eng.set_option("async", 0)
     eng.set_option("dispatch_events", 0)
+    # the same step on the panel's own tiles (what the first 15 runs on a site list cost; the timed steps of rounds 1-3):
+    # compacted tiles forbidden, a fresh upload, queued steps after the same clock settling
+    in_place = None
+    if layout_timed == 2 and world == 1:
+        eng.set_option("compact_tiles", -1)
+        eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
+        eng.set_option("async", 1)
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                eng.run(targets, ld=True)
+            eng.sync()
+        n_ip = max(32, min(args.steps, 200))
+        t_ip = time.perf_counter()
+        for _ in range(n_ip):
+            eng.run(targets, ld=True)
+        eng.sync()
+        ip_ms = (time.perf_counter() - t_ip) / n_ip * 1e3
+        eng.set_option("async", 0)
+        ip_ld = float(np.mean([eng.run_ms(b)["ld"] for b in range(32)]))
+        in_place = {"ms_per_step": ip_ms, "ld_launch_ms": ip_ld, "ld_layout": eng.ld_layout(), "steps": n_ip,
+                    "sites_per_s": n_cov / (ip_ms * 1e-3),
+                    "hbm_frac": algorithmic_bytes_per_site(args.ids, 1) * n_cov / (ip_ld * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        eng.set_option("compact_tiles", 0)
+        eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
     up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov, eng2)
     if eng2 is not None:
@@ -971,6 +1015,7 @@ def main():
     many = None
     if world == 1 and not args.no_many:
         many_t = [(args.target + 5 * i) % args.ids for i in range(args.many_targets)]
+        eng.set_option("compact_tiles", -1)         # this part: the panel's own tiles, however many runs it takes (the upload before it left them)
         eng.run(many_t, ld=True)
         best = None
         for _ in range(3):
@@ -991,6 +1036,7 @@ def main():
         eng.set_option("site_results", 1)
         # the same run from the compacted, window-aligned tiles of the site list (the engine switches by itself from
         # "compact_targets" = 256 comparison individuals; forced here): the re-layout is paid once, inside the first run
+        eng.set_option("compact_tiles", 0)
         eng.set_option("compact_targets", 1)
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
         eng.sync()
@@ -1094,8 +1140,14 @@ def main():
             "config": {"workload": f"--LD, {L} SNP rows (synthetic chr1), {args.ids}-individual phased panel, "
                                    f"window {args.window}, 1 comparison individual (BASELINE.json configs[3])",
                        "rows": int(rows_total), "windowed_sites": int(cov_total), "n_ids": args.ids,
-                       "windows_rank0": int(eng.n_windows), "segments_rank0": n_segments,
+                       "windows_rank0": int(eng.n_windows),
+                       "segments_rank0": n_segments_compact if layout_timed == 2 else n_segments_in_place,
+                       "segments_rank0_in_place": n_segments_in_place,
                        "window": args.window, "targets": len(targets), "epsilon": 0.02, "max_cov": 20,
+                       "tiles": ("compacted, window-aligned tiles of the site list (ld_layout 2): the engine re-laid the site list "
+                                 f"out by itself during run {relayout['after_runs']} on it, before the warm-up steps; "
+                                 "`in_place_tiles` is the same step before that") if layout_timed == 2 else
+                                "the panel's own tiles (ld_layout 1)" if layout_timed == 1 else "none (strict kernel)",
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -1117,6 +1169,12 @@ def main():
                          "valu": valu_roofline(float(np.mean(ms_kernel)) if ms_kernel else ld_ms, int(eng.n_windows),
                                                (args.ids + 63) // 64) if world == 1 else None},
             "kernel_ms": kern,
+            "ld_layout": layout_timed,
+            "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows into compacted, "
+                             "window-aligned tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
+                             "untimed; the rule: the runs on one upload add up, an individual of the counting kernels as 16, a "
+                             "group of the matrix-core kernel as 15, against compact_targets = 256 (DESIGN s4.1b)"),
+            "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},
             "host_queue_ms_per_step": dt_host / args.steps * 1e3,

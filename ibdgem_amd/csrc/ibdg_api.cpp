@@ -136,6 +136,8 @@ struct ibdg_ctx {
     // the per-target LDS images of k_win_target (segment records with the target's tile words, window constants) depend
     // on the prepared sites and the targets only: a further run over the same sites and targets reuses them
     uint64_t sites_gen = 0;            // bumped by every upload of sites and every change of layout
+    uint64_t relayout_credit = 0;      // what the runs on this upload would have saved on the compacted tiles so far, in
+                                       // comparison individuals of the matrix-core kernel (see ibdg_run)
     uint64_t wt_gen = 0;               // sites_gen the images in wtarget / twords were made for
     uint32_t wt_first = 0, wt_count = 0;   // ... for comparison individuals [wt_first, wt_first + wt_count) of prev_targets
 
@@ -175,9 +177,12 @@ struct ibdg_ctx {
     long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
+    long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
     long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
                                      // (tools/density_sweep.py: one comparison at 1 row in 3: 0.82 ms in place, 0.94 compacted; in 4: 0.76 / 0.76; in 5: 0.79 / 0.65)
-    long opt_compact_targets = 256;  // ... or when a run has at least this many comparison individuals (the re-layout is paid once)
+    long opt_compact_targets = 256;  // ... or when the runs on one upload add up to this many comparison individuals (the re-layout
+                                     // is paid once; an individual of the counting kernels counts as 16: it saves 0.09 ms of a
+                                     // 0.8 ms run where one of the matrix-core kernel saves 0.007 of 0.185, the gather costs 1.5)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under
@@ -405,6 +410,13 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
     if (ensure(c, c->panel, n_rows * (size_t)c->stride * 8) || ensure(c, c->alt_count, n_rows * 4))
         return 1;
     if (c->pop_lut_ok && ensure(c, c->t32, (size_t)c->n_chunks * c->n_pairs * 64 * 16))
+        return 1;
+    // ... and room for the compacted tiles of a site list on all these rows at the usual window sizes (32 ceil(W / 32) / W
+    // <= 1.3: W = 100, 50, 75..., 97 and more), so that a re-layout in the middle of a series of runs does not allocate:
+    // a hipMalloc of gigabytes is normally 0.2 ms but now and then 270-370 ms (after somebody's large hipFree:
+    // tools/hipmalloc_in_process.py), which is 300 runs' worth.  Other windows grow it when their turn comes.
+    if (c->pop_lut_ok && c->opt_compact >= 0 && c->opt_reserve_compact &&
+        ensure(c, c->t32c, (size_t)c->n_chunks * (size_t)(c->n_pairs * 1.3 + 8) * 64 * 16))
         return 1;
     // pow(1-f,2.0), pow(f,2.0) for every possible alt count (src/ibd-math.c:93-95 with
     // f = k/(2N), src/ibd-parse.c:98)
@@ -670,11 +682,16 @@ int build_segments(ibdg_ctx *c, bool compact)
         if (pairs >= (1ull << 31))
             return 0;
         c->n_pairs_c = (uint32_t)((pairs + 3) & ~3ull);
+        const bool tr = getenv("IBDG_TRACE_RELAYOUT") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_a = now();
         if (ensure(c, c->t32c, (size_t)c->n_chunks * c->n_pairs_c * 64 * 16))
             return 1;
+        if (tr) { fprintf(stderr, "## relayout: ensure %.3f ms\n", now() - t_a); t_a = now(); }
         ibdg::launch_gather_transpose32((const uint64_t *)c->panel.p, c->stride, (const uint2 *)c->rec_cov.p, c->n_cov,
                                         c->window, c->n_chunks, c->n_pairs_c, (uint32_t *)c->t32c.p, c->stream);
         HIP_TRY(c, hipGetLastError());
+        if (tr) { fprintf(stderr, "## relayout: launch %.3f ms\n", now() - t_a); t_a = now(); (void)hipStreamSynchronize(c->stream); fprintf(stderr, "## relayout: gather %.3f ms\n", now() - t_a); }
     }
     if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
         ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
@@ -1070,6 +1087,7 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
         c->prep_dirty = false;
     }
     ++c->sites_gen;
+    c->relayout_credit = 0;
     c->seg_room = c->pop_lut_ok ? seg_room : 0;
     c->compact = false;
     if (n_sites) {
@@ -1346,13 +1364,21 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
 
     bool use_pop = false, s2_after_prep = false, side_fast = false;
     if (ld_mode && c->pop_lut_ok && c->pop_sites_ok && !c->compact && c->opt_compact == 0 && c->opt_variant != 1 &&
-        c->opt_variant != 3 && T >= (size_t)std::max<long>(1, c->opt_compact_targets)) {
-        // many comparison individuals over one site list: the compacted tiles' one-off gather is paid back by the
-        // fewer segments every one of them counts (the site list belongs to the pileup, not to the comparison
-        // individual: src/ibdgem.c:522 loops the individuals over the same rows)
-        if (quiesce(c)) return 1;
-        if (build_segments(c, true)) return 1;
-        if (!c->pop_sites_ok && build_segments(c, false)) return 1;     // (cannot happen: it applied a moment ago)
+        c->opt_variant != 3 && c->pop_dense_enough) {
+        // Comparison individuals over one site list (the site list belongs to the pileup, not to the comparison
+        // individual: src/ibdgem.c:522 loops the individuals over the same rows): the compacted tiles' one-off gather
+        // is paid back by the fewer segments every later run counts.  The runs on an upload add up -- one run of
+        // 256 individuals, nine batches of 30, or sixteen runs of one individual through the counting kernel all
+        // reach the point where the re-layout has paid for itself (a rent-or-buy rule: never more than twice the
+        // cost of having known the number of runs beforehand).
+        // (a group of the matrix-core kernel costs the same whether it holds 3 or IBDG_TG individuals)
+        const bool to_mfma = c->opt_mfma_targets && c->tab_in_lds && T >= (size_t)c->opt_mfma_min;
+        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * IBDG_TG : (uint64_t)T * 16u;
+        if (c->relayout_credit >= (uint64_t)std::max<long>(1, c->opt_compact_targets)) {
+            if (quiesce(c)) return 1;
+            if (build_segments(c, true)) return 1;
+            if (!c->pop_sites_ok && build_segments(c, false)) return 1;     // (cannot happen: it applied a moment ago)
+        }
     }
     if (ld_mode) {
         const bool can = c->pop_lut_ok && c->pop_sites_ok && (c->compact ? c->t32c.p : c->t32.p);
@@ -1848,6 +1874,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "compact_tiles")) {
         if (value < -1 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: compact_tiles must be -1 (never), 0 (auto) or 1 (always)");
         c->opt_compact = value; return 0;
+    }
+    if (!strcmp(name, "reserve_compact")) {
+        if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: reserve_compact must be 0 or 1");
+        c->opt_reserve_compact = value; return 0;
     }
     if (!strcmp(name, "compact_density")) {
         if (value < 1 || value > 1000000) return fail(c, "[::] ERROR in ibdg_set_option: compact_density must be 1..1000000");

@@ -1678,6 +1678,7 @@ typedef struct {
     size_t bg_n;
     int ref_order, has_B;
     int n_uploads;               /* uploads running at the same time */
+    size_t share_sites;          /* --LD comparison individuals that will run on ONE site list (0: each its own) */
     int failed;
     pthread_t th;
     int started;
@@ -1694,6 +1695,10 @@ static void *upload_run(void *arg)
     /* the uploads of all devices run side by side: each staging team gets its share of the host's threads (and locks
      * as much less memory: two 8 MB buffers per thread) */
     if (j->n_uploads > 1 && ibdg_set_option(j->eng, "stage_workers", j->n_uploads >= 8 ? 1 : 8 / j->n_uploads))
+        return NULL;
+    /* that many individuals over one site list pay for its compacted tiles several times over: have them from the
+     * first batch on (left alone, the engine gets there by itself once its runs have added up: nine batches) */
+    if (j->share_sites >= 240 && ibdg_set_option(j->eng, "compact_tiles", 1))
         return NULL;
     if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
         return NULL;
@@ -2163,6 +2168,7 @@ int main(int argc, char **argv)
             ups[d].eng = engs[d]; ups[d].r0 = 0; ups[d].n = n_rows; ups[d].n_ids = n_ids;
             ups[d].ref_order = opt_ref_order; ups[d].has_B = has_B; ups[d].bg_idx = bg.idx; ups[d].bg_n = bg.n;
             ups[d].n_uploads = n_eng;
+            ups[d].share_sites = batchable && opt_ld && !opt_ref_order ? targets.n : 0;
         }
         if (!slice_mode) {
             /* whole panel to every device, all copies at once, under the filter chain below */

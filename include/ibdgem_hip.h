@@ -205,9 +205,9 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * (no sites, or only the strict kernel applies), 1 the panel's own 32-row tiles (every tile between a window's
  * first and last panel row is streamed), 2 the compacted, window-aligned tiles of this site list: only the rows
  * that carry reads (the rows the reference's window loop multiplies, src/ibdgem.c:596-601, :657-663), gathered
- * and transposed once per ibdg_upload_sites -- or by the first ibdg_run with "compact_targets" or more
- * comparison individuals -- so that a window costs ceil(window / 32) tile words whatever the pileup's density.
- * Chosen per upload (option "compact_tiles"). */
+ * and transposed once per ibdg_upload_sites -- or by the ibdg_run with which the runs on this upload have added up to
+ * "compact_targets" comparison individuals -- so that a window costs ceil(window / 32) tile words whatever the pileup's
+ * density.  Chosen per upload and per run (option "compact_tiles"); the results are the same bits from either. */
 int ibdg_ld_layout(const ibdg_ctx *ctx);
 
 /* Options: "dispatch_events" (0/1: time the --LD launches through their own
@@ -232,8 +232,13 @@ int ibdg_ld_layout(const ibdg_ctx *ctx);
  * order);
  * "compact_tiles" (set before ibdg_upload_sites: 0, the default = the compacted tiles of ibdg_ld_layout when fewer than
  * one panel row in "compact_density" (default 4) between the first and the last site carries reads, when the rows
- * are not in file order, or when a run has "compact_targets" (default 256) or more comparison individuals, the panel's
+ * are not in file order, or once the runs on one upload have added up to "compact_targets" (default 256) comparison
+ * individuals -- the site list belongs to the pileup, src/ibdgem.c:522 runs every individual over the same rows; an
+ * individual of the counting kernels counts as 16, a group of the matrix-core kernel as 15: what each saves on the
+ * compacted tiles against the 1.2 ms of the gather at 4M rows, i.e. the 16th single run re-lays out -- the panel's
  * own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
+ * "reserve_compact" (0/1, default 1, set before ibdg_upload_panel: the buffer of the compacted tiles, 1.3 x the
+ * panel's, is allocated with the panel so that a re-layout never allocates);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;

@@ -709,19 +709,22 @@ def test_plain_double_powers_in_the_matrix_core_kernel(eps, M, cov):
 
 
 def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
-    """A run with "compact_targets" or more comparison individuals re-lays the site list out once (the site list belongs
-    to the pileup, src/ibdgem.c:522); later runs on the same upload keep the compacted tiles; results unchanged."""
+    """The runs on one upload add up: once they hold "compact_targets" comparison individuals (an individual of the
+    counting kernels counts as 16, a group of the matrix-core kernel as 15) the site list is re-laid out once (the site
+    list belongs to the pileup, src/ibdgem.c:522); later runs on the same upload keep the compacted tiles; results
+    unchanged."""
     N, L = 200, 3000
     alle, nr, na = synth(4242, L, N)
     targets = list(range(3, 3 + 20))
     with E.Engine() as eng:
-        eng.set_option("compact_targets", 16)
+        eng.set_option("compact_targets", 80)
+        eng.set_option("mfma_min", 5)
         eng.upload_panel(E.pack_alleles_fast(alle), N)
         eng.upload_sites(np.arange(L), nr, na, 100)
-        eng.run(targets[:4], ld=True)
+        eng.run(targets[:4], ld=True)                    # 4 x 16 = 64
         assert eng.ld_layout() == 1
         four = [eng.window_ll(i) for i in range(4)]
-        eng.run(targets, ld=True)
+        eng.run(targets, ld=True)                        # + two groups of 15 = 94
         assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2
         many = [eng.window_ll(i) for i in range(len(targets))]
         for i in (0, 7, 19):
@@ -734,6 +737,26 @@ def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
             assert_bits(eng.window_ll(i), four[i], f"four again, t={targets[i]}")
         # a new upload starts from the panel's own tiles again
         eng.upload_sites(np.arange(L), nr, na, 100)
+        assert eng.ld_layout() == 1
+        # one individual at a time (the reference's own loop, src/ibdgem.c:522): the fifth run re-lays out, same bits
+        per_run = []
+        for k in range(7):
+            eng.run([targets[k % 2]], ld=True)
+            assert eng.ld_layout() == (1 if k < 4 else 2), k
+            per_run.append((eng.site_ll(0), eng.window_ll(0)))
+        for k in range(2, 7):
+            assert_bits(per_run[k][0], per_run[k % 2][0], f"run {k} per-row values")
+            assert_bits(per_run[k][1], per_run[k % 2][1], f"run {k} windows")
+        # ... and one run of many individuals on a fresh upload does so at once
+        eng.set_option("compact_targets", 16)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run(targets, ld=True)
+        assert eng.ld_layout() == 2
+        # forbidden: never
+        eng.set_option("compact_tiles", -1)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        for k in range(3):
+            eng.run(targets, ld=True)
         assert eng.ld_layout() == 1
 
 
