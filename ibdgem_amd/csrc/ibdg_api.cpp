@@ -138,6 +138,7 @@ struct ibdg_ctx {
     uint64_t sites_gen = 0;            // bumped by every upload of sites and every change of layout
     uint64_t relayout_credit = 0;      // what the runs on this upload would have saved on the compacted tiles so far, in
                                        // comparison individuals of the matrix-core kernel (see ibdg_run)
+    int wt_mx = -1;                    // ... and the form of the records (option mx_counts)
     uint64_t wt_gen = 0;               // sites_gen the images in wtarget / twords were made for
     uint32_t wt_first = 0, wt_count = 0;   // ... for comparison individuals [wt_first, wt_first + wt_count) of prev_targets
 
@@ -177,6 +178,7 @@ struct ibdg_ctx {
     long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
+    long opt_mx_counts = 1;          // k_ld_popcount: the counts of a haplotype word by one matrix instruction (0: 12 (mask, count) pairs)
     long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
     long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
                                      // (tools/density_sweep.py: one comparison at 1 row in 3: 0.82 ms in place, 0.94 compacted; in 4: 0.76 / 0.76; in 5: 0.79 / 0.65)
@@ -1480,8 +1482,18 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             fit = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
             gg_batch = fit < n_gg ? fit : n_gg;
         }
+        // one comparison individual per workgroup: the counts of a haplotype word on the matrix cores where the larger
+        // records leave the run's LDS image within reach (option "mx_counts")
+        // ... and its power tables in LDS are plain doubles, rho^n as rho^n 2^(s n): s = the integer nearest to -log2 rho keeps
+        // every entry, and every product of a rho and a sigma entry whose exponents add up to a window's reads, a normal number
+        const double log2_rho = std::log2(c->eps / (1 - c->eps)), log2_sigma = std::log2(0.5 / (1 - c->eps));
+        const long rho_shift = std::lround(-log2_rho);
+        const double per_read = std::max(std::fabs(log2_rho + (double)rho_shift), std::fabs(log2_sigma));
+        const int mx_counts = c->opt_mx_counts && rho_shift >= 0 && rho_shift <= 40 &&
+                              (!c->tab_in_lds || (double)(c->ct_max + 1) * per_read <= 1000.0) &&
+                              ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
         if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
-            ensure(c, c->twords, T_one * (size_t)c->n_segs * 32) ||
+            ensure(c, c->twords, T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
@@ -1515,6 +1527,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
+        pa.mx_counts = (uint32_t)mx_counts;
+        pa.rho_shift = (uint32_t)rho_shift;
         ibdg::KernelEvents first, dominant, last;  // all null unless dispatch_events
         if (dispatch_events) {
             first.start = E.start_own;
@@ -1573,6 +1587,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         side_fast = n_gg > 0;
         if (n_grp) {
             ibdg::PopArgs pm = pa;
+            pm.mx_counts = 0;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
             pm.wc_ready = (const uint32_t *)c->wtarget_mt.p;
             ibdg::launch_win_target_mt(pm, (unsigned)n_grp, c->stream, first);
@@ -1586,12 +1601,13 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             // a caller that runs a comparison again, e.g. timed steps: one launch of ~10 us less per run, which on an
             // eighth of a chromosome is a tenth of the step)
             const bool wt_cached = same_inputs && c->wt_gen == c->sites_gen && c->wt_first == pa.t_base &&
-                                   c->wt_count == (uint32_t)T_one && !dispatch_events;
+                                   c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && !dispatch_events;
             if (!wt_cached)
                 ibdg::launch_win_target(pa, (unsigned)T_one, c->stream, first);
             c->wt_gen = c->sites_gen;
             c->wt_first = pa.t_base;
             c->wt_count = (uint32_t)T_one;
+            c->wt_mx = mx_counts;
             if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream, dominant))
                 return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         }
@@ -1874,6 +1890,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "compact_tiles")) {
         if (value < -1 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: compact_tiles must be -1 (never), 0 (auto) or 1 (always)");
         c->opt_compact = value; return 0;
+    }
+    if (!strcmp(name, "mx_counts")) {
+        if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: mx_counts must be 0 or 1");
+        c->opt_mx_counts = value; return 0;
     }
     if (!strcmp(name, "reserve_compact")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: reserve_compact must be 0 or 1");

@@ -121,6 +121,8 @@ struct PopArgs {
     uint32_t ring_slots;        // 4 or 8 tile pairs of LDS ring per wave
     uint32_t tab_len;           // entries per power table = (max cov_total) + 1
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
+    uint32_t rho_shift = 0;     // ... whose rho^n table (in LDS) holds rho^n * 2^(rho_shift n) as plain doubles
+    uint32_t mx_counts = 0;     // 1: k_ld_popcount takes the counts of a haplotype word on the matrix cores (records of 128 bytes)
 };
 
 // events a dispatch updates with its own start / stop time (either may be null)
@@ -180,6 +182,7 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
 void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
                                uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
+size_t ld_popcount_rec_bytes(int mx_counts);      // bytes of one segment record in rec_ready
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
                              int ring_slots, int multi_target);

@@ -56,8 +56,17 @@
 // (k_win_target); while a workgroup stages them it adds the LDS address of the table each one indexes
 // (rho^n: words 1, 4, 5; sigma^n: words 2, 3, 6), see stage_wc_base.
 #define IBDG_WC_WORDS 8
+// LDS image of a segment for the counts on the matrix cores (k_ld_popcount<.., MX = true>; 32 words):
+//   flags cov0 cov1 cov2 | t0 t1 - - | four A fragments of 24 bytes: the rows' weights in FP6 for the sums
+//   <x,cov> <x,alt> <x & t0,cov> <x & t1,cov>  (k_win_target_mx; flags bit 12 there: planes beyond cov 0-2 / alt 0-2)
+#define IBDG_RECX_WORDS 32
 
 namespace ibdg {
+
+typedef int mx_v8i __attribute__((ext_vector_type(8)));
+typedef float mx_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t mx_u4 __attribute__((ext_vector_type(4)));      // (plain vector types: the struct ones cannot be tied asm operands)
+typedef uint32_t mx_u2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
 // Panel transposition (once per upload): site-major rows ->
@@ -232,6 +241,140 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same for the counts on the matrix cores (round 4).
+//
+// v_mfma_scale_f32_16x16x128_f8f6f4 multiplies a 16 x 128 matrix A by a 128 x 16 matrix B; lane l holds 32 K-elements
+// of row (A) / column (B) l % 16: k = 32 (l / 16) .. + 31.  A is made block diagonal,
+//     A[4 kb' + sum][32 kb + r] = weight_sum[r]  if kb == kb'  else 0
+// and every lane supplies ITS OWN tile word as "column l % 16, K block l / 16" (its bits as FP4 numbers).  Then
+//     D[4 kb + sum][n] = sum_r weight_sum[r] * bit_r(word of lane n + 16 kb)
+// and the C/D layout (column = lane % 16, rows 4 (lane / 16) .. + 3 in the lane's four registers) returns to every lane
+// the four weighted sums of its own word: <x,cov> <x,alt> <x & t0,cov> <x & t1,cov> -- one instruction for the twelve
+// (mask, count) pairs of a haplotype word, no lane movement.  Bits become FP4 (e2m1) without shifts where possible:
+//     dword 0 = x & 0x11111111  rows 4j     value 0.5      dword 2 = x & 0x44444444         rows 4j + 2  value 2
+//     dword 1 = x & 0x22222222  rows 4j + 1 value 1        dword 3 = (x >> 3) & 0x11111111  rows 4j + 3  value 0.5
+// (nibble 1000 is -0: useless) and A carries w, w/2, w/4, w in FP6 e2m3, exact for w = 0..7, with the block scale 2:
+// every product is w, the sums are exact integers in f32 (tools/ubench/fp4_count.hip checks the layout with random
+// words and weights).  Only the 16 lanes with l % 16 / 4 == l / 16 hold a non-zero A fragment: lanes 20 kb + sum read
+// the 24 bytes of `sum` from the segment's record, the others keep zeros.
+// Element k = 8 d + j of a lane's 32  <->  row r = 4 j + d of the tile.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fp6_weight_code(uint32_t w, int d)
+{
+    // e2m3 (bias 1, exponent 0 = subnormal m/8) of w (d = 0, 3), w/2 (d = 1), w/4 (d = 2), w = 0..7, as bytes of two words
+    const uint32_t lo = d == 1 ? 0x0c080400u : d == 2 ? 0x06040200u : 0x14100800u;
+    const uint32_t hi = d == 1 ? 0x16141210u : d == 2 ? 0x0e0c0a08u : 0x1e1c1a18u;
+    return ((w & 4 ? hi : lo) >> (8 * (w & 3))) & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__restrict__ rec_ready,
+                                                       uint32_t *__restrict__ wc_ready)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = blockIdx.y;
+    const uint32_t tgt = a.targets[a.t_base + t];
+    const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
+    if ((i >> 2) < a.n_segs) {               // threads 4s .. 4s+3: the four A fragments of segment s
+        const uint32_t sg = i >> 2, sum = i & 3;
+        const Seg &S = a.segs[sg];
+        const uint2 at = tile_words(tt, S.tile);
+        uint32_t p0, p1, p2;
+        if (sum == 1) {
+            p0 = S.alt[0]; p1 = S.alt[1]; p2 = S.alt[2];
+        } else {
+            const uint32_t m = sum == 0 ? 0xffffffffu : sum == 2 ? at.x : at.y;
+            p0 = S.cov[0] & m; p1 = S.cov[1] & m; p2 = S.cov[2] & m;
+        }
+        uint32_t f[6] = {0, 0, 0, 0, 0, 0};   // 32 x 6 bits
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int d = k >> 3, r = 4 * (k & 7) + d;
+            const uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
+            const uint32_t code = fp6_weight_code(w, d);
+            const int pos = 6 * k, wd = pos >> 5, sh = pos & 31;
+            f[wd] |= code << sh;
+            if (sh > 26)
+                f[wd + 1] |= code >> (32 - sh);
+        }
+        uint32_t *o = rec_ready + ((size_t)t * a.n_segs + sg) * IBDG_RECX_WORDS;
+        uint2 *fo = reinterpret_cast<uint2 *>(o + 8 + 6 * sum);
+        fo[0] = make_uint2(f[0], f[1]);
+        fo[1] = make_uint2(f[2], f[3]);
+        fo[2] = make_uint2(f[4], f[5]);
+        if (sum == 0) {
+            const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24;
+            const uint32_t fl = (S.flags & ~(1u << 12)) | ((ncov > 3 || nalt > 3) ? 1u << 12 : 0u);
+            uint4 *oh = reinterpret_cast<uint4 *>(o);
+            oh[0] = make_uint4(fl, S.cov[0], S.cov[1], S.cov[2]);
+            oh[1] = make_uint4(at.x, at.y, 0, 0);
+        }
+    }
+    if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w (as k_win_target)
+        const uint32_t w = i >> 3;
+        uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
+        const uint32_t s1 = a.wconst[w + 1].seg_begin;
+        for (uint32_t s = a.wconst[w].seg_begin + (i & 7); s < s1; s += 8) {
+            const Seg &S = a.segs[s];
+            const uint2 at = tile_words(tt, S.tile);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0cov += (uint32_t)__popc(at.x & S.cov[k]) << k;
+                a1cov += (uint32_t)__popc(at.y & S.cov[k]) << k;
+                a0alt += (uint32_t)__popc(at.x & S.alt[k]) << k;
+                a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            a0cov += __shfl_xor(a0cov, m);
+            a1cov += __shfl_xor(a1cov, m);
+            a0alt += __shfl_xor(a0alt, m);
+            a1alt += __shfl_xor(a1alt, m);
+        }
+        if ((i & 7) == 0) {
+            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WC_WORDS);
+            const uint32_t AT = wcs[4];
+            // byte offsets into tables of 8-byte entries (the matrix-core form's power tables, see its window end)
+            const uint32_t sc = a.tab_in_lds ? 8 : 16;       // (16-byte entries where the tables stay in global memory)
+            o[0] = make_uint4(wcs[2], sc * AT, sc * a0cov, sc * a1cov);
+            o[1] = make_uint4(sc * (AT - a0alt), sc * (AT - a1alt), 0, 0);
+        }
+    }
+}
+
+// the bits of a tile word as 32 FP4 numbers (0 or 0.5 / 1 / 2 / 0.5 by dword, see above)
+__device__ __forceinline__ mx_v8i bits_to_fp4(uint32_t x)
+{
+    mx_v8i b = {0, 0, 0, 0, 0, 0, 0, 0};
+    b[0] = (int)(x & 0x11111111u);
+    b[1] = (int)(x & 0x22222222u);
+    b[2] = (int)(x & 0x44444444u);
+    b[3] = (int)((x >> 3) & 0x11111111u);
+    return b;
+}
+
+// the lanes that hold a non-zero A fragment: 20 kb + sum
+#define IBDG_MX_A_LANES 0xF0000F0000F0000Full
+
+// One segment's LDS reads of the matrix-core form: the broadcast header (flags and the cov planes for the x0&x1 counts),
+// the lane's two tile words and -- in the 16 lanes that carry one -- the A fragment; the other lanes keep their zeros.
+__device__ __forceinline__ void lds_fetch_mx(uint4 &h0, uint2 &x, mx_u4 &a_lo, mx_u2 &a_hi, uint32_t rec_addr, uint32_t x_addr,
+                                             uint32_t frag_addr)
+{
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b64 %1, %5\n\t"
+                 "s_mov_b64 exec, %7\n\t"
+                 "ds_read2_b64 %2, %6 offset1:1\n\t"
+                 "ds_read_b64 %3, %6 offset:16\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi)
+                 : "v"(rec_addr), "v"(x_addr), "v"(frag_addr), "s"((uint64_t)IBDG_MX_A_LANES)
+                 : "memory");
+}
+
 // Two wave-wide sums at once through a 1 KiB LDS scratch of the wave: every lane writes its two
 // addends into two arrays of 64 doubles; lane 32j+p then reads elements 2p, 2p+1 of sum j (one
 // 16-byte read at scratch + 16*lane), adds them, and the 32 lanes of half j finish with five
@@ -346,6 +489,55 @@ __device__ __forceinline__ void lds_read_pow10(uint4 (&p)[10], const uint32_t (&
                    "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
                  : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
                    "v"(ad[8]), "v"(ad[9])
+                 : "memory");
+}
+
+// ten 8-byte power-table entries (the matrix-core form's tables of plain doubles)
+__device__ __forceinline__ void lds_read_pow10_b64(uint2 (&p)[10], const uint32_t (&ad)[10])
+{
+    asm volatile("ds_read_b64 %0, %10\n\t"
+                 "ds_read_b64 %1, %11\n\t"
+                 "ds_read_b64 %2, %12\n\t"
+                 "ds_read_b64 %3, %13\n\t"
+                 "ds_read_b64 %4, %14\n\t"
+                 "ds_read_b64 %5, %15\n\t"
+                 "ds_read_b64 %6, %16\n\t"
+                 "ds_read_b64 %7, %17\n\t"
+                 "ds_read_b64 %8, %18\n\t"
+                 "ds_read_b64 %9, %19\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]),
+                   "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                   "v"(ad[8]), "v"(ad[9])
+                 : "memory");
+}
+
+// the same in two round trips (6 + 4 entries): 16 registers fewer at the window end, which the matrix-core form needs to
+// stay at eight waves per SIMD
+__device__ __forceinline__ void lds_read_pow6(uint4 (&p)[10], const uint32_t (&ad)[10])
+{
+    asm volatile("ds_read_b128 %0, %6\n\t"
+                 "ds_read_b128 %1, %7\n\t"
+                 "ds_read_b128 %2, %8\n\t"
+                 "ds_read_b128 %3, %9\n\t"
+                 "ds_read_b128 %4, %10\n\t"
+                 "ds_read_b128 %5, %11\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5])
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_read_pow4(uint4 (&p)[10], const uint32_t (&ad)[10])
+{
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %5\n\t"
+                 "ds_read_b128 %2, %6\n\t"
+                 "ds_read_b128 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[6]), "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
+                 : "v"(ad[6]), "v"(ad[7]), "v"(ad[8]), "v"(ad[9])
                  : "memory");
 }
 
@@ -481,7 +673,67 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
         ++s;                                                                                                    \
     }
 
-template <int NS, bool TAB_LDS>
+// The same with the counts of the two haplotype words on the matrix cores (acc0 / acc1: <x,cov> <x,alt> <x&t0,cov>
+// <x&t1,cov> of x0 / x1 as exact integers in f32; a window's first segment starts them from zero) and the three
+// planes of <x0&x1,cov> as (mask, count) pairs.
+#define IBDG_SEGMENT_MX(FIRST)                                                                                     \
+    {                                                                                                           \
+        uint4 h0;                                                                                               \
+        uint2 x;                                                                                                \
+        lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                              \
+        flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
+        const uint32_t adv = (flags >> 4) & 0xff;                                                               \
+        if (adv) {                                                                                              \
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
+                if (q_issue <= q_last)                                                                          \
+                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
+            if (q_issue - 1 <= q_last)                                                                          \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
+            else                                                                                                \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                       \
+        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;                                                    \
+        const uint32_t hom = x.x & x.y;                                                                         \
+        {                                                                                                       \
+            const mx_v8i av = {(int)af_lo.x, (int)af_lo.y, (int)af_lo.z, (int)af_lo.w, (int)af_hi.x, (int)af_hi.y, 0, 0}; \
+            const mx_v4f zero = {0.f, 0.f, 0.f, 0.f};                                                           \
+            acc0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.x), FIRST ? zero : acc0, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
+            acc1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.y), FIRST ? zero : acc1, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
+        }                                                                                                       \
+        if (FIRST) {                                                                                            \
+            ch[0] = __popc(hom & h0.y); ch[1] = __popc(hom & h0.z); ch[2] = __popc(hom & h0.w);                 \
+        } else {                                                                                                \
+            ch[0] += __popc(hom & h0.y); ch[1] += __popc(hom & h0.z); ch[2] += __popc(hom & h0.w);              \
+        }                                                                                                       \
+        if (flags & (1u << 12)) {                                                                               \
+            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
+            const uint2 at = lds_read_b64(rec_addr + 16);                                                       \
+            for (uint32_t k = 3; k < ncov; ++k) {                                                               \
+                const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
+                const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
+                acc0[0] += (float)((uint32_t)__popc(u0) << k);                                                  \
+                acc1[0] += (float)((uint32_t)__popc(u1) << k);                                                  \
+                ch[0] += (uint32_t)__popc(hom & cov) << k;                                                      \
+                acc0[2] += (float)((uint32_t)__popc(u0 & at.x) << k);                                           \
+                acc1[2] += (float)((uint32_t)__popc(u1 & at.x) << k);                                           \
+                acc0[3] += (float)((uint32_t)__popc(u0 & at.y) << k);                                           \
+                acc1[3] += (float)((uint32_t)__popc(u1 & at.y) << k);                                           \
+            }                                                                                                   \
+            for (uint32_t k = 3; k < nalt; ++k) {                                                               \
+                const uint32_t alt = segs[seg0 + s].alt[k];                                                     \
+                acc0[1] += (float)((uint32_t)__popc(x.x & alt) << k);                                           \
+                acc1[1] += (float)((uint32_t)__popc(x.y & alt) << k);                                           \
+            }                                                                                                   \
+        }                                                                                                       \
+        rec_addr += IBDG_RECX_WORDS * 4;                                                                        \
+        frag_addr += IBDG_RECX_WORDS * 4;                                                                       \
+        ++s;                                                                                                    \
+    }
+
+template <int NS, bool TAB_LDS, bool MX>
 __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
                                                      const uint32_t *__restrict__ rec_ready,
@@ -507,12 +759,15 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         return;
 
     // ---- LDS carve-up (see ld_popcount_lds_bytes)
-    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][22]
-    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * IBDG_REC_WORDS;               // [win_per_group][12]
+    constexpr uint32_t RECW = MX ? IBDG_RECX_WORDS : IBDG_REC_WORDS;
+    uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][RECW]
+    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * RECW;                         // [win_per_group][8]
     uint4 *tab_lds = reinterpret_cast<uint4 *>(
-        smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
-    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * 32 : 0;
-    char *ring0 = smem + ((((size_t)a.max_seg * IBDG_REC_WORDS + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
+        smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
+    // (matrix-core form with the tables in LDS: plain doubles, 8 bytes per entry -- see the window end)
+    constexpr bool PLAIN = MX && TAB_LDS;
+    const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * (PLAIN ? 16 : 32) : 0;
+    char *ring0 = smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
 
     // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
     // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
@@ -536,21 +791,32 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     {
         // plain contiguous copies (k_win_target prepared the LDS images): every load of a thread is
         // independent of the others, so the whole staging costs about one memory latency
-        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * (IBDG_REC_WORDS / 4);
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)t * a.n_segs + seg0) * (RECW / 4);
         uint4 *rdst = reinterpret_cast<uint4 *>(rec_lds);
-        for (uint32_t i = threadIdx.x; i < nseg * (IBDG_REC_WORDS / 4); i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < nseg * (RECW / 4); i += blockDim.x)
             rdst[i] = rsrc[i];
         // with the tables in LDS the constants become LDS addresses (table base + 16 * exponent), otherwise
         // they stay byte offsets into the global tables
         const uint32_t stab1 = TAB_LDS ? (uint32_t)(uintptr_t)(lds_void *)tab_lds : 0u;
-        const uint32_t stab2 = TAB_LDS ? stab1 + a.tab_len * 16 : 0u;
+        const uint32_t stab2 = TAB_LDS ? stab1 + a.tab_len * (PLAIN ? 8 : 16) : 0u;
         const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
         for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
             wdst[i] = stage_wc_base(wsrc[i], i, stab1, stab2);
-        if (TAB_LDS)
+        if (PLAIN) {
+            // rho^n * 2^(s n) and sigma^n as plain doubles: the mantissas of the {mantissa, exponent} tables, exactly (a power
+            // of two moves no bit); s = a.rho_shift keeps rho^n inside the double range for every n of the table
+            // (the host checks), sigma = 1 / (2 (1 - eps)) > 1/2 needs none
+            double *td = reinterpret_cast<double *>(tab_lds);
+            const PowEntry *p1 = reinterpret_cast<const PowEntry *>(pow_1me), *p2 = reinterpret_cast<const PowEntry *>(pow_eps);
+            for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x) {
+                const PowEntry e = i < a.tab_len ? p1[i] : p2[i - a.tab_len];
+                td[i] = __builtin_ldexp(e.m, e.e + (i < a.tab_len ? (int)(a.rho_shift * i) : 0));
+            }
+        } else if (TAB_LDS) {
             for (uint32_t i = threadIdx.x; i < 2 * a.tab_len; i += blockDim.x)
                 tab_lds[i] = i < a.tab_len ? pow_1me[i] : pow_eps[i - a.tab_len];
+        }
     }
     __syncthreads();
 
@@ -584,11 +850,23 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     uint32_t rec_addr = (uint32_t)(uintptr_t)(lds_void *)rec_lds;     // same value in every lane (VGPR)
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
     uint32_t s = 0;
+    // (matrix-core form) the two accumulators, the lane's A fragment -- zero except in the lanes 20 kb + sum, which read
+    // the 24 bytes of `sum` behind the record's header
+    mx_v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    mx_u4 af_lo = {0, 0, 0, 0};
+    mx_u2 af_hi = {0, 0};
+    uint32_t frag_addr = rec_addr + 32 + 24 * (lane & 3);
     for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
-        IBDG_SEGMENT(true)                               // its first segment starts the counters
-        while (!(flags & (1u << 13)) && s < nseg)        // the others add to them
-            IBDG_SEGMENT(false)
+        if constexpr (MX) {
+            IBDG_SEGMENT_MX(true)
+            while (!(flags & (1u << 13)) && s < nseg)
+                IBDG_SEGMENT_MX(false)
+        } else {
+            IBDG_SEGMENT(true)                           // its first segment starts the counters
+            while (!(flags & (1u << 13)) && s < nseg)    // the others add to them
+                IBDG_SEGMENT(false)
+        }
         {
         {
             uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
@@ -596,14 +874,49 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             const int eK = (int)k0.x;
             // table addresses of 16*AT, 16*<t0,cov>, 16*<t1,cov>, 16*(AT-<t0,alt>), 16*(AT-<t1,alt>), 0
             const uint32_t kAT = k0.y, kc0 = k0.z, kc1 = k0.w, kb0 = k1.x, kb1 = k1.y, ktab2 = k1.z;
-            const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1), CH = planes_sum<FC>(ch);
-            const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
-            const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
-            const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
+            uint32_t C0, C1, G00, G01, G10, G11, a0, a1;
+            const uint32_t CH = planes_sum<FC>(ch);
+            if constexpr (MX) {
+                C0 = (uint32_t)acc0[0]; a0 = (uint32_t)acc0[1]; G00 = (uint32_t)acc0[2]; G10 = (uint32_t)acc0[3];
+                C1 = (uint32_t)acc1[0]; a1 = (uint32_t)acc1[1]; G01 = (uint32_t)acc1[2]; G11 = (uint32_t)acc1[3];
+            } else {
+                C0 = planes_sum<FC>(c0); C1 = planes_sum<FC>(c1);
+                G00 = planes_sum<FC>(g00); G01 = planes_sum<FC>(g01);
+                G10 = planes_sum<FC>(g10); G11 = planes_sum<FC>(g11);
+                a0 = planes_sum<FA>(A0); a1 = planes_sum<FA>(A1);
+            }
             // ad[2i] / ad[2i+1]: where rho^E2 / sigma^E3 of product i sit (table base + 16 * exponent), with
             //   pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH          E2 = AT - a0 - a1 + CH
             //   pDg[At+hx] (:716-719):     E3 = <t,cov> + Cx - 2 G(x,t)  E2 = AT - <t,alt> - ax + G(x,t)
             uint32_t ad[10];
+            if constexpr (PLAIN) {
+                // 8-byte entries; rho^E2 sits in its table as rho^E2 * 2^(s E2): the product's exponent is made up for it from
+                // the table address itself, eK - s E2 = (8 eK + s tab1 - s ad) >> 3
+                ad[0] = lshl_add<3>(CH - (a0 + a1), kAT);
+                ad[1] = lshl_add<3>(mad24<-2>(CH, C0 + C1), ktab2);
+                ad[2] = lshl_add<3>(G00, mad24<-8>(a0, kb0));   ad[3] = mad24<-16>(G00, lshl_add<3>(C0, kc0));
+                ad[4] = lshl_add<3>(G01, mad24<-8>(a1, kb0));   ad[5] = mad24<-16>(G01, lshl_add<3>(C1, kc0));
+                ad[6] = lshl_add<3>(G10, mad24<-8>(a0, kb1));   ad[7] = mad24<-16>(G10, lshl_add<3>(C0, kc1));
+                ad[8] = lshl_add<3>(G11, mad24<-8>(a1, kb1));   ad[9] = mad24<-16>(G11, lshl_add<3>(C1, kc1));
+                uint2 pq[10];
+                lds_read_pow10_b64(pq, ad);
+                const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+                const uint32_t e8 = mad24r(tab1, a.rho_shift, (uint32_t)eK << 3);        // 8 eK + s tab1 (wave-uniform)
+                const uint32_t ms = 0u - a.rho_shift;
+                double val[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
+                    const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
+                    val[i] = __builtin_ldexp(m1 * m2, (int)mad24r(ad[2 * i], ms, e8) >> 3);
+                }
+                double s0 = wgt * val[0];                                   // :743
+                double s1 = wgt * (((val[1] + val[2]) + val[3]) + val[4]);  // :744-745
+                const double tot = wave_sum2(s0, s1, scr_w, scr_r);
+                if ((lane & 31) == 31)
+                    a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
+                continue;
+            }
             ad[0] = lshl_add<4>(CH - (a0 + a1), kAT);
             ad[1] = lshl_add<4>(mad24<-2>(CH, C0 + C1), ktab2);
             ad[2] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[3] = mad24r(G00, m32, lshl_add<4>(C0, kc0));   // A0, h0
@@ -611,7 +924,14 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             ad[6] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[7] = mad24r(G10, m32, lshl_add<4>(C0, kc1));   // A1, h0
             ad[8] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[9] = mad24r(G11, m32, lshl_add<4>(C1, kc1));   // A1, h1
             uint4 pw[10];
-            if (TAB_LDS) {
+            double P2, Q00, Q01;
+            if (TAB_LDS && MX) {
+                lds_read_pow6(pw, ad);
+                P2 = ld_value(eK, pw[0], pw[1]);
+                Q00 = ld_value(eK, pw[2], pw[3]);
+                Q01 = ld_value(eK, pw[4], pw[5]);
+                lds_read_pow4(pw, ad);
+            } else if (TAB_LDS) {
                 lds_read_pow10(pw, ad);
             } else {
 #pragma unroll
@@ -620,9 +940,11 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     pw[2 * i + 1] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_eps) + ad[2 * i + 1]);
                 }
             }
-            const double P2 = ld_value(eK, pw[0], pw[1]);
-            const double Q00 = ld_value(eK, pw[2], pw[3]);
-            const double Q01 = ld_value(eK, pw[4], pw[5]);
+            if (!(TAB_LDS && MX)) {
+                P2 = ld_value(eK, pw[0], pw[1]);
+                Q00 = ld_value(eK, pw[2], pw[3]);
+                Q01 = ld_value(eK, pw[4], pw[5]);
+            }
             const double Q10 = ld_value(eK, pw[6], pw[7]);
             const double Q11 = ld_value(eK, pw[8], pw[9]);
             double s0 = wgt * P2;                                   // :743
@@ -638,6 +960,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 }
 
 #undef IBDG_SEGMENT
+#undef IBDG_SEGMENT_MX
 
 // ---------------------------------------------------------------------------
 // Several comparison individuals per workgroup (BASELINE.json configs[4]: hundreds of them against
@@ -1036,28 +1359,37 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, Ker
 {
     if (a.n_win == 0)
         return;
+    if (a.mx_counts) {
+        const uint32_t n = a.n_segs * 4 > a.n_win * 8 ? a.n_segs * 4 : a.n_win * 8;
+        hipExtLaunchKernelGGL(k_win_target_mx, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a,
+                              const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+        return;
+    }
     const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
     hipExtLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a,
                           const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
 }
 
+size_t ld_popcount_rec_bytes(int mx_counts) { return (mx_counts ? IBDG_RECX_WORDS : IBDG_REC_WORDS) * 4; }
+
 // LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
                              int ring_slots, int multi_target)
 {
-    const size_t rec_words = multi_target ? IBDG_RECM_WORDS : IBDG_REC_WORDS;
-    const size_t wc_words = multi_target ? IBDG_WCM_WORDS : IBDG_WC_WORDS;
+    // multi_target: 0 = one comparison individual (vector-ALU counts), 1 = groups of IBDG_MT, 2 = one, counts on the matrix cores
+    const size_t rec_words = multi_target == 1 ? IBDG_RECM_WORDS : multi_target == 2 ? IBDG_RECX_WORDS : IBDG_REC_WORDS;
+    const size_t wc_words = multi_target == 1 ? IBDG_WCM_WORDS : IBDG_WC_WORDS;
     size_t head = ((size_t)max_seg * rec_words + (size_t)win_per_group * wc_words) * 4 + 15;
     if (tab_in_lds)
-        head += (size_t)tab_len * 32;
+        head += (size_t)tab_len * (multi_target == 2 ? 16 : 32);      // (matrix-core form: plain doubles)
     return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024 + 8 * 1024;    // rings + wave_sum2 scratch
 }
 
-template <int NS, bool TAB>
+template <int NS, bool TAB, bool MX>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st, KernelEvents ev)
 {
-    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, 0);
-    auto kern = k_ld_popcount<NS, TAB>;
+    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, MX ? 2 : 0);
+    auto kern = k_ld_popcount<NS, TAB, MX>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
@@ -1074,13 +1406,22 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (planes < 1 || planes > 8)
         return 1;
     dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
+    if (a.mx_counts) {
+        if (a.ring_slots == 2)
+            return a.tab_in_lds ? launch_pop<2, true, true>(a, grid, st, ev) : launch_pop<2, false, true>(a, grid, st, ev);
+        if (a.ring_slots == 3)
+            return a.tab_in_lds ? launch_pop<3, true, true>(a, grid, st, ev) : launch_pop<3, false, true>(a, grid, st, ev);
+        if (a.ring_slots == 4)
+            return a.tab_in_lds ? launch_pop<4, true, true>(a, grid, st, ev) : launch_pop<4, false, true>(a, grid, st, ev);
+        return a.tab_in_lds ? launch_pop<8, true, true>(a, grid, st, ev) : launch_pop<8, false, true>(a, grid, st, ev);
+    }
     if (a.ring_slots == 2)
-        return a.tab_in_lds ? launch_pop<2, true>(a, grid, st, ev) : launch_pop<2, false>(a, grid, st, ev);
+        return a.tab_in_lds ? launch_pop<2, true, false>(a, grid, st, ev) : launch_pop<2, false, false>(a, grid, st, ev);
     if (a.ring_slots == 3)
-        return a.tab_in_lds ? launch_pop<3, true>(a, grid, st, ev) : launch_pop<3, false>(a, grid, st, ev);
+        return a.tab_in_lds ? launch_pop<3, true, false>(a, grid, st, ev) : launch_pop<3, false, false>(a, grid, st, ev);
     if (a.ring_slots == 4)
-        return a.tab_in_lds ? launch_pop<4, true>(a, grid, st, ev) : launch_pop<4, false>(a, grid, st, ev);
-    return a.tab_in_lds ? launch_pop<8, true>(a, grid, st, ev) : launch_pop<8, false>(a, grid, st, ev);
+        return a.tab_in_lds ? launch_pop<4, true, false>(a, grid, st, ev) : launch_pop<4, false, false>(a, grid, st, ev);
+    return a.tab_in_lds ? launch_pop<8, true, false>(a, grid, st, ev) : launch_pop<8, false, false>(a, grid, st, ev);
 }
 
 // The same for groups of IBDG_MT comparison individuals (a.t_base = first of them, n_groups groups)
