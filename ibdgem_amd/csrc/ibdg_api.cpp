@@ -1487,7 +1487,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // ... and its power tables in LDS are plain doubles, rho^n as rho^n 2^(s n): s = the integer nearest to -log2 rho keeps
         // every entry, and every product of a rho and a sigma entry whose exponents add up to a window's reads, a normal number
         const double log2_rho = std::log2(c->eps / (1 - c->eps)), log2_sigma = std::log2(0.5 / (1 - c->eps));
-        const long rho_shift = std::lround(-log2_rho);
+        // (8 where the table allows it: the window end then makes the exponent up with one subtraction)
+        const bool shift8 = (double)(c->ct_max + 1) * std::max(std::fabs(log2_rho + 8.0), std::fabs(log2_sigma)) <= 1000.0;
+        const long rho_shift = shift8 ? 8 : std::lround(-log2_rho);
         const double per_read = std::max(std::fabs(log2_rho + (double)rho_shift), std::fabs(log2_sigma));
         const int mx_counts = c->opt_mx_counts && rho_shift >= 0 && rho_shift <= 40 &&
                               (!c->tab_in_lds || (double)(c->ct_max + 1) * per_read <= 1000.0) &&

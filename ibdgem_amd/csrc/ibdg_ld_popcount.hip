@@ -901,14 +901,24 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 uint2 pq[10];
                 lds_read_pow10_b64(pq, ad);
                 const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
-                const uint32_t e8 = mad24r(tab1, a.rho_shift, (uint32_t)eK << 3);        // 8 eK + s tab1 (wave-uniform)
-                const uint32_t ms = 0u - a.rho_shift;
                 double val[5];
+                if (a.rho_shift == 8) {                  // (the host's choice where the table allows it): eK - 8 E2 = eK + tab1 - ad
+                    const uint32_t e1 = (uint32_t)eK + tab1;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
-                    const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
-                    val[i] = __builtin_ldexp(m1 * m2, (int)mad24r(ad[2 * i], ms, e8) >> 3);
+                    for (int i = 0; i < 5; ++i) {
+                        const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
+                        const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
+                        val[i] = __builtin_ldexp(m1 * m2, (int)(e1 - ad[2 * i]));
+                    }
+                } else {
+                    const uint32_t e8 = mad24r(tab1, a.rho_shift, (uint32_t)eK << 3);        // 8 eK + s tab1 (wave-uniform)
+                    const uint32_t ms = 0u - a.rho_shift;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
+                        const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
+                        val[i] = __builtin_ldexp(m1 * m2, (int)mad24r(ad[2 * i], ms, e8) >> 3);
+                    }
                 }
                 double s0 = wgt * val[0];                                   // :743
                 double s1 = wgt * (((val[1] + val[2]) + val[3]) + val[4]);  // :744-745

@@ -647,6 +647,46 @@ def test_rows_tens_of_thousands_of_panel_rows_apart(oracle):
             assert_ld_close(eng.window_ll(0)[:, :2], res["win"][:, :2], f"tiles={tiles}")
 
 
+@pytest.mark.parametrize("N,L,W,M,cov,eps,T", [(150, 2600, 100, 20, 2.0, 0.02, 1), (64, 700, 100, 50, 14.0, 0.02, 1),
+                                                (131, 1500, 33, 31, 6.0, 0.001, 2), (300, 2000, 64, 20, 0.6, 0.3, 1),
+                                                (700, 900, 257, 50, 20.0, 0.02, 1), (2504, 1300, 100, 20, 2.0, 0.1, 3),
+                                                (70, 900, 2, 20, 2.0, 0.45, 1), (90, 3000, 100, 7, 3.0, 0.02, 1)])
+@pytest.mark.parametrize("tiles", [-1, 1])
+def test_matrix_core_counts_give_the_bits_of_the_vector_counts(oracle, N, L, W, M, cov, eps, T, tiles):
+    """One comparison individual per workgroup (k_ld_popcount): the four weighted sums of a haplotype word by one
+    v_mfma_scale_f32_16x16x128_f8f6f4 (option mx_counts 1, the default: weights 0..7 as FP6, bits as FP4, rows with eight
+    reads or more through the rare-plane path; power tables as plain doubles scaled per step) against the twelve (mask,
+    count) pairs of mx_counts 0: the sums are the same integers, so the results are the same bits -- deep pileups (planes
+    beyond the third), other error rates (another scaling step), windows whose tables do not fit LDS; and both agree with
+    the oracle."""
+    rng = np.random.default_rng(N * 31 + W)
+    f = np.clip(rng.beta(0.3, 1.0, size=L), 1e-3, 0.999)
+    alle = (rng.random((L, 2 * N)) < f[:, None]).astype(np.uint8)
+    c = np.minimum(rng.poisson(cov, size=L), M)
+    na = rng.binomial(c, f).astype(np.uint8)
+    nr = (c - na).astype(np.uint8)
+    targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
+    out = {}
+    for mx in (0, 1):
+        with E.Engine(0, eps, M) as eng:
+            eng.set_option("mx_counts", mx)
+            eng.set_option("compact_tiles", tiles)
+            eng.set_option("ld_variant", 2)
+            eng.set_option("mfma_targets", 0)            # (T = 2, 3: single runs of k_ld_popcount, blockIdx.z = individual)
+            eng.set_option("multi_target", 0)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, W)
+            eng.run(targets, ld=True, pu_id=targets[0] if T > 1 else -1)
+            assert eng.last_ld_variant() == 2
+            out[mx] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(T)]
+    for i, t in enumerate(targets):
+        assert_bits(out[1][i][0], out[0][i][0], f"t={t} per-row values")
+        assert_bits(out[1][i][1], out[0][i][1], f"t={t} windows")
+    res = oracle.compare(alle, nr, na, targets[0], window=W, ld=True, eps=eps, max_cov=M, pu_id=targets[0] if T > 1 else -1)
+    assert_bits(out[1][0][1][:, 2], res["win"][:, 2], "LIBD2")
+    assert_ld_close(out[1][0][1][:, :2], res["win"][:, :2], "matrix-core counts vs oracle")
+
+
 @pytest.mark.parametrize("N,L,W,M,cov,T", [(150, 2600, 100, 20, 2.0, 1), (70, 900, 2, 20, 2.0, 2), (131, 1700, 33, 3, 1.0, 4),
                                             (300, 3000, 64, 20, 0.4, 9), (700, 5000, 257, 40, 9.0, 17), (64, 640, 32, 20, 2.0, 5),
                                             (2504, 1300, 100, 20, 2.0, 3), (130, 4000, 31, 20, 5.0, 31)])

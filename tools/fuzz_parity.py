@@ -50,7 +50,8 @@ for case in range(n_cases):
     if rng.random() < 0.5:
         opts = {"ring_slots": int(rng.choice([2, 3, 4, 8])), "windows_per_wave": int(rng.choice([1, 2, 5, 16, 64])),
                 "guided_runs": int(rng.choice([0, 1, 4, 16])), "multi_target": int(rng.choice([0, 1])),
-                "mfma_targets": int(rng.choice([0, 1, 1])), "mfma_min": int(rng.choice([1, 2, 8, 15]))}
+                "mfma_targets": int(rng.choice([0, 1, 1])), "mfma_min": int(rng.choice([1, 2, 8, 15])),
+                "mx_counts": int(rng.choice([0, 1, 1]))}
     desc = f"case {case}: N={N} L={L} keep={len(keep)} W={W} eps={eps} M={M} cov={cov} T={T} bg={'y' if bg is not None else 'n'} pu={pu} variant={variant} tiles={tiles} {opts}"
     try:
         with E.Engine(0, eps, M) as eng:
