@@ -459,9 +459,13 @@ def valu_roofline(launch_ms, n_win, n_chunks):
         return None
     k, d = p["per_launch"], p["derived"]
     cyc = p["cycles_per_valu_instruction"]["value"]
-    issue = k["SQ_INSTS_VALU"] * cyc / p["simds"]
+    mfma = k.get("SQ_INSTS_MFMA", 0.0) if p.get("cycles_per_mfma") else 0.0
+    issue = ((k["SQ_INSTS_VALU"] - mfma) * cyc + mfma * (p.get("cycles_per_mfma") or 0.0)) / p["simds"]
     bound_ms = issue / p["nominal_clock_hz"] * 1e3
+    busy = {n: k[n] for n in ("VALUBusy", "LdsUtil", "SALUBusy", "MeanOccupancyPerCU") if n in k}
     return {"bound": "valu-issue", "profile": fn, "instruction_counts_replayed_from_profile": True, "valu_instructions_per_launch": k["SQ_INSTS_VALU"],
+            "mfma_instructions_per_launch": mfma or None, "cycles_per_mfma": p.get("cycles_per_mfma"),
+            "busy_shares_of_the_profile_pct": busy or None,
             "valu_instructions_per_window_and_chunk": d["valu_per_window_chunk"],
             "cycles_per_instruction": cyc, "simds": p["simds"], "issue_cycles_per_simd": issue,
             "kernel_cycles_profiled": d["kernel_cycles"], "frac_of_kernel_cycles": issue / d["kernel_cycles"],
@@ -880,6 +884,7 @@ def main():
     ms_all = [eng.run_ms(b) for b in range(min(args.steps, 32))]
     ms_ld = [m["ld"] for m in ms_all]
     layout_timed = eng.ld_layout()
+    count_unit = eng.last_count_unit()
 
     if args.timed_only:
         if rank == 0:
@@ -1149,7 +1154,8 @@ def main():
                                  "`in_place_tiles` is the same step before that") if layout_timed == 2 else
                                 "the panel's own tiles (ld_layout 1)" if layout_timed == 1 else "none (strict kernel)",
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
-            "roofline": {"bound": "hbm", "kernel": "k_ld_popcount" if ld_variant == 2 else "k_ld_window",
+            "roofline": {"bound": "hbm", "kernel": ("k_ld_popcount (a word's weighted sums by one v_mfma_scale_f32_16x16x128_f8f6f4)"
+                                                    if count_unit == 2 else "k_ld_popcount") if ld_variant == 2 else "k_ld_window",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world)[0],
                          "traffic_from_profile": traffic_bytes(args, world)[1],

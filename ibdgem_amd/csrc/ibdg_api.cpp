@@ -128,6 +128,7 @@ struct ibdg_ctx {
     bool pop_dense_enough = true; // the site list went to the layout asked for (false: "compact_tiles" -1 on a sparse pileup)
     std::vector<unsigned long> nck_h;
     int last_variant = 0;
+    int last_count_unit = 0;           // 2: the last --LD run's single-individual launches counted on the matrix cores, 1: by (mask, count) pairs, 0: no such launch
     // inputs of the previous ibdg_run whose device copies are still valid
     std::vector<uint32_t> prev_targets;
     std::vector<uint8_t> prev_bg;
@@ -178,6 +179,7 @@ struct ibdg_ctx {
     long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
+    long opt_sum_dpp = 1;            // ... its wave sums by DPP moves (0: ds_swizzle, as the vector-ALU form)
     long opt_mx_counts = 1;          // k_ld_popcount: the counts of a haplotype word by one matrix instruction (0: 12 (mask, count) pairs)
     long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
     long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
@@ -1390,6 +1392,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         use_pop = can && c->opt_variant != 1 && c->opt_variant != 3 && (c->opt_variant == 2 || c->pop_dense_enough);
     }
     c->last_variant = ld_mode ? (use_pop ? 2 : (c->opt_variant == 3 ? 3 : 1)) : 0;
+    c->last_count_unit = 0;
     const bool recount = c->opt_count_in_run || !c->counts_valid;
     const int ev_slot = (c->ev_head + 1) % ibdg_ctx::EV_RING;      // becomes the head once the run is queued
     ibdg_ctx::EvSet &E = c->evs[ev_slot];
@@ -1531,6 +1534,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
         pa.mx_counts = (uint32_t)mx_counts;
         pa.rho_shift = (uint32_t)rho_shift;
+        pa.sum_dpp = (uint32_t)c->opt_sum_dpp;
         ibdg::KernelEvents first, dominant, last;  // all null unless dispatch_events
         if (dispatch_events) {
             first.start = E.start_own;
@@ -1610,6 +1614,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->wt_first = pa.t_base;
             c->wt_count = (uint32_t)T_one;
             c->wt_mx = mx_counts;
+            c->last_count_unit = mx_counts ? 2 : 1;
             if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream, dominant))
                 return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         }
@@ -1861,6 +1866,8 @@ int ibdg_last_run_ms(ibdg_ctx *c, float out[5])
 
 int ibdg_last_ld_variant(const ibdg_ctx *c) { return c ? c->last_variant : 0; }
 
+int ibdg_last_count_unit(const ibdg_ctx *c) { return c ? c->last_count_unit : 0; }
+
 int ibdg_ld_layout(const ibdg_ctx *c)
 {
     if (!c || !c->sites_valid || !c->pop_sites_ok)
@@ -1892,6 +1899,10 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "compact_tiles")) {
         if (value < -1 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: compact_tiles must be -1 (never), 0 (auto) or 1 (always)");
         c->opt_compact = value; return 0;
+    }
+    if (!strcmp(name, "sum_dpp")) {
+        if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: sum_dpp must be 0 or 1");
+        c->opt_sum_dpp = value; return 0;
     }
     if (!strcmp(name, "mx_counts")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: mx_counts must be 0 or 1");

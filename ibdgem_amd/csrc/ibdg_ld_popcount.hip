@@ -303,11 +303,14 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
         fo[1] = make_uint2(f[2], f[3]);
         fo[2] = make_uint2(f[4], f[5]);
         if (sum == 0) {
+            // control word of this form: bits 0-13 ring byte offset of the NEXT segment's tile words, 14 planes beyond
+            // cov 0-2 / alt 0-2 present, 15 last segment of its window, 16-23 tile pairs to advance before the next segment
             const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24;
-            const uint32_t fl = (S.flags & ~(1u << 12)) | ((ncov > 3 || nalt > 3) ? 1u << 12 : 0u);
+            const uint32_t fl = ((S.flags & 7) * 1024 + ((S.flags >> 3) & 1) * 8) | ((ncov > 3 || nalt > 3) ? 1u << 14 : 0u) |
+                                (((S.flags >> 13) & 1) << 15) | (((S.flags >> 4) & 0xff) << 16);
             uint4 *oh = reinterpret_cast<uint4 *>(o);
             oh[0] = make_uint4(fl, S.cov[0], S.cov[1], S.cov[2]);
-            oh[1] = make_uint4(at.x, at.y, 0, 0);
+            oh[1] = make_uint4(at.x, at.y, ncov | (nalt << 8), 0);
         }
     }
     if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w (as k_win_target)
@@ -400,6 +403,30 @@ __device__ __forceinline__ double wave_sum2(double a, double b, uint32_t scr_w, 
     v = swz_add<4>(v);
     v = swz_add<8>(v);
     v = swz_add<16>(v);
+    return v;
+}
+
+// The same with the five exchange steps as DPP moves (two v_mov_dpp and the add per step: 15 vector instructions instead
+// of 5, but no trip through the LDS crossbar and nothing to wait for): the additions and their order are those of the
+// swizzle form -- after every step the lanes of a group hold the same subtotal, so a mirror within the group's double is the
+// exchange with lane ^ X -- and the totals are the same bits.  For the matrix-core form, whose wave time is LDS round trips.
+// Lanes 31 and 63 hold the totals of the first and second sum (row_bcast:15 fills rows 1 and 3 only).
+__device__ __forceinline__ double wave_sum2_dpp(double a, double b, uint32_t scr_w, uint32_t scr_r)
+{
+    uint4 r;
+    asm volatile("ds_write_b64 %1, %2\n\t"
+                 "ds_write_b64 %1, %3 offset:512\n\t"
+                 "ds_read_b128 %0, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r)
+                 : "v"(scr_w), "v"(a), "v"(b), "v"(scr_r)
+                 : "memory");
+    double v = __hiloint2double((int)r.y, (int)r.x) + __hiloint2double((int)r.w, (int)r.z);
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]      lane ^ 1
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]      lane ^ 2
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror          the other quad of the eight
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror               the other eight of the row
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3: the other row of the half
     return v;
 }
 
@@ -682,18 +709,16 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
         uint2 x;                                                                                                \
         lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                              \
         flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
-        const uint32_t adv = (flags >> 4) & 0xff;                                                               \
+        const uint32_t adv = flags >> 16;                                                                       \
         if (adv) {                                                                                              \
+            /* every advance requests a pair -- past the run's last one that pair again, into a slot nobody reads any  \
+               more -- so the count of loads in flight stays the nominal one and one counted wait serves */     \
             for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
-                if (q_issue <= q_last)                                                                          \
-                    __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
-                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
-            if (q_issue - 1 <= q_last)                                                                          \
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
-            else                                                                                                \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(q_issue < q_last ? q_issue : q_last) * 64), \
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);  \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                       \
         }                                                                                                       \
-        x_off = (flags & 7) * 1024 + ((flags >> 3) & 1) * 8;                                                    \
+        x_off = flags & 0x3fff;                                                                                 \
         const uint32_t hom = x.x & x.y;                                                                         \
         {                                                                                                       \
             const mx_v8i av = {(int)af_lo.x, (int)af_lo.y, (int)af_lo.z, (int)af_lo.w, (int)af_hi.x, (int)af_hi.y, 0, 0}; \
@@ -708,9 +733,10 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
         } else {                                                                                                \
             ch[0] += __popc(hom & h0.y); ch[1] += __popc(hom & h0.z); ch[2] += __popc(hom & h0.w);              \
         }                                                                                                       \
-        if (flags & (1u << 12)) {                                                                               \
-            const uint32_t ncov = (flags >> 16) & 0xff, nalt = flags >> 24;                                     \
-            const uint2 at = lds_read_b64(rec_addr + 16);                                                       \
+        if (flags & (1u << 14)) {                                                                               \
+            const uint4 h1 = lds_read_b128(rec_addr + 16);                                                      \
+            const uint2 at = make_uint2(h1.x, h1.y);                                                            \
+            const uint32_t nn = __builtin_amdgcn_readfirstlane(h1.z), ncov = nn & 0xff, nalt = nn >> 8;         \
             for (uint32_t k = 3; k < ncov; ++k) {                                                               \
                 const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
                 const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
@@ -782,8 +808,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     if (has_chunk) {
 #pragma unroll
         for (int i = 0; i < NS; ++i, ++q_issue)
-            if (q_issue <= q_last)
-                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
+            if (MX || q_issue <= q_last)              // (matrix-core form: always, see its segment)
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(q_issue < q_last ? q_issue : q_last) * 64),
                                                  (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
     }
 
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     uint32_t c0[FC], c1[FC], ch[FC], g00[FC], g01[FC], g10[FC], g11[FC], A0[FA], A1[FA];
 
     // the first pair must have landed (it was requested before the staging loads, so it has)
-    if (q_issue - 1 <= q_last)
+    if (MX || q_issue - 1 <= q_last)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -860,7 +886,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         uint32_t flags;
         if constexpr (MX) {
             IBDG_SEGMENT_MX(true)
-            while (!(flags & (1u << 13)) && s < nseg)
+            while (!(flags & (1u << 15)))                // (a run ends with the last segment of a window)
                 IBDG_SEGMENT_MX(false)
         } else {
             IBDG_SEGMENT(true)                           // its first segment starts the counters
@@ -922,7 +948,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                 }
                 double s0 = wgt * val[0];                                   // :743
                 double s1 = wgt * (((val[1] + val[2]) + val[3]) + val[4]);  // :744-745
-                const double tot = wave_sum2(s0, s1, scr_w, scr_r);
+                const double tot = a.sum_dpp ? wave_sum2_dpp(s0, s1, scr_w, scr_r) : wave_sum2(s0, s1, scr_w, scr_r);
                 if ((lane & 31) == 31)
                     a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
                 continue;

@@ -46,6 +46,7 @@ SYMBOLS = {
     "ibdg_run_kernel_ms": (C.c_int, [_P, C.c_uint, _P]),
     "ibdg_last_ld_variant": (C.c_int, [_P]),
     "ibdg_ld_layout": (C.c_int, [_P]),
+    "ibdg_last_count_unit": (C.c_int, [_P]),
     "ibdg_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "ibdg_set_background_order": (C.c_int, [_P, _P, C.c_size_t]),
     "ibdg_selftest": (C.c_int, [C.c_char_p]),
@@ -271,6 +272,11 @@ class Engine:
 
     def last_ld_variant(self):
         return self.lib.ibdg_last_ld_variant(self.ctx)
+
+    def last_count_unit(self):
+        """2 = the last run's single-individual launches took the sums of a haplotype word on the matrix cores, 1 = by
+        (mask, count) pairs, 0 = no such launch (ibdg_last_count_unit)."""
+        return self.lib.ibdg_last_count_unit(self.ctx)
 
     def ld_layout(self):
         """0 none, 1 the panel's own tiles, 2 the compacted, window-aligned tiles of the site list."""

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout, ibdg_last_count_unit; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
@@ -210,6 +210,13 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
  * density.  Chosen per upload and per run (option "compact_tiles"); the results are the same bits from either. */
 int ibdg_ld_layout(const ibdg_ctx *ctx);
 
+/* How the last ibdg_run's exponent-counting launches for single comparison individuals (k_ld_popcount: one individual,
+ * or the one to four left over beside the groups of the other kernels) took the weighted sums of a haplotype word:
+ * 2 = one matrix instruction per word (v_mfma_scale_f32_16x16x128_f8f6f4: the rows' weights as FP6, the word's bits as
+ * FP4; option "mx_counts", the default), 1 = twelve (mask, count) pairs on the vector ALU, 0 = no such launch in that
+ * run.  The sums are exact integers either way: same results, bit for bit. */
+int ibdg_last_count_unit(const ibdg_ctx *ctx);
+
 /* Options: "dispatch_events" (0/1: time the --LD launches through their own
  * dispatch packets, which makes ibdg_run_kernel_ms available; costs ~10 us per
  * run more than the default single event record); "async" (0/1: ibdg_run returns as soon as its kernels are queued;
@@ -239,6 +246,10 @@ int ibdg_ld_layout(const ibdg_ctx *ctx);
  * own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "reserve_compact" (0/1, default 1, set before ibdg_upload_panel: the buffer of the compacted tiles, 1.3 x the
  * panel's, is allocated with the panel so that a re-layout never allocates);
+ * "mx_counts" (0/1, default 1: see ibdg_last_count_unit; applies where a run's records of 128 bytes per (window, tile)
+ * segment fit the workgroup's LDS and the powers rho^n 2^(s n) of a window's table stay normal doubles, always so at the
+ * table sizes kept in LDS); "sum_dpp" (0/1, default 1: the wave sums of that form exchange by DPP moves instead of
+ * ds_swizzle -- same additions, same bits);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;

@@ -677,7 +677,7 @@ def test_matrix_core_counts_give_the_bits_of_the_vector_counts(oracle, N, L, W, 
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, W)
             eng.run(targets, ld=True, pu_id=targets[0] if T > 1 else -1)
-            assert eng.last_ld_variant() == 2
+            assert eng.last_ld_variant() == 2 and eng.last_count_unit() == 1 + mx
             out[mx] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(T)]
     for i, t in enumerate(targets):
         assert_bits(out[1][i][0], out[0][i][0], f"t={t} per-row values")

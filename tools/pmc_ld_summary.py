@@ -20,10 +20,21 @@ name = [k for k in raw if "k_ld_popcount<" in k][0]
 k = raw[name]
 pairs = n_win * n_chunks
 valu = k["SQ_INSTS_VALU"]
-pair_instr = 50.0 * n_segs * n_chunks          # 25 pairs x 2 instructions per (segment, chunk)
-cyc = (pair_instr * 3.2 + (valu - pair_instr) * 4.2) / valu
+mfma = k.get("SQ_INSTS_MFMA", 0.0)
+matrix_form = mfma > 0                         # k_ld_popcount<.., MX = true>: the counts of a haplotype word by one MFMA
+if matrix_form:
+    # SQ_INSTS_VALU counts the matrix instructions too.  The vector instructions of this form are a mix of the double-rate
+    # class (v_and_b32, v_add_u32, v_bitop3_b32: 2.2-2.4 cycles alone) and the single-rate one (4.2-5: shifts, v_bcnt,
+    # conversions, fp64): priced like the earlier rounds' mix, 3.5; a v_mfma_scale_f32_16x16x128_f8f6f4 (FP6 x FP4) holds the
+    # SIMD's vector issue for its 16 cycles (tools/ubench/fp4_count.hip: times add)
+    pair_instr = 0.0
+    cyc = 3.5
+    issue = ((valu - mfma) * cyc + mfma * 16.0) / 1024
+else:
+    pair_instr = 50.0 * n_segs * n_chunks          # 25 pairs x 2 instructions per (segment, chunk)
+    cyc = (pair_instr * 3.2 + (valu - pair_instr) * 4.2) / valu
+    issue = valu * cyc / 1024
 kernel_cycles = k["GRBM_GUI_ACTIVE"] / 8
-issue = valu * cyc / 1024
 wc = k.get("SQ_WAVE_CYCLES")
 out = {
     "source": "tools/pmc_ld.sh (rocprofv3 --kernel-trace --pmc passes over `bench.py --timed-only --steps 3 --warmup 1 --opt "
@@ -43,14 +54,19 @@ out = {
         "lds_per_window_chunk": k.get("SQ_INSTS_LDS", 0) / pairs,
         "pair_instructions_per_window_chunk": pair_instr / pairs,
         "kernel_cycles": kernel_cycles,
+        "mfma_per_window_chunk": mfma / pairs,
         "valu_issue_cycles_per_simd": issue,
         "valu_issue_share_of_kernel_cycles": issue / kernel_cycles,
     },
     "simds": 1024,
     "cycles_per_valu_instruction": {
         "value": cyc,
-        "source": "weighted: the segment loop's (mask, count) pairs at 3.2 cycles per instruction (profiles/r02_nop_mix.txt, "
+        "source": ("the matrix-core form's mix of double-rate and single-rate vector instructions priced at 3.5 like the earlier "
+                   "rounds' mix; each of its matrix instructions at 16 cycles (tools/ubench/fp4_count.hip, profiles/r04_fp4_count.txt)")
+                  if matrix_form else
+                  "weighted: the segment loop's (mask, count) pairs at 3.2 cycles per instruction (profiles/r02_nop_mix.txt, "
                   "'and NOP bcnt'), all other vector instructions at 4.2 (profiles/r02_issue_rates.txt)"},
+    "cycles_per_mfma": 16.0 if matrix_form else None,
     "nominal_clock_hz": 2.4e9,
 }
 if wc:
