@@ -1062,7 +1062,8 @@ def main():
         for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
             if fn.endswith("_mfma_pmc.json"):
                 with open(os.path.join(pdir, fn)) as fh:
-                    k = json.load(fh).get("kernels", {}).get("ibdg::k_ld_mfma")
+                    j = json.load(fh)
+                    k = (j.get("kernels") or j).get("ibdg::k_ld_mfma")       # (summarised or raw per-kernel averages)
                 if k:
                     pmc = {"profile": fn, "VALUBusy_pct": k.get("VALUBusy"), "LdsUtil_pct": k.get("LdsUtil"),
                            "MfmaUtil_pct": k.get("MfmaUtil"), "valu_instructions_per_launch": k.get("SQ_INSTS_VALU"),

@@ -184,9 +184,10 @@ struct ibdg_ctx {
     long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
     long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
                                      // (tools/density_sweep.py: one comparison at 1 row in 3: 0.82 ms in place, 0.94 compacted; in 4: 0.76 / 0.76; in 5: 0.79 / 0.65)
-    long opt_compact_targets = 256;  // ... or when the runs on one upload add up to this many comparison individuals (the re-layout
-                                     // is paid once; an individual of the counting kernels counts as 16: it saves 0.09 ms of a
-                                     // 0.8 ms run where one of the matrix-core kernel saves 0.007 of 0.185, the gather costs 1.5)
+    long opt_compact_targets = 256;  // ... or when the runs on one upload add up to this many comparison individuals of the
+                                     // matrix-core kernel k_ld_mfma (the re-layout is paid once: one of them saves 0.007 ms of
+                                     // 0.185, the gather costs 1.5; an individual of the counting kernels counts as 16 with
+                                     // (mask, count) pairs -- it saves 0.04-0.09 ms of 0.77 -- and not at all with mx_counts)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under
@@ -1376,8 +1377,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // reach the point where the re-layout has paid for itself (a rent-or-buy rule: never more than twice the
         // cost of having known the number of runs beforehand).
         // (a group of the matrix-core kernel costs the same whether it holds 3 or IBDG_TG individuals)
+        // (the counting kernel with its sums on the matrix cores gains nothing from the compacted tiles -- 0.60 ms either way,
+        // profiles/r04_count_units.txt -- its runs add nothing; with (mask, count) pairs, option mx_counts 0, 0.73 against 0.77)
         const bool to_mfma = c->opt_mfma_targets && c->tab_in_lds && T >= (size_t)c->opt_mfma_min;
-        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * IBDG_TG : (uint64_t)T * 16u;
+        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * IBDG_TG : c->opt_mx_counts ? 0u : (uint64_t)T * 16u;
         if (c->relayout_credit >= (uint64_t)std::max<long>(1, c->opt_compact_targets)) {
             if (quiesce(c)) return 1;
             if (build_segments(c, true)) return 1;

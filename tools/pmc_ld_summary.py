@@ -37,8 +37,8 @@ else:
 kernel_cycles = k["GRBM_GUI_ACTIVE"] / 8
 wc = k.get("SQ_WAVE_CYCLES")
 out = {
-    "source": "tools/pmc_ld.sh (rocprofv3 --kernel-trace --pmc passes over `bench.py --timed-only --steps 3 --warmup 1 --opt "
-              "compact_tiles=1`: the tiles of a site list in use; per-launch averages over the dispatches of each pass), summarised by tools/pmc_ld_summary.py",
+    "source": "tools/pmc_ld.sh (rocprofv3 --kernel-trace --pmc passes over `bench.py --timed-only --steps 3 --warmup 1`; "
+              "per-launch averages over the dispatches of each pass), summarised by tools/pmc_ld_summary.py",
     "kernel": name,
     "config": {"sites": 4000000, "n_ids": 2504, "window": 100, "targets": 1, "n_win": n_win, "n_chunks": n_chunks,
                "n_segs": n_segs},

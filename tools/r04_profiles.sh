@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 PY=$(python3 -c 'import os, sys; print(os.path.realpath(sys.executable))')
 # 1. the bench line, and in the same call on the same box the per-kernel times of the timed steps
 timeout -k 10 900 "$PY" bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && echo "bench done" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- "$PY" bench.py --timed-only --opt compact_tiles=1 > gpurun_out/${tag}_stats.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- "$PY" bench.py --timed-only > gpurun_out/${tag}_stats.log 2>&1 &&
 cp gpurun_out/${tag}_stats/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv && echo "stats done" &&
 timeout -k 10 300 "$PY" bench.py --steps 20 --warmup 5 --no-e2e --no-cpu-baseline --no-many > gpurun_out/${tag}_bench_driver_flags.json 2>/dev/null &&
 # 2. counters of the dominant kernel (six passes) and its traffic (two)

@@ -18,7 +18,7 @@ for name, kb in raw["FETCH_SIZE"].items():
 dom = max((k for k in kernels if "k_ld_popcount<" in k), key=lambda k: kernels[k]["hbm_bytes_corrected"])
 out = {
     "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python bench.py "
-              "--timed-only --steps 3 --warmup 1 --opt compact_tiles=1 (the tiles of a site list in use); summarised by tools/traffic_summary.py",
+              "--timed-only --steps 3 --warmup 1; summarised by tools/traffic_summary.py",
     "config": {"sites": 4000000, "n_ids": 2504, "window": 100, "targets": 1},
     "unit": "KB as reported by rocprofv3, averaged over dispatches",
     "gfx950_correction": "FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM): fetch bytes "
