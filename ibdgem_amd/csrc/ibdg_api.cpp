@@ -168,7 +168,7 @@ struct ibdg_ctx {
     long opt_multi_target = 1;   // groups of comparison individuals share a workgroup (k_ld_popcount_mt)
     long opt_mfma_targets = 1;   // 5 or more comparison individuals: groups of IBDG_TG through the matrix cores (k_ld_mfma)
     long opt_mfma_plain_tau = 1; // k_ld_mfma looks tau^G up as a plain double where a window's powers allow it (same bits, half the LDS bytes)
-    long opt_mfma_min = 3;       // smallest (last) group worth a launch of its own (round 4: a group of 3 takes 2.15 ms, three single runs 2.5; of 4: 2.09 against 2.30 through k_ld_popcount_mt; of 2: 2.13 against 1.76)
+    long opt_mfma_min = 4;       // smallest (last) group worth a launch of its own (round 4: a group of 4 takes 2.09-2.17 ms, four single runs 2.5; a group of 3 2.14 against 1.87 for three single runs since their counts moved to the matrix cores -- 3 until then; of 2: 2.13 against 1.28)
     long opt_guided = 4;   // shrink the runs towards the end of the grid (0 = uniform runs; n scales the
                            // estimate of workgroups in flight by n/4 -- 4 measured best at 500k and 4M rows)
     long opt_ring = 2;     // LDS ring slots per wave (2, 3, 4 or 8); 2 measured fastest (fewest LDS bytes)

@@ -256,7 +256,7 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * set before ibdg_upload_sites); "multi_target" (0/1, default 1: with four or more
  * comparison individuals in one ibdg_run, groups of four share a workgroup of
  * the exponent-counting kernel -- same results, ~1.4x the throughput); "mfma_targets" (0/1,
- * default 1: with "mfma_min" (1..15, default 3) or more comparison individuals in one ibdg_run,
+ * default 1: with "mfma_min" (1..15, default 4) or more comparison individuals in one ibdg_run,
  * groups of 15 go through the matrix-core kernel -- the sums that depend on the comparison
  * individual as integer matrix products; same results, ~2.5x the throughput of single runs; "mfma_plain_tau"
  * (0/1, default 1: that kernel looks the powers tau^G of a window up as plain doubles where none of them leaves the

@@ -305,7 +305,7 @@ def test_groups_of_comparison_individuals_share_a_workgroup(oracle, M, cov, T):
                                                 (150, 600, 100, 20, 2.0, 130, 8),     # nine groups: two batches of operands
                                                 (64, 400, 257, 50, 20.0, 16, 1)])     # deep windows: exponents in the thousands
 def test_many_comparison_individuals_through_the_matrix_cores(oracle, N, L, W, M, cov, T, tmin):
-    """T >= mfma_min (3 since round 4; 5 before): groups of 15 comparison individuals go through k_ld_mfma (the G(x,t) sums as integer matrix
+    """T >= mfma_min (4 since the single runs count on the matrix cores; 3 and 5 before): groups of 15 comparison individuals go through k_ld_mfma (the G(x,t) sums as integer matrix
     products, 32 background individuals per wave; the window end factored as V_x U_t tau^G), what is left through
     the counting kernels.  Per-row values and LIBD2 are the bits of single runs; the --LD columns agree with the
     counting kernels and, for EVERY comparison individual, with the oracle within the bar (the factored products
