@@ -687,16 +687,11 @@ int build_segments(ibdg_ctx *c, bool compact)
         if (pairs >= (1ull << 31))
             return 0;
         c->n_pairs_c = (uint32_t)((pairs + 3) & ~3ull);
-        const bool tr = getenv("IBDG_TRACE_RELAYOUT") != nullptr;
-        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        double t_a = now();
         if (ensure(c, c->t32c, (size_t)c->n_chunks * c->n_pairs_c * 64 * 16))
             return 1;
-        if (tr) { fprintf(stderr, "## relayout: ensure %.3f ms\n", now() - t_a); t_a = now(); }
         ibdg::launch_gather_transpose32((const uint64_t *)c->panel.p, c->stride, (const uint2 *)c->rec_cov.p, c->n_cov,
                                         c->window, c->n_chunks, c->n_pairs_c, (uint32_t *)c->t32c.p, c->stream);
         HIP_TRY(c, hipGetLastError());
-        if (tr) { fprintf(stderr, "## relayout: launch %.3f ms\n", now() - t_a); t_a = now(); (void)hipStreamSynchronize(c->stream); fprintf(stderr, "## relayout: gather %.3f ms\n", now() - t_a); }
     }
     if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
         ensure(c, c->wraw, (size_t)c->n_win * sizeof(ibdg::WinRaw)))
