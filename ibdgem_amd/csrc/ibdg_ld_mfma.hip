@@ -104,12 +104,17 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
         }
         sel >>= 4 * kb;
         const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24, np = ncov > nalt ? ncov : nalt;
+        // Where no row of the tile has 16 reads or more (nearly every segment) dword d of the image carries the weights times
+        // 8 >> d: the kernel then takes the background bits of its B operand with four masks and no shifts -- values 1, 2, 4, 8
+        // by dword -- and every product is 8 w all the same (8 x 15 fits the signed byte).  Otherwise the plain weights, and
+        // the kernel shifts every bit to the value 8 (seg_wide).
+        const bool wide = np > 4;
         uint32_t out[4] = {0, 0, 0, 0};
         for (uint32_t k = 0; k < np; ++k) {
             const uint32_t f = ((use_alt ? S.alt[k] : S.cov[k]) >> (4 * kb)) & sel;
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                out[d] += ((f >> d) & 0x01010101u) << k;                // weights <= 127: no carry between bytes
+                out[d] += ((f >> d) & 0x01010101u) << (wide ? k : k + 3 - d);       // weights <= 127 (<= 120): no carry between bytes
         }
         a.aimg[((size_t)grp * a.n_segs + s) * 64 + l] = make_uint4(out[0], out[1], out[2], out[3]);
     }
@@ -420,7 +425,8 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t ahead = seg0 + i + 2 < seg1 ? seg0 + i + 2 : seg1 - 1;
         const uint32_t first = (i == 0 || a.segs[seg0 + i - 1].last) ? 1u << 25 : 0u;
         const uint32_t deep = ((S.flags >> 16) & 0xff) > 3 ? 1u << 24 : 0u;
-        rec[2 * i] = make_uint4(a.segs[ahead].tile | deep | first | (S.last ? 1u << 26 : 0u), S.cov[0], S.cov[1], S.cov[2]);
+        const uint32_t wide = (((S.flags >> 16) & 0xff) > 4 || (S.flags >> 24) > 4) ? 1u << 27 : 0u;       // a weight of 16 or more: k_win_target_g
+        rec[2 * i] = make_uint4(a.segs[ahead].tile | deep | wide | first | (S.last ? 1u << 26 : 0u), S.cov[0], S.cov[1], S.cov[2]);
         rec[2 * i + 1] = make_uint4(S.cov[3], S.cov[4], S.cov[5], S.cov[6]);
     }
     __syncthreads();
@@ -451,6 +457,7 @@ void k_ld_mfma(MfmaArgs a)
     // half h): y = x rotated so that that bit sits at 3 + d + 8 j (left by 3 in the lower half of the wave, right by 1
     // in the upper; what wraps around lands where no mask looks), so dword d = (y >> d) & 0x08080808
     const uint32_t rot = h ? 1u : 29u;
+    const uint32_t sh4 = 4 * h;          // (segments without a weight of 16 or more: the bits stay where they are in their bytes)
 
     // the reduction strip: lane (h, n) puts its addend I of a turn at row 8 h + I, column n; lane L = 4 s + p reads row s
     const uint32_t put_addr = (uint32_t)(uintptr_t)(lds_void *)strip + (8 * h * SS + n) * 8;
@@ -517,11 +524,20 @@ void k_ld_mfma(MfmaArgs a)
         r_cur = rec_p[2];                    // (behind the run's last record: a spare one, never used)
         const uint2 x = xq;
         const v4i A = {(int)aq.x, (int)aq.y, (int)aq.z, (int)aq.w};
-        const uint32_t b0 = __builtin_amdgcn_alignbit(x.x, x.x, rot), b1 = __builtin_amdgcn_alignbit(x.y, x.y, rot);
-        const v4i B0 = {(int)(b0 & 0x08080808u), (int)((b0 >> 1) & 0x08080808u), (int)((b0 >> 2) & 0x08080808u),
-                        (int)((b0 >> 3) & 0x08080808u)};
-        const v4i B1 = {(int)(b1 & 0x08080808u), (int)((b1 >> 1) & 0x08080808u), (int)((b1 >> 2) & 0x08080808u),
-                        (int)((b1 >> 3) & 0x08080808u)};
+        v4i B0, B1;
+        if (__builtin_expect((ctl & (1u << 27)) != 0, 0)) {
+            // a row with 16 reads or more in the tile: plain weights in the image, every bit to the value 8
+            const uint32_t b0 = __builtin_amdgcn_alignbit(x.x, x.x, rot), b1 = __builtin_amdgcn_alignbit(x.y, x.y, rot);
+            B0 = v4i{(int)(b0 & 0x08080808u), (int)((b0 >> 1) & 0x08080808u), (int)((b0 >> 2) & 0x08080808u),
+                     (int)((b0 >> 3) & 0x08080808u)};
+            B1 = v4i{(int)(b1 & 0x08080808u), (int)((b1 >> 1) & 0x08080808u), (int)((b1 >> 2) & 0x08080808u),
+                     (int)((b1 >> 3) & 0x08080808u)};
+        } else {
+            // the image carries the weights times 8 >> d: the bit of row 4 h + d + 8 j as it stands in its byte, 1 << d
+            const uint32_t y0 = x.x >> sh4, y1 = x.y >> sh4;
+            B0 = v4i{(int)(y0 & 0x01010101u), (int)(y0 & 0x02020202u), (int)(y0 & 0x04040404u), (int)(y0 & 0x08080808u)};
+            B1 = v4i{(int)(y1 & 0x01010101u), (int)(y1 & 0x02020202u), (int)(y1 & 0x04040404u), (int)(y1 & 0x08080808u)};
+        }
         const uint32_t hom = x.x & x.y;
         uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
         if (ctl & (1u << 24)) {              // deep rows (cov >= 8): max_cov < 128, seven planes at most
