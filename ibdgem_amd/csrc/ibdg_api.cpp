@@ -99,6 +99,14 @@ struct ibdg_ctx {
     size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
     hipEvent_t ev_up[3] = {};           // before the host-to-device copies, after them, after the last prep kernel
     hipEvent_t ev_prep2 = nullptr;      // stream2: the per-window constants of an upload are there
+    // The finalising step of the last run of single individuals (k_ld_finalize's work) when it has been left to the NEXT
+    // run's k_ld_popcount launch (option "finalize_in_next"): whoever reads results or replaces inputs first makes up for
+    // it with a launch of its own (flush_finalize).  The partial sums alternate between the two halves of their buffer.
+    bool fin_pending = false;
+    ibdg::PopFinalArgs fin_args;
+    unsigned fin_count = 0;
+    uint64_t fin_sites_gen = 0;
+    int part_half = 0;
     float up_ms[3] = {0.f, 0.f, 0.f};   // copies, preparation on the device (with its host round trips), whole call
     bool up_ms_pending = false;         // the first two are still to be read from the events
 
@@ -179,6 +187,7 @@ struct ibdg_ctx {
     long opt_compact = 0;            // tiles the --LD kernels read: 0 = chosen per upload (the panel's own where the pileup is
                                      // dense, compacted where it is sparse or the rows are out of file order) and
                                      // per run (many comparison individuals), 1 = always compacted, -1 = never
+    long opt_fin_next = 1;           // queued runs of single individuals: a run's finalising step rides in the next run's --LD launch
     long opt_sum_dpp = 1;            // ... its wave sums by DPP moves (0: ds_swizzle, as the vector-ALU form)
     long opt_mx_counts = 1;          // k_ld_popcount: the counts of a haplotype word by one matrix instruction (0: 12 (mask, count) pairs)
     long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
@@ -227,9 +236,21 @@ int fail(ibdg_ctx *c, const char *fmt, ...)
             return fail((c), "[::] ERROR in %s: %s: %s", __func__, #call, hipGetErrorString(e_)); \
     } while (0)
 
+// The finalising launch a run left to its successor, when no successor took it
+int flush_finalize(ibdg_ctx *c)
+{
+    if (c->fin_pending) {
+        c->fin_pending = false;
+        ibdg::launch_ld_finalize(c->fin_args, c->fin_count, c->stream, ibdg::KernelEvents());
+        HIP_TRY(c, hipGetLastError());
+    }
+    return 0;
+}
+
 // The main stream waits for whatever stream2 still holds (queued, not a host wait).
 int join_streams(ibdg_ctx *c)
 {
+    if (flush_finalize(c)) return 1;
     if (c->s2_pending) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_s2, 0));
         c->s2_pending = false;
@@ -1321,6 +1342,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                              (!bg_count || (c->prev_bg.size() == c->n_ids &&
                                             std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin()))) &&
                              (!ld_mode || c->weight.p);
+    // a finalising step left to "the next run" is taken along only by a run over the same individuals, background and
+    // prepared sites (it reads the background counts and the windows' constants): anything else makes up for it first
+    if (c->fin_pending && (!same_inputs || !ld_mode || c->fin_sites_gen != c->sites_gen || !c->opt_fin_next || !c->opt_async) &&
+        flush_finalize(c))
+        return 1;
     if (!same_inputs) {
         // stream2 may still read the previous targets: the main stream waits for it before overwriting
         if (join_streams(c)) return 1;
@@ -1495,11 +1521,12 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const int mx_counts = c->opt_mx_counts && rho_shift >= 0 && rho_shift <= 40 &&
                               (!c->tab_in_lds || (double)(c->ct_max + 1) * per_read <= 1000.0) &&
                               ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
+        const size_t part_bytes = T * (size_t)c->n_win * c->n_chunks * 16;       // the counting kernels' sums per chunk; two halves taken in turn
         if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
-            ensure(c, c->partial, T_cnt ? T * (size_t)c->n_win * c->n_chunks * 16 : 0) ||
+            ensure(c, c->partial, T_cnt ? 2 * part_bytes : 0) ||
             ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
             ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 512) ||
             ensure(c, c->partial_h, gg_batch * (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128)))
@@ -1526,7 +1553,22 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.t_base = (uint32_t)T_g;
         pa.weight = (const double *)c->weight.p;
         pa.lanes = (uint32_t)lanes;
-        pa.partial = (double *)c->partial.p;
+        // Queued runs of single individuals (the timed steps of a shard, a caller's loop over the same comparison): this run's
+        // finalising step -- one wave per window, 5 us, but a launch of its own with its gap and the event packet behind it:
+        // a tenth of a step on an eighth of a chromosome -- is left to the NEXT run's --LD launch, whose first workgroups
+        // do it on the way (the kernel boundary between the two launches is all the ordering it needs), and this run's
+        // launch does the same for its predecessor.  The partial sums alternate between two halves of their buffer.
+        const bool fin_in_next = c->opt_fin_next && c->opt_async && T_one > 0 && T_one == T_cnt && n_gg == 0 && !dispatch_events;
+        if (c->fin_pending && (!fin_in_next || c->fin_count != (unsigned)T_cnt || c->fin_args.t_base != (uint32_t)T_g) &&
+            flush_finalize(c))
+            return 1;
+        pa.partial = (double *)((char *)c->partial.p + (fin_in_next ? (size_t)c->part_half * part_bytes : 0));
+        if (c->fin_pending) {
+            pa.fin_prev = c->fin_args.partial;
+            pa.n_refpanel = (const int *)c->nrefpanel.p;
+            pa.win_ll = (double *)c->win_ll.p;
+            c->fin_pending = false;
+        }
         pa.ring_slots = (uint32_t)c->seg_ring;
         pa.tab_len = c->ct_max + 1;
         pa.tab_in_lds = (uint32_t)c->tab_in_lds;
@@ -1626,7 +1668,15 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             fa.partial = pa.partial;
             fa.t_base = (uint32_t)T_g;
             fa.halves = 0;
-            ibdg::launch_ld_finalize(fa, (unsigned)T_cnt, c->stream, last);
+            if (fin_in_next) {
+                c->fin_pending = true;
+                c->fin_args = fa;
+                c->fin_count = (unsigned)T_cnt;
+                c->fin_sites_gen = c->sites_gen;
+                c->part_half ^= 1;
+            } else {
+                ibdg::launch_ld_finalize(fa, (unsigned)T_cnt, c->stream, last);
+            }
         }
     } else if (ld_mode) {
         ibdg::LdArgs la;
@@ -1897,6 +1947,11 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
     if (!strcmp(name, "compact_tiles")) {
         if (value < -1 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: compact_tiles must be -1 (never), 0 (auto) or 1 (always)");
         c->opt_compact = value; return 0;
+    }
+    if (!strcmp(name, "finalize_in_next")) {
+        if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: finalize_in_next must be 0 or 1");
+        if (join_streams(c)) return 1;
+        c->opt_fin_next = value; return 0;
     }
     if (!strcmp(name, "sum_dpp")) {
         if (value < 0 || value > 1) return fail(c, "[::] ERROR in ibdg_set_option: sum_dpp must be 0 or 1");

@@ -122,6 +122,9 @@ struct PopArgs {
     uint32_t tab_len;           // entries per power table = (max cov_total) + 1
     uint32_t tab_in_lds;        // 1: the workgroup keeps both tables in LDS
     uint32_t rho_shift = 0;     // ... whose rho^n table (in LDS) holds rho^n * 2^(rho_shift n) as plain doubles
+    const double *fin_prev = nullptr;   // k_ld_popcount: the partial sums of the PREVIOUS run of the same shape, finalised by this launch's first workgroups
+    const int *n_refpanel = nullptr;    // ... what that takes (k_ld_finalize's arguments)
+    double *win_ll = nullptr;
     uint32_t sum_dpp = 0;       // ... and whose wave sums exchange by DPP moves instead of ds_swizzle
     uint32_t mx_counts = 0;     // 1: k_ld_popcount takes the counts of a haplotype word on the matrix cores (records of 128 bytes)
 };

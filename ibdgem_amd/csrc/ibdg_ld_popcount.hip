@@ -777,7 +777,38 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const unsigned t = blockIdx.z;
     // workgroups of one run are neighbours in blockIdx order (and so in dispatch order): the
     // runs at the end of the grid are the short ones (host: guided run lengths)
-    const uint32_t run = blockIdx.x / a.n_cgroups, cgroup = blockIdx.x - run * a.n_cgroups;
+    // The first workgroups of the grid (a.fin_prev != null: ceil(windows / waves of a workgroup) of them) do the finalising step of the PREVIOUS
+    // run of the same shape -- k_ld_finalize's arithmetic, a wave per window -- whose partial sums that launch left in the
+    // other half of their buffer: complete and visible, a kernel boundary lies between.  The workgroups of the runs follow.
+    uint32_t bx = blockIdx.x;
+    if (a.fin_prev) {
+        const uint32_t n_fin = (a.n_win + a.waves_per_group - 1) / a.waves_per_group;
+        if (bx < n_fin) {
+            const uint32_t w = bx * a.waves_per_group + wave;
+            if (w < a.n_win) {
+                const unsigned tt = a.t_base + t;
+                const double2 *p = reinterpret_cast<const double2 *>(a.fin_prev) + ((size_t)tt * a.n_win + w) * a.n_chunks;
+                double t0 = 0.0, t1 = 0.0;
+                for (uint32_t cc = lane; cc < a.n_chunks; cc += 64) {
+                    const double2 v = p[cc];
+                    t0 += v.x;
+                    t1 += v.y;
+                }
+                t0 = wave_sum_to_lane63(t0);
+                t1 = wave_sum_to_lane63(t1);
+                if (lane == 63) {
+                    const int nref = a.n_refpanel[tt];
+                    const double mK = wconst[w].mK;             // mantissa of K' (its exponent went into every term)
+                    double *o = a.win_ll + ((size_t)tt * a.n_win + w) * 3;
+                    o[0] = (t0 * mK) / (double)nref;
+                    o[1] = (t1 * mK) / (double)(nref * 4);
+                }
+            }
+            return;
+        }
+        bx -= n_fin;
+    }
+    const uint32_t run = bx / a.n_cgroups, cgroup = bx - run * a.n_cgroups;
     const uint32_t w0 = run_begin[run], w1 = run_begin[run + 1];
     const uint32_t seg0 = wconst[w0].seg_begin, seg1 = wconst[w1].seg_begin;
     const uint32_t nseg = seg1 - seg0;
@@ -1441,7 +1472,7 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
         return 0;
     if (planes < 1 || planes > 8)
         return 1;
-    dim3 grid(a.n_runs * a.n_cgroups, 1, n_targets);
+    dim3 grid(a.n_runs * a.n_cgroups + (a.fin_prev ? (a.n_win + a.waves_per_group - 1) / a.waves_per_group : 0), 1, n_targets);
     if (a.mx_counts) {
         if (a.ring_slots == 2)
             return a.tab_in_lds ? launch_pop<2, true, true>(a, grid, st, ev) : launch_pop<2, false, true>(a, grid, st, ev);

@@ -250,6 +250,10 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * segment fit the workgroup's LDS and the powers rho^n 2^(s n) of a window's table stay normal doubles, always so at the
  * table sizes kept in LDS); "sum_dpp" (0/1, default 1: the wave sums of that form exchange by DPP moves instead of
  * ds_swizzle -- same additions, same bits);
+ * "finalize_in_next" (0/1, default 1; with "async" only: a run of single comparison individuals leaves its finalising
+ * step -- the sum over the chunks and the background average, src/ibdgem.c:751-752 -- to the next run's --LD launch when
+ * that run is over the same individuals, background and prepared sites; whoever reads results or replaces inputs first
+ * gets a launch of its own for it: one launch, its gap and an event packet less per queued run, same results);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;

@@ -812,6 +812,59 @@ def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
         assert eng.ld_layout() == 1
 
 
+def test_queued_runs_leave_the_finalising_step_to_the_next_launch(oracle):
+    """Option "async": a run of single comparison individuals leaves its finalising step (k_ld_finalize's arithmetic) to
+    the next run's --LD launch when that run is over the same individuals, background and prepared sites -- otherwise,
+    and whenever somebody reads results or replaces inputs first, a launch of its own makes up for it.  Whatever the
+    sequence, the window tables are the bits of the synchronous runs (src/ibdgem.c:751-752 either way)."""
+    N, L = 300, 5000
+    alle, nr, na = synth(1234, L, N)
+    bg = np.random.default_rng(5).integers(0, 3, size=N).astype(np.uint8)
+    with E.Engine() as eng:
+        eng.set_option("multi_target", 0)
+        eng.set_option("mfma_targets", 0)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        want = {}
+        for key, (tg, kw) in {"a": ([3], {}), "b": ([5], {}), "c": ([3, 5, 9], {}), "d": ([3], {"bg_count": bg, "pu_id": 3})}.items():
+            eng.run(tg, ld=True, **kw)
+            want[key] = [eng.window_ll(i) for i in range(len(tg))]
+        res_a = oracle.compare(alle, nr, na, 3, window=100, ld=True)
+        assert_ld_close(want["a"][0][:, :2], res_a["win"][:, :2], "synchronous run vs oracle")
+        for fin_next in (1, 0):
+            eng.set_option("finalize_in_next", fin_next)
+            eng.set_option("async", 1)
+            for _ in range(4):
+                eng.run([3], ld=True)                                    # three finalising steps ride along, the last one is made up for
+            assert_bits(eng.window_ll(0), want["a"][0], f"queued runs, finalize_in_next {fin_next}")
+            eng.run([3], ld=True)
+            eng.run([5], ld=True)                                        # other individual: the pending step first
+            eng.run([5], ld=True)
+            assert_bits(eng.window_ll(0), want["b"][0], "after a change of individual")
+            eng.run([3, 5, 9], ld=True)
+            eng.run([3, 5, 9], ld=True)
+            for i in range(3):
+                assert_bits(eng.window_ll(i), want["c"][i], f"three single individuals per run, {i}")
+            eng.run([3], ld=True, bg_count=bg, pu_id=3)
+            eng.run([3], ld=True, bg_count=bg, pu_id=3)
+            eng.run([3], ld=True)                                        # other background counts
+            assert_bits(eng.window_ll(0), want["a"][0], "after a change of background")
+            eng.run([3], ld=True, bg_count=bg, pu_id=3)
+            eng.run([3], ld=True, bg_count=bg, pu_id=3)
+            eng.sync()
+            assert_bits(eng.window_ll(0), want["d"][0], "background multiplicities")
+            # new sites between queued runs: the pending step belongs to the old ones
+            eng.run([3], ld=True)
+            eng.upload_sites(np.arange(L // 2), nr[:L // 2], na[:L // 2], 100)
+            eng.run([3], ld=True)
+            eng.run([3], ld=True)
+            half = eng.window_ll(0)
+            eng.set_option("async", 0)
+            eng.run([3], ld=True)
+            assert_bits(half, eng.window_ll(0), "after new sites")
+            eng.upload_sites(np.arange(L), nr, na, 100)
+
+
 def test_dispatch_events_give_the_dominant_kernel_duration():
     """Option "dispatch_events": the --LD launches are timed through their own dispatch packets; the
     dominant kernel's duration lies inside the interval of the --LD launches, results unchanged."""
