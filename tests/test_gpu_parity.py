@@ -865,6 +865,57 @@ def test_queued_runs_leave_the_finalising_step_to_the_next_launch(oracle):
             eng.upload_sites(np.arange(L), nr, na, 100)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sequences_of_queued_runs_uploads_and_reads(seed):
+    """Queued runs (option "async") in random order with reads, new sites, other individuals, other backgrounds, several
+    individuals per run (single runs, groups of four, the matrix-core groups) and the finalising step left to the next
+    launch or not: every table read is the bits of the same run made synchronously on a fresh engine state."""
+    rng = np.random.default_rng(seed)
+    N, L = 200, 4000
+    alle, nr, na = synth(77 + seed, L, N)
+    bg = rng.integers(0, 3, size=N).astype(np.uint8)
+    site_sets = [np.arange(L), np.arange(L // 3, L), np.sort(rng.choice(L, size=L // 2, replace=False))]
+    target_sets = [[3], [5], [3, 5, 9], list(range(20, 27)), list(range(40, 58))]
+    kw_sets = [{}, {"bg_count": bg, "pu_id": 3}]
+
+    def key(si, ti, ki):
+        return si, ti, ki
+
+    want = {}
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        for si, rows in enumerate(site_sets):
+            eng.upload_sites(rows, nr[rows], na[rows], 100)
+            for ti, tg in enumerate(target_sets):
+                for ki, kw in enumerate(kw_sets):
+                    eng.run(tg, ld=True, **kw)
+                    want[key(si, ti, ki)] = [eng.window_ll(i) for i in range(len(tg))]
+        eng.set_option("async", 1)
+        si = 0
+        eng.upload_sites(site_sets[0], nr[site_sets[0]], na[site_sets[0]], 100)
+        last = None
+        for step in range(150):
+            op = rng.random()
+            if op < 0.6:
+                ti, ki = (int(rng.integers(len(target_sets))), int(rng.integers(len(kw_sets)))) if last is None or rng.random() < 0.4 else last[1:]
+                eng.run(target_sets[ti], ld=True, **kw_sets[ki])
+                last = (si, ti, ki)
+            elif op < 0.8 and last is not None:
+                tg = target_sets[last[1]]
+                i = int(rng.integers(len(tg)))
+                assert_bits(eng.window_ll(i), want[last][i], f"seed {seed} step {step}: {last}, individual {i}")
+            elif op < 0.88:
+                si = int(rng.integers(len(site_sets)))
+                eng.upload_sites(site_sets[si], nr[site_sets[si]], na[site_sets[si]], 100)
+                last = None
+            elif op < 0.94:
+                eng.set_option("finalize_in_next", int(rng.integers(2)))
+            else:
+                eng.sync()
+        if last is not None:
+            assert_bits(eng.window_ll(0), want[last][0], f"seed {seed}: the last run {last}")
+
+
 def test_dispatch_events_give_the_dominant_kernel_duration():
     """Option "dispatch_events": the --LD launches are timed through their own dispatch packets; the
     dominant kernel's duration lies inside the interval of the --LD launches, results unchanged."""
