@@ -37,6 +37,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef __GLIBC__
+#include <malloc.h>
+#endif
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
@@ -219,7 +222,11 @@ static int read_idlist_csv(const char *csv, const names_t *ids, idlist_t *out)
     char *buf = strdup(csv);
     out->idx = malloc((strlen(csv) / 2 + 2) * sizeof *out->idx);
     out->n = 0;
-    for (char *tok = strtok(buf, ","); tok; tok = strtok(NULL, ",")) {
+    /* strtok_r: the device contexts start on a thread of their own while this runs, and the runtime's start-up splits
+     * strings with strtok too -- the two shared its hidden state, and every now and then the list ended early in one of
+     * the runtime's strings ("Sample 00000000 not found ...", fewer comparisons than asked for, exit code 0) */
+    char *save = NULL;
+    for (char *tok = strtok_r(buf, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
         long k = find_name(ids, tok);
         if (k < 0) {
             fprintf(stderr, "Sample %s not found in reference panel.\n", tok);
@@ -645,7 +652,8 @@ static int read_genotypes_vcf(const char *vcf_fn, names_t *ids)
         size_t cap = 0;
         ids->n = 0;
         ids->names = NULL;
-        for (char *tok = strtok(p, "\t"); tok; tok = strtok(NULL, "\t")) {
+        char *save = NULL;
+        for (char *tok = strtok_r(p, "\t", &save); tok; tok = strtok_r(NULL, "\t", &save)) {
             if (ids->n == cap) {
                 cap = cap ? cap * 2 : 256;
                 ids->names = ls_xrealloc(ids->names, cap * sizeof *ids->names);
@@ -1402,8 +1410,10 @@ static void *fmt_summary(void *arg)
     return NULL;
 }
 
-/* 160 bytes hold any row: three integers of at most 20 digits, three numbers of at most 24 characters */
-static int write_summary_parallel(FILE *sum, sum_job proto, size_t n_win, int threads)
+/* 160 bytes hold any row: three integers of at most 20 digits, three numbers of at most 24 characters.
+ * *buf / *cap: the caller's buffer, kept from one individual to the next (5.5 MB at 35 000 windows: allocated anew for every
+ * individual it went back to the system each time -- a map, 600 page faults and an unmap per summary file). */
+static int write_summary_parallel(FILE *sum, sum_job proto, size_t n_win, int threads, char **buf, size_t *cap)
 {
     sum_job jobs[64];
     pthread_t tid[64];
@@ -1411,7 +1421,12 @@ static int write_summary_parallel(FILE *sum, sum_job proto, size_t n_win, int th
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
     const int team = n_win < 2048 ? 1 : threads;
-    char *all = malloc(n_win * 160 + 16);
+    if (*cap < n_win * 160 + 16) {
+        free(*buf);
+        *buf = malloc(n_win * 160 + 16);
+        *cap = *buf ? n_win * 160 + 16 : 0;
+    }
+    char *all = *buf;
     if (!all)
         return 1;
     for (int t = 0; t < team; ++t) {
@@ -1429,11 +1444,20 @@ static int write_summary_parallel(FILE *sum, sum_job proto, size_t n_win, int th
     for (int t = 0; t + 1 < team; ++t)
         if (started[t])
             pthread_join(tid[t], NULL);
-    int rc = 0;
-    for (int t = 0; t < team; ++t)
-        if (fwrite(jobs[t].buf, 1, jobs[t].len, sum) != jobs[t].len)
-            rc = 1;
-    free(all);
+    /* straight to the descriptor (stdio would copy the 2.5 MB through its buffer); what stdio holds goes first */
+    int rc = fflush(sum) != 0;
+    const int fd = fileno(sum);
+    for (int t = 0; t < team && !rc; ++t)
+        for (size_t off = 0; off < jobs[t].len;) {
+            const ssize_t w = write(fd, jobs[t].buf + off, jobs[t].len - off);
+            if (w < 0) {
+                if (errno == EINTR)
+                    continue;
+                rc = 1;
+                break;
+            }
+            off += (size_t)w;
+        }
     return rc;
 }
 
@@ -1461,16 +1485,34 @@ typedef struct {
     double *win_ll;
     size_t n_win;
     int failed;
+    int dev_idx;                             /* which of the run's devices (its slot of win_cache) */
+    int same_sites;                          /* the site list is the same for every comparison individual of the run */
 } shard_job;
+
+/* Per device: the window table of the site list at hand (first row, last row, covered rows per window -- the same for
+ * every comparison individual over that list: fetched once, not once per individual) and a page-locked buffer through
+ * which an individual's window likelihoods come back at link speed (0.8 MB each at 35 000 windows: through pageable
+ * memory the copy took longer than the individual's share of the engine's run). */
+typedef struct {
+    size_t n_win;
+    uint32_t *first, *last, *ncov;
+    int valid;
+    double *stage;
+    size_t stage_cap;
+} win_cache;
+static win_cache g_wcache[64];
 
 static void *shard_run(void *arg)
 {
     shard_job *j = arg;
     const size_t n = j->b - j->a;
+    win_cache *wc = &g_wcache[j->dev_idx & 63];
     j->failed = 1;
-    if (j->do_upload && ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a,
-                                          j->fo ? j->fo + j->a : NULL, n, j->window))
-        return NULL;
+    if (j->do_upload) {
+        wc->valid = 0;
+        if (ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a, j->fo ? j->fo + j->a : NULL, n, j->window))
+            return NULL;
+    }
     if (j->do_run && ibdg_run(j->eng, j->targets, j->n_targets, j->bg_count, j->pu_id, j->ld))
         return NULL;
     j->n_win = ibdg_num_windows(j->eng);
@@ -1478,7 +1520,40 @@ static void *shard_run(void *arg)
     j->w_last = malloc((j->n_win + 1) * 4);
     j->w_ncov = malloc((j->n_win + 1) * 4);
     j->win_ll = malloc((j->n_win + 1) * 24);
-    if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov) || ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
+    if (!j->w_first || !j->w_last || !j->w_ncov || !j->win_ll)
+        return NULL;
+    if (j->same_sites && wc->valid && wc->n_win == j->n_win) {
+        memcpy(j->w_first, wc->first, j->n_win * 4);
+        memcpy(j->w_last, wc->last, j->n_win * 4);
+        memcpy(j->w_ncov, wc->ncov, j->n_win * 4);
+    } else {
+        if (ibdg_get_windows(j->eng, j->w_first, j->w_last, j->w_ncov))
+            return NULL;
+        if (j->same_sites) {
+            free(wc->first); free(wc->last); free(wc->ncov);
+            wc->first = malloc((j->n_win + 1) * 4);
+            wc->last = malloc((j->n_win + 1) * 4);
+            wc->ncov = malloc((j->n_win + 1) * 4);
+            if (wc->first && wc->last && wc->ncov) {
+                memcpy(wc->first, j->w_first, j->n_win * 4);
+                memcpy(wc->last, j->w_last, j->n_win * 4);
+                memcpy(wc->ncov, j->w_ncov, j->n_win * 4);
+                wc->n_win = j->n_win;
+                wc->valid = 1;
+            }
+        }
+    }
+    if (wc->stage_cap < (j->n_win + 1) * 24) {
+        if (wc->stage)
+            ibdg_host_free(wc->stage);
+        wc->stage = ibdg_host_alloc((j->n_win + 1) * 24);
+        wc->stage_cap = wc->stage ? (j->n_win + 1) * 24 : 0;
+    }
+    if (wc->stage) {
+        if (ibdg_get_window_ll(j->eng, j->t_local, wc->stage))
+            return NULL;
+        memcpy(j->win_ll, wc->stage, j->n_win * 24);
+    } else if (ibdg_get_window_ll(j->eng, j->t_local, j->win_ll))
         return NULL;
     if (j->want_sites && ibdg_get_site_ll(j->eng, j->t_local, j->site_ll + 3 * j->a))
         return NULL;
@@ -1855,9 +1930,11 @@ typedef struct {
     pthread_t th;
     int running, failed;
     int pending;                                /* the files are open and still hold whatever an earlier run left in them */
+    char *sum_buf;                              /* the slot's buffer for the text of a summary file (kept between individuals) */
+    size_t sum_cap;
 } out_job;
 
-enum { OUT_SLOTS = 6 };
+enum { OUT_SLOTS = 12 };
 static out_job g_outs[OUT_SLOTS];
 
 /* see quit(): join the output threads; when the run is failing, empty the files nobody got to */
@@ -1932,7 +2009,7 @@ static void *output_individual(void *arg)
         sum_job sj;
         memset(&sj, 0, sizeof sj);
         sj.s_row = o->s_row; sj.w_first = o->w_first; sj.w_last = o->w_last; sj.w_ncov = o->w_ncov; sj.win_ll = o->win_ll;
-        if (write_summary_parallel(sum, sj, o->n_win, o->threads)) {
+        if (write_summary_parallel(sum, sj, o->n_win, o->threads, &o->sum_buf, &o->sum_cap)) {
             fprintf(stderr, "[::] ERROR writing the summary rows of %s.\n", o->tname);
             return NULL;
         }
@@ -1960,6 +2037,12 @@ int main(int argc, char **argv)
 {
     const clock_t t_start = clock();
     phase("start");
+#ifdef __GLIBC__
+    /* the per-individual arrays (window tables, 1.2 MB) and text buffers come and go once per comparison individual: kept in
+     * the heap instead of a map, 300 page faults and an unmap each time (0.3 ms of an individual's 0.7 in a whole-panel run) */
+    mallopt(M_MMAP_THRESHOLD, 256 << 20);
+    mallopt(M_TRIM_THRESHOLD, 512 << 20);
+#endif
     fmt_init();
     const char *hap_fn = NULL, *legend_fn = NULL, *indv_fn = NULL, *pu_fn = NULL, *vcf_fn = NULL;
     const char *sample_fn = NULL, *sample_csv = NULL, *bg_fn = NULL, *af_fn = NULL, *pos_fn = NULL;
@@ -2044,7 +2127,8 @@ int main(int argc, char **argv)
         dev_job.eps = opt_eps;
         dev_job.max_cov = opt_max_cov;
         char *dl = strdup(devices_arg);
-        for (char *tok = strtok(dl, ","); tok && dev_job.n < 64; tok = strtok(NULL, ","))
+        char *save = NULL;
+        for (char *tok = strtok_r(dl, ",", &save); tok && dev_job.n < 64; tok = strtok_r(NULL, ",", &save))
             dev_job.dev[dev_job.n++] = atoi(tok);
         free(dl);
         if (pthread_create(&g_dev_thread, NULL, dev_start, &dev_job) != 0)
@@ -2235,11 +2319,15 @@ int main(int argc, char **argv)
      * a per-row array of its own -- when the site list is the same for all of them (it is read by the writers), the rows go
      * to files (stdout keeps its order) and there is a table to write at all. */
     out_job *const outs = g_outs;
-    const int overlap = !has_v && cull_p == 1.0 && !opt_plan && !opt_summary_only && targets.n > 1;
+    /* (--summary-only: the summary files alone, 2.5 MB each at 35 000 windows -- 1.5 ms per individual when written one
+     * after the other, most of a whole-panel job whose engine time is 0.2 ms per individual) */
+    const int overlap = !has_v && cull_p == 1.0 && !opt_plan && targets.n > 1;
     double *site_slot[OUT_SLOTS] = {site_ll};
-    int out_slots = 4;
+    /* (--summary-only: 2.5 MB per individual instead of 330: twelve individuals at a time with four formatter threads each --
+     * 0.52 ms per individual in a run of 960 against 0.65 with six and eight, 0.90 with four, tools/many_summaries.py) */
+    int out_slots = opt_summary_only ? 12 : 4;
     char *row_pre = NULL;                       /* columns 1-9 of every row as text, shared by all individuals' tables */
-    uint32_t *row_pre_off = NULL;                  /* (IBDGEM_OUT_SLOTS=1..6, default 4: for the tests and for measurements) */
+    uint32_t *row_pre_off = NULL;                  /* (IBDGEM_OUT_SLOTS=1..12, default 4, 12 with --summary-only: for the tests and for measurements) */
     if (getenv("IBDGEM_OUT_SLOTS") && atoi(getenv("IBDGEM_OUT_SLOTS")) >= 1 && atoi(getenv("IBDGEM_OUT_SLOTS")) <= OUT_SLOTS)
         out_slots = atoi(getenv("IBDGEM_OUT_SLOTS"));
     const int out_threads_env = getenv("IBDGEM_OUT_THREADS") ? atoi(getenv("IBDGEM_OUT_THREADS")) : 0;   /* (measurement switch) */
@@ -2304,7 +2392,7 @@ int main(int argc, char **argv)
         }
         const unsigned long processed = n;
         phase("per individual: site list");
-        if (ti == 0 && overlap && targets.n >= 3 && n > 0) {
+        if (ti == 0 && overlap && !opt_summary_only && targets.n >= 3 && n > 0) {
             /* nine of a row's fourteen columns are the same for every comparison individual: their text is made once */
             fmt_job pp;
             memset(&pp, 0, sizeof pp);
@@ -2394,6 +2482,7 @@ int main(int argc, char **argv)
                     j->do_upload = j->do_run = 1;
                 }
                 j->bg_count = bg_count; j->pu_id = (int)pu_id; j->ld = opt_ld;
+                j->dev_idx = d; j->same_sites = batchable;
                 j->site_ll = site_ll;
                 /* (no thread to be had: the shard runs here -- never exit() while other shard threads are
                  * inside the GPU runtime) */
@@ -2412,19 +2501,25 @@ int main(int argc, char **argv)
             }
             if (shard_failed >= 0)
                 DIE("%s\n", ibdg_last_error(jobs[shard_failed].eng));
-            w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = malloc((n_win + 1) * 4);
-            win_ll = malloc((n_win + 1) * 24);
-            size_t wo = 0;
-            for (int d = 0; d < n_eng; ++d) {
-                shard_job *j = &jobs[d];
-                for (size_t w = 0; w < j->n_win; ++w) {
-                    w_first[wo + w] = j->w_first[w] + (uint32_t)j->a;
-                    w_last[wo + w] = j->w_last[w] + (uint32_t)j->a;
-                    w_ncov[wo + w] = j->w_ncov[w];
-                    memcpy(win_ll + 3 * (wo + w), j->win_ll + 3 * w, 24);
+            if (n_eng == 1 && jobs[0].a == 0) {
+                /* one device, the whole site list: its arrays as they are (a copy of 1.2 MB per individual otherwise) */
+                w_first = jobs[0].w_first; w_last = jobs[0].w_last; w_ncov = jobs[0].w_ncov; win_ll = jobs[0].win_ll;
+            } else {
+                w_first = malloc((n_win + 1) * 4); w_last = malloc((n_win + 1) * 4); w_ncov = malloc((n_win + 1) * 4);
+                win_ll = malloc((n_win + 1) * 24);
+                size_t wo = 0;
+                for (int d = 0; d < n_eng; ++d) {
+                    shard_job *j = &jobs[d];
+                    const uint32_t a0 = (uint32_t)j->a;
+                    for (size_t w = 0; w < j->n_win; ++w) {
+                        w_first[wo + w] = j->w_first[w] + a0;
+                        w_last[wo + w] = j->w_last[w] + a0;
+                    }
+                    memcpy(w_ncov + wo, j->w_ncov, j->n_win * 4);
+                    memcpy(win_ll + 3 * wo, j->win_ll, j->n_win * 24);
+                    wo += j->n_win;
+                    free(j->w_first); free(j->w_last); free(j->w_ncov); free(j->win_ll);
                 }
-                wo += j->n_win;
-                free(j->w_first); free(j->w_last); free(j->w_ncov); free(j->win_ll);
             }
         }
 
@@ -2462,7 +2557,7 @@ int main(int argc, char **argv)
         const int all_threads = opt_threads > 0 ? opt_threads : default_threads();
         /* (tools/many_tables.py: files of 1 / 2 / 3 / 4 / 6 individuals at once with 8 threads each 73* / 66 / 57 / 47 / 54 ms per
          * individual, *16 threads; 4 x 4 threads 58, 3 x 16 threads 57) */
-        o->threads = overlap && out_slots > 1 && all_threads > 3 ? all_threads / 2 : all_threads;
+        o->threads = overlap && out_slots > 1 && all_threads > 3 ? (opt_summary_only ? (all_threads + 3) / 4 : all_threads / 2) : all_threads;
         if (overlap && out_threads_env > 0)
             o->threads = out_threads_env;
         o->running = overlap && pthread_create(&o->th, NULL, output_individual, o) == 0;

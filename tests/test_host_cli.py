@@ -517,6 +517,21 @@ def test_threaded_pileup_reader_on_messy_lines(tmp_path):
     assert "Problem parsing garbage" in want.stderr and "Cannot parse ? in reads field" in want.stderr
 
 
+def test_host_sources_keep_clear_of_libc_calls_with_hidden_state():
+    """The device contexts start on a thread of their own while the main thread parses its inputs, and the GPU runtime's
+    start-up uses libc freely: strtok in the -s parser shared its hidden state with the runtime's strtok and now and then
+    cut the list of comparison individuals short ("Sample 00000000 not found in reference panel.", exit code 0).  The
+    program's sources use the re-entrant forms only (rand(): the program has its own copy of glibc's generator)."""
+    import re
+    host = os.path.join(REPO, "ibdgem_amd", "host")
+    for fn in sorted(os.listdir(host)):
+        if fn.endswith(".c"):
+            text = open(os.path.join(host, fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            for call in ("strtok", "localtime", "gmtime", "asctime", "ctime", "strerror", "rand", "srand", "getpwnam", "readdir"):
+                assert not re.search(r"(?<![A-Za-z0-9_])%s\s*\(" % call, text), f"{fn}: {call}()"
+
+
 def test_number_conversions_equal_printf():
     """The per-site table is written with the program's own %e / %lf conversions (long double / 128-bit integer
     arithmetic, sprintf for whatever falls within 1e-6 of a rounding boundary): against sprintf on two million
