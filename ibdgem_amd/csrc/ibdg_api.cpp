@@ -1856,6 +1856,13 @@ int ibdg_get_window_ll(ibdg_ctx *c, size_t t, double *out)
     return fetch(c, out, (const char *)c->win_ll.p + t * (size_t)c->n_win * 24, (size_t)c->n_win * 24);
 }
 
+int ibdg_get_window_ll_all(ibdg_ctx *c, double *out)
+{
+    if (!c) return 1;
+    if (!c->have_results) return fail(c, "[::] ERROR in ibdg_get_window_ll_all: no results (call ibdg_run)");
+    return fetch(c, out, c->win_ll.p, c->n_targets * (size_t)c->n_win * 24);
+}
+
 int ibdg_get_alt_counts(ibdg_ctx *c, size_t first_row, size_t n, uint32_t *out)
 {
     if (!c) return 1;

@@ -40,6 +40,7 @@ SYMBOLS = {
     "ibdg_get_site_af": (C.c_int, [_P, _P]),
     "ibdg_get_site_ll": (C.c_int, [_P, C.c_size_t, _P]),
     "ibdg_get_window_ll": (C.c_int, [_P, C.c_size_t, _P]),
+    "ibdg_get_window_ll_all": (C.c_int, [_P, _P]),
     "ibdg_get_alt_counts": (C.c_int, [_P, C.c_size_t, C.c_size_t, _P]),
     "ibdg_last_run_ms": (C.c_int, [_P, _P]),
     "ibdg_run_ms": (C.c_int, [_P, C.c_uint, _P]),
@@ -241,6 +242,14 @@ class Engine:
             out = np.empty((self.n_windows, 3), dtype=np.float64)
         assert out.dtype == np.float64 and out.size >= self.n_windows * 3 and out.flags.c_contiguous
         self._chk(self.lib.ibdg_get_window_ll(self.ctx, t, out.ctypes.data))
+        return out
+
+    def window_ll_all(self, n_targets, out=None):
+        """The window tables of all `n_targets` comparison individuals of the last run in one copy: [n_targets][n_windows][3]."""
+        if out is None:
+            out = np.empty((n_targets, self.n_windows, 3), dtype=np.float64)
+        assert out.dtype == np.float64 and out.size >= n_targets * self.n_windows * 3 and out.flags.c_contiguous
+        self._chk(self.lib.ibdg_get_window_ll_all(self.ctx, out.ctypes.data))
         return out
 
     def alt_counts(self, first, n):

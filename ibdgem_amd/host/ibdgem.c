@@ -1487,6 +1487,8 @@ typedef struct {
     int failed;
     int dev_idx;                             /* which of the run's devices (its slot of win_cache) */
     int same_sites;                          /* the site list is the same for every comparison individual of the run */
+    const uint32_t *next_targets;            /* the batch after this one (NULL: none), queued on the device while the host goes */
+    size_t n_next;                           /* through this batch's tables -- window tables only (--summary-only) */
 } shard_job;
 
 /* Per device: the window table of the site list at hand (first row, last row, covered rows per window -- the same for
@@ -1499,6 +1501,12 @@ typedef struct {
     int valid;
     double *stage;
     size_t stage_cap;
+    /* a batch's window tables, taken off the device in one copy, so that the next batch can run while the host goes through
+     * them (one table at a time left the device idle for the 4 ms the host needs per batch of 30, beside 6 ms of running) */
+    double *batch_ll;
+    size_t batch_cap, batch_T;
+    const uint32_t *batch_of;                /* the batch (its targets) the tables belong to; NULL: none */
+    const uint32_t *ahead_of;                /* the batch that has been queued ahead on the device; NULL: none */
 } win_cache;
 static win_cache g_wcache[64];
 
@@ -1513,8 +1521,39 @@ static void *shard_run(void *arg)
         if (ibdg_upload_sites(j->eng, j->row + j->a, j->nr + j->a, j->na + j->a, j->fo ? j->fo + j->a : NULL, n, j->window))
             return NULL;
     }
-    if (j->do_run && ibdg_run(j->eng, j->targets, j->n_targets, j->bg_count, j->pu_id, j->ld))
-        return NULL;
+    if (j->do_upload || j->do_run)
+        wc->batch_of = NULL;
+    if (j->do_run) {
+        if (wc->ahead_of != j->targets) {        /* not queued ahead (the first batch, or no look-ahead in this run) */
+            if (wc->ahead_of && ibdg_sync(j->eng))
+                return NULL;
+            if (ibdg_run(j->eng, j->targets, j->n_targets, j->bg_count, j->pu_id, j->ld))
+                return NULL;
+        }
+        wc->ahead_of = NULL;
+        if (j->next_targets || j->n_targets > 1) {
+            const size_t nw = ibdg_num_windows(j->eng), need = j->n_targets * (nw + 1) * 24;
+            if (wc->batch_cap < need) {
+                if (wc->batch_ll)
+                    ibdg_host_free(wc->batch_ll);
+                wc->batch_ll = ibdg_host_alloc(need);
+                wc->batch_cap = wc->batch_ll ? need : 0;
+            }
+            if (wc->batch_ll && !j->want_sites) {
+                if (ibdg_get_window_ll_all(j->eng, wc->batch_ll))        /* waits for the run */
+                    return NULL;
+                wc->batch_of = j->targets;
+                wc->batch_T = j->n_targets;
+                if (j->next_targets) {                                    /* the next batch runs while this one's files are made */
+                    if (ibdg_set_option(j->eng, "async", 1) ||
+                        ibdg_run(j->eng, j->next_targets, j->n_next, j->bg_count, j->pu_id, j->ld) ||
+                        ibdg_set_option(j->eng, "async", 0))
+                        return NULL;
+                    wc->ahead_of = j->next_targets;
+                }
+            }
+        }
+    }
     j->n_win = ibdg_num_windows(j->eng);
     j->w_first = malloc((j->n_win + 1) * 4);
     j->w_last = malloc((j->n_win + 1) * 4);
@@ -1542,6 +1581,11 @@ static void *shard_run(void *arg)
                 wc->valid = 1;
             }
         }
+    }
+    if (wc->batch_of == j->targets && j->t_local < wc->batch_T) {
+        memcpy(j->win_ll, wc->batch_ll + j->t_local * j->n_win * 3, j->n_win * 24);
+        j->failed = 0;
+        return NULL;                             /* (window tables only: want_sites is off on this path) */
     }
     if (wc->stage_cap < (j->n_win + 1) * 24) {
         if (wc->stage)
@@ -2475,6 +2519,10 @@ int main(int argc, char **argv)
                     j->t_local = ti - b0;
                     j->do_upload = ti == 0;
                     j->do_run = ti == b0;
+                    if (b0 + TARGET_BATCH < targets.n && opt_summary_only) {
+                        j->next_targets = targets.idx + b0 + TARGET_BATCH;
+                        j->n_next = targets.n - (b0 + TARGET_BATCH) < TARGET_BATCH ? targets.n - (b0 + TARGET_BATCH) : TARGET_BATCH;
+                    }
                 } else {
                     j->targets = &targets.idx[ti];
                     j->n_targets = 1;

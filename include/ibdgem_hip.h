@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout, ibdg_last_count_unit; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
@@ -170,6 +170,10 @@ int ibdg_get_site_af(ibdg_ctx *ctx, double *af);
 int ibdg_get_site_ll(ibdg_ctx *ctx, size_t t, double *out);
 /* LIBD0, LIBD1, LIBD2 per window of target t: out[n_windows][3] (summary columns 4-6). */
 int ibdg_get_window_ll(ibdg_ctx *ctx, size_t t, double *out);
+/* The same for every target of the last ibdg_run in one copy: out[n_targets][n_windows][3] (a caller that runs batches of
+ * comparison individuals takes a batch's tables off the device at once and can queue the next batch before it goes
+ * through them: the host program's --summary-only loop, reference src/ibdgem.c:522 with :751-756). */
+int ibdg_get_window_ll_all(ibdg_ctx *ctx, double *out);
 /* Alt-allele count of panel rows [first_row, first_row+n): out[n] (for tests). */
 int ibdg_get_alt_counts(ibdg_ctx *ctx, size_t first_row, size_t n, uint32_t *out);
 

@@ -845,6 +845,9 @@ def test_queued_runs_leave_the_finalising_step_to_the_next_launch(oracle):
             eng.run([3, 5, 9], ld=True)
             for i in range(3):
                 assert_bits(eng.window_ll(i), want["c"][i], f"three single individuals per run, {i}")
+            every = eng.window_ll_all(3)                                 # ibdg_get_window_ll_all: the same tables in one copy
+            for i in range(3):
+                assert_bits(every[i], want["c"][i], f"all tables at once, {i}")
             eng.run([3], ld=True, bg_count=bg, pu_id=3)
             eng.run([3], ld=True, bg_count=bg, pu_id=3)
             eng.run([3], ld=True)                                        # other background counts
