@@ -540,34 +540,6 @@ __device__ __forceinline__ void lds_read_pow10_b64(uint2 (&p)[10], const uint32_
                  : "memory");
 }
 
-// the same in two round trips (6 + 4 entries): 16 registers fewer at the window end, which the matrix-core form needs to
-// stay at eight waves per SIMD
-__device__ __forceinline__ void lds_read_pow6(uint4 (&p)[10], const uint32_t (&ad)[10])
-{
-    asm volatile("ds_read_b128 %0, %6\n\t"
-                 "ds_read_b128 %1, %7\n\t"
-                 "ds_read_b128 %2, %8\n\t"
-                 "ds_read_b128 %3, %9\n\t"
-                 "ds_read_b128 %4, %10\n\t"
-                 "ds_read_b128 %5, %11\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5])
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5])
-                 : "memory");
-}
-
-__device__ __forceinline__ void lds_read_pow4(uint4 (&p)[10], const uint32_t (&ad)[10])
-{
-    asm volatile("ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %5\n\t"
-                 "ds_read_b128 %2, %6\n\t"
-                 "ds_read_b128 %3, %7\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p[6]), "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
-                 : "v"(ad[6]), "v"(ad[7]), "v"(ad[8]), "v"(ad[9])
-                 : "memory");
-}
-
 // The counting itself is written in assembly, one statement per group of (mask, count) pairs, for the sake of ONE
 // scalar instruction inside every pair:
 //     v_and_b32 t, x, m ; s_nop 0 ; v_bcnt_u32_b32 c, t, c
@@ -990,15 +962,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             ad[4] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[5] = mad24r(G01, m32, lshl_add<4>(C1, kc0));   // A0, h1
             ad[6] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[7] = mad24r(G10, m32, lshl_add<4>(C0, kc1));   // A1, h0
             ad[8] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[9] = mad24r(G11, m32, lshl_add<4>(C1, kc1));   // A1, h1
-            uint4 pw[10];
-            double P2, Q00, Q01;
-            if (TAB_LDS && MX) {
-                lds_read_pow6(pw, ad);
-                P2 = ld_value(eK, pw[0], pw[1]);
-                Q00 = ld_value(eK, pw[2], pw[3]);
-                Q01 = ld_value(eK, pw[4], pw[5]);
-                lds_read_pow4(pw, ad);
-            } else if (TAB_LDS) {
+            uint4 pw[10];                           // (not the matrix-core form with its tables in LDS: that one has left above)
+            if (TAB_LDS) {
                 lds_read_pow10(pw, ad);
             } else {
 #pragma unroll
@@ -1007,11 +972,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     pw[2 * i + 1] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(pow_eps) + ad[2 * i + 1]);
                 }
             }
-            if (!(TAB_LDS && MX)) {
-                P2 = ld_value(eK, pw[0], pw[1]);
-                Q00 = ld_value(eK, pw[2], pw[3]);
-                Q01 = ld_value(eK, pw[4], pw[5]);
-            }
+            const double P2 = ld_value(eK, pw[0], pw[1]);
+            const double Q00 = ld_value(eK, pw[2], pw[3]);
+            const double Q01 = ld_value(eK, pw[4], pw[5]);
             const double Q10 = ld_value(eK, pw[6], pw[7]);
             const double Q11 = ld_value(eK, pw[8], pw[9]);
             double s0 = wgt * P2;                                   // :743
