@@ -31,6 +31,13 @@
 // reference's running product.  The host enables this kernel only when the P(D|G) table is
 // the unclamped binomial form (no DBL_MIN clamp, exact coefficients); otherwise the strict
 // multiplying kernel in ibdg_kernels.hip is used.
+//
+// Round 4: for ONE comparison individual per workgroup the four sums of a haplotype word that a lane needs --
+// <x,cov> <x,alt> <x & t0,cov> <x & t1,cov> -- come from one v_mfma_scale_f32_16x16x128_f8f6f4 with a block-diagonal FP6
+// weight matrix and the word's bits as FP4 numbers (k_win_target_mx, lds_fetch_mx, IBDG_SEGMENT_MX; template parameter MX
+// of k_ld_popcount); only <x0 & x1,cov> is still three (mask, count) pairs.  The sums are the same
+// integers, the results the same bits.  The pairs described above remain the form of option mx_counts 0 and of the kernel
+// for groups of four comparison individuals (k_ld_popcount_mt).
 #include "ibdg_kernels.h"
 #include "ibdg_ld_dev.h"
 
