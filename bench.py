@@ -370,8 +370,8 @@ def sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, target, m
     """The reference's real inputs are thin pileups (low-coverage ancient DNA): a panel row without a pileup line
     never reaches the window loop (src/ibdgem.c:596-601), and every row that does costs the same (:669-722).
     Engine clock -- site arrays resident in HBM -> window tables in host memory: ibdg_upload_sites_dev (site
-    preparation AND the gather + transposition of the compacted tiles inside) + ibdg_run + ibdg_get_window_ll of
-    every comparison individual -- with a pileup on 10 % and on 2 % of this rank's panel rows, one comparison
+    preparation AND the gather + transposition of the compacted tiles inside) + ibdg_run + ibdg_get_window_ll_all (every
+    comparison individual's window table in one copy) -- with a pileup on 10 % and on 2 % of this rank's panel rows, one comparison
     individual and many; beside it the same with the compacted tiles forbidden (option compact_tiles -1: what
     round 3 did with such a pileup -- the strict fp64 kernel), and the largest relative difference between the two
     window tables."""
@@ -401,8 +401,7 @@ def sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, target, m
                 def once():
                     eng.upload_sites_dev(d_idx.data_ptr(), d_nr.data_ptr(), d_na.data_ptr(), k, window)
                     eng.run(tg, ld=True)
-                    for i in range(T):
-                        eng.window_ll(i, out=pin.array[i])
+                    eng.window_ll_all(T, out=pin.array)       # every individual's window table in one copy (ibdg_get_window_ll_all)
                 for _ in range(3):
                     once()
                 ms = []
@@ -430,8 +429,8 @@ def sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, target, m
         out[f"pileup_on_{int(share * 100)}pct_of_rows"] = leg
         del d_idx, d_nr, d_na
     eng.set_option("compact_tiles", 0)
-    out["note"] = ("engine clock (host wall, best of 10 after 3 untimed; upload_sites_dev + run + every window table to page-locked "
-                   "memory, option async), the re-layout inside it; ld_variant 2 = exponent counting / matrix cores, 1 = strict fp64 "
+    out["note"] = ("engine clock (host wall, best of 10 after 3 untimed; upload_sites_dev + run + all window tables to page-locked "
+                   "memory in one copy, option async), the re-layout inside it; ld_variant 2 = exponent counting / matrix cores, 1 = strict fp64 "
                    "products; ld_layout 2 = compacted window-aligned tiles of the site list, 1 = the panel's own tiles")
     return out
 
