@@ -8,6 +8,10 @@ import bench
 rows = 4_000_000
 dev = torch.device("cuda", 0)
 panel, n_ref, n_alt = bench.build_shard(torch, dev, 0, rows, 2504, 7, 20241008)
+if os.environ.get("THIN"):                      # reads on one row in THIN only (a thin pileup: the reference's real inputs)
+    keep = np.random.default_rng(5).random(rows) < 1.0 / float(os.environ["THIN"])
+    n_ref = np.where(keep, n_ref, 0).astype(n_ref.dtype)
+    n_alt = np.where(keep, n_alt, 0).astype(n_alt.dtype)
 words = panel.cpu().numpy().view(np.uint64)
 del panel
 torch.cuda.empty_cache()
