@@ -606,10 +606,27 @@ def end_to_end_clocks(words_all, n_ref, n_alt, n_ids, target, window, cold_rows,
                                     # from the program's own phase clocks: engine + output files of the 30, the site list being
                                     # built once.  (The difference of two wall clocks, which this field was until round 3, mostly
                                     # measures whether the two runs met the driver's 0.2 s at process end and 0.13 s at device start.)
-                                    "s_per_further_individual": (ph_many.get("per individual: engine (upload, run, results)", 0.0) +
-                                                                 ph_many.get("per individual: output files", 0.0)) / 30,
+                                    "s_per_further_individual": sum(v for k, v in ph_many.items()
+                                                                    if k.startswith("per individual: engine") or k.startswith("per individual: output")
+                                                                    or k.startswith("per individual: waiting") or k.startswith("output files of the last")) / 30,
                                     "wall_clock_difference_per_individual_s": (t_many - t_sum) / 29,
                                     "phases_s": ph_many}
+        # ... and with 600 of them (a quarter of the whole-panel job the reference's loop is for, src/ibdgem.c:522: one pileup
+        # against every individual of the panel; batches of 30, the next batch queued on the device while the host writes
+        # this one's summary files, twelve files at a time)
+        n_600 = min(600, n_ids)
+        names600 = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(n_600))
+        qbase = [a if a != f"ind{target}" else names600 for a in base]
+        os.makedirs(os.path.join(d, "o7"))
+        t_600 = timed_run(qbase + ["-O", "o7", "--summary-only"], d, repeat=2)
+        ph_600 = run_phases(qbase + ["-O", "o7", "--summary-only"], d)
+        n_files = len([f for f in os.listdir(os.path.join(d, "o7")) if f.endswith(".summary.txt")])
+        warm["six_hundred_individuals"] = {"individuals": n_600, "summary_only_s": t_600, "summary_files_written": n_files,
+                                           "s_per_individual_from_phases": sum(v for k, v in ph_600.items()
+                                                                               if k.startswith("per individual") or k.startswith("output files of the last")) / n_600,
+                                           "phases_s": ph_600}
+        for fn in os.listdir(os.path.join(d, "o7")):
+            os.remove(os.path.join(d, "o7", fn))
         # eight individuals WITH their per-site tables (the default run): 8 x 330 MB of text.  The files of up to four
         # individuals are written beside the main thread's work on the ones after them; IBDGEM_OUT_SLOTS=1 is one at a time.
         eight = ",".join(f"ind{(target + 5 * i) % n_ids}" for i in range(8))

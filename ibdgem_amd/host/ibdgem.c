@@ -1388,6 +1388,7 @@ static int write_rows_parallel(FILE *tab, fmt_job proto, size_t n, int threads)
 typedef struct {
     size_t a, b;                         /* windows [a, b) */
     const uint32_t *s_row, *w_first, *w_last, *w_ncov;
+    const unsigned long *pos_first, *pos_last;   /* the windows' first and last positions, or NULL (looked up row by row) */
     const double *win_ll;
     char *buf;
     size_t len;
@@ -1399,8 +1400,8 @@ static void *fmt_summary(void *arg)
     char *q = j->buf;
     for (size_t w = j->a; w < j->b; ++w) {
         q = put_u64(q, w + 1); *q++ = '\t';
-        q = put_u64(q, rows[j->s_row[j->w_first[w]]].pos); *q++ = '\t';
-        q = put_u64(q, rows[j->s_row[j->w_last[w]]].pos); *q++ = '\t';
+        q = put_u64(q, j->pos_first ? j->pos_first[w] : rows[j->s_row[j->w_first[w]]].pos); *q++ = '\t';
+        q = put_u64(q, j->pos_last ? j->pos_last[w] : rows[j->s_row[j->w_last[w]]].pos); *q++ = '\t';
         q += fmt_ll(q, j->win_ll[3 * w], '\t');
         q += fmt_ll(q, j->win_ll[3 * w + 1], '\t');
         q += fmt_ll(q, j->win_ll[3 * w + 2], '\t');
@@ -1974,6 +1975,7 @@ typedef struct {
     pthread_t th;
     int running, failed;
     int pending;                                /* the files are open and still hold whatever an earlier run left in them */
+    const unsigned long *pos_first, *pos_last;  /* shared: the windows' first / last positions of the common site list, or NULL */
     char *sum_buf;                              /* the slot's buffer for the text of a summary file (kept between individuals) */
     size_t sum_cap;
 } out_job;
@@ -2053,6 +2055,7 @@ static void *output_individual(void *arg)
         sum_job sj;
         memset(&sj, 0, sizeof sj);
         sj.s_row = o->s_row; sj.w_first = o->w_first; sj.w_last = o->w_last; sj.w_ncov = o->w_ncov; sj.win_ll = o->win_ll;
+        sj.pos_first = o->pos_first; sj.pos_last = o->pos_last;
         if (write_summary_parallel(sum, sj, o->n_win, o->threads, &o->sum_buf, &o->sum_cap)) {
             fprintf(stderr, "[::] ERROR writing the summary rows of %s.\n", o->tname);
             return NULL;
@@ -2571,8 +2574,24 @@ int main(int argc, char **argv)
             }
         }
 
+        /* the positions a summary row names (:751-756) are the same for every individual over a common site list: looked up
+         * once -- row by row they are two dependent loads into 160 MB of row records per window and individual */
+        static unsigned long *sum_pos_first, *sum_pos_last;
+        static size_t sum_pos_n;
+        if (overlap && !no_engine && (ti == 0 || sum_pos_n != n_win)) {
+            free(sum_pos_first); free(sum_pos_last);
+            sum_pos_first = malloc((n_win + 1) * sizeof *sum_pos_first);
+            sum_pos_last = malloc((n_win + 1) * sizeof *sum_pos_last);
+            sum_pos_n = n_win;
+            for (size_t w = 0; w < n_win && sum_pos_first && sum_pos_last; ++w) {
+                sum_pos_first[w] = rows[s_row[w_first[w]]].pos;
+                sum_pos_last[w] = rows[s_row[w_last[w]]].pos;
+            }
+        }
         phase("per individual: engine (upload, run, results)");
         out_job *o = &outs[overlap ? ti % (size_t)out_slots : 0];
+        o->pos_first = overlap && !no_engine && sum_pos_first && sum_pos_last ? sum_pos_first : NULL;
+        o->pos_last = o->pos_first ? sum_pos_last : NULL;
         o->out_dir = out_dir; o->user_cmd = user_cmd; o->in_dist = in_dist; o->mean_cov = mean_cov; o->cull_p = cull_p;
         o->cand = cand; o->s_cand = s_cand; o->s_row = s_row; o->s_nr = s_nr; o->s_na = s_na; o->pu = pu;
         o->tname = tname; o->tgt = tgt; o->n = n; o->n_win = n_win;
