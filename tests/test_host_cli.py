@@ -449,6 +449,29 @@ def test_cli_summary_only_writes_the_same_summary_files_and_no_tab_files(tmp_pat
 
 
 @pytest.mark.gpu
+def test_cli_summary_only_over_all_individuals_of_the_panel(tmp_path):
+    """The whole-panel job (one pileup against every individual, src/ibdgem.c:522) with --summary-only: batches of 30, the
+    next batch queued on the device while this one's summary files are written, twelve files at a time -- every summary
+    file equals the one of a run that writes tables too (no look-ahead, four files at a time), and the two the reference
+    was run for are its own, byte for byte."""
+    meta = G.cases("synA")
+    cwd = os.path.join(G.GOLD, "synA", "input")
+    a, b = tmp_path / "summaries", tmp_path / "tables"
+    a.mkdir()
+    b.mkdir()
+    _run_full(meta["base_args"] + ["--LD", "--summary-only"], cwd, a)          # no -s: every individual of the panel
+    _run_full(meta["base_args"] + ["--LD"], cwd, b)
+    want = sorted(f for f in os.listdir(b) if f.endswith(".summary.txt"))
+    assert len(want) > 60 and sorted(os.listdir(a)) == want
+    for fn in want:
+        assert _read(str(a / fn)) == _read(str(b / fn)), fn
+    ref = os.path.join(G.GOLD, "synA", "ld_default", "ref7")
+    for fn in sorted(os.listdir(ref)):
+        if ".summary." in fn:
+            assert _read(str(a / fn[:-3])) == _read(os.path.join(ref, fn)), fn
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["ld_default", "ld_bg_dup", "ld_bg_self_nan", "ld_pu_in_panel"])
 def test_cli_reference_order_mode(case, tmp_path):
     """--reference-order: the background sums are taken serially in the reference's order (list order of
