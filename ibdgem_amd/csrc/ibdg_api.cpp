@@ -99,6 +99,7 @@ struct ibdg_ctx {
     size_t tab_fail_from = (size_t)-1;  // first exponent whose power leaves the 32-bit exponent field
     hipEvent_t ev_up[3] = {};           // before the host-to-device copies, after them, after the last prep kernel
     hipEvent_t ev_prep2 = nullptr;      // stream2: the per-window constants of an upload are there
+    hipEvent_t ev_prepA = nullptr;      // main stream: the site records of an upload are there (behind k_prep_site_scatter)
     // The finalising step of the last run of single individuals (k_ld_finalize's work) when it has been left to the NEXT
     // run's k_ld_popcount launch (option "finalize_in_next"): whoever reads results or replaces inputs first makes up for
     // it with a launch of its own (flush_finalize).  The partial sums alternate between the two halves of their buffer.
@@ -769,7 +770,8 @@ int build_segments(ibdg_ctx *c, bool compact)
         HIP_TRY(c, hipMemcpyAsync(c->runs.p, c->runs_h.data(), c->runs_h.size() * 4, hipMemcpyHostToDevice, c->stream));
         if (first_try) {
             // the run structure goes ahead of the segment kernels, whose last one makes the control words for it
-            // (stream2 is idle: ibdg_upload_sites drained both streams before it began; stage A has been waited for)
+            // (stream2 is idle: ibdg_upload_sites drained both streams before it began; it waits for stage A's records)
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_prepA, 0));
             ibdg::launch_prep_segments(sa, (const uint32_t *)c->runs.p, c->n_runs, NS, c->stream, c->stream2);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipEventRecord(c->ev_prep2, c->stream2));
@@ -955,6 +957,7 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
     for (hipEvent_t &ev : c->ev_up)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_prep2, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_prepA, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // (coherent: the kernels' stores must reach the host while the stream is still busy, not at its next drain)
     if ((e = hipHostMalloc((void **)&c->info_h, sizeof(ibdg::PrepInfo), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
         return bail("hipHostMalloc", e);
@@ -1002,6 +1005,8 @@ void ibdg_destroy(ibdg_ctx *c)
             (void)hipEventDestroy(ev);
     if (c->ev_prep2)
         (void)hipEventDestroy(c->ev_prep2);
+    if (c->ev_prepA)
+        (void)hipEventDestroy(c->ev_prepA);
     for (int b = 0; b < 2 * ibdg_ctx::STAGE_WORKERS; ++b) {
         if (c->stage_ev[b])
             (void)hipEventDestroy(c->stage_ev[b]);
@@ -1129,6 +1134,9 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
         pa.seq = ++c->prep_seq;
         ibdg::launch_prep_sites(pa, c->stream);
         HIP_TRY(c, hipGetLastError());
+        // (the hand-over comes from the scan, BEFORE the scatter kernel: whatever reads the site records on the second
+        // stream waits for this event; the main stream is ordered anyway)
+        HIP_TRY(c, hipEventRecord(c->ev_prepA, c->stream));
         if (wait_info(c, c->prep_seq))
             return 1;
         c->prep_dirty = false;                  // the stage's last workgroup has left everything clean

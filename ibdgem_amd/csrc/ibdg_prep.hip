@@ -143,6 +143,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_count(SiteIn in, uin
             atomicMin(&info->err_cov_site, (uint32_t)s);
         if (in.row_index && in.row_index[s] >= in.n_rows)
             atomicMin(&info->err_row_site, (uint32_t)s);
+        // the panel rows the sites span (in file order: what the covered rows span at most) -- here, not in the scatter
+        // kernel, so that the host has everything it waits for when the scan behind this kernel is done
+        if (s == 0)
+            info->first_row = in.row_index ? in.row_index[s] : (uint32_t)s;
+        if (s + 1 == in.n_sites)
+            info->last_row = in.row_index ? in.row_index[s] : (uint32_t)s;
         return r + a >= 1;
     });
     if (threadIdx.x == 0)
@@ -150,8 +156,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_count(SiteIn in, uin
 }
 
 // One block: exclusive scan of cnt[0..n) in place, the grand total to *total.
+// stage A (info and mirror given): the host's copy of PrepInfo is written here, by the thread that knows the total --
+// everything the host waits for after stage A (the covered rows' number, the first offending site, the rows spanned) is
+// known once the counting kernel and this scan are done, so it is told now and decides the layout, builds the run table
+// and queues stage B while the scatter kernel still runs (a hand-over kernel of its own behind the scatter kernel cost
+// its launch and the host's turn-around on top: 25 us of an upload of 0.16 ms).
 __global__ __launch_bounds__(1024) void k_prep_scan(uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ total,
-                                                   WinConst *__restrict__ behind_last)
+                                                   WinConst *__restrict__ behind_last, PrepInfo *__restrict__ info,
+                                                   PrepInfo *__restrict__ mirror, uint32_t seq)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
@@ -184,6 +196,20 @@ __global__ __launch_bounds__(1024) void k_prep_scan(uint32_t *__restrict__ cnt, 
             behind_last->eK = 0;
             behind_last->cov_total = behind_last->alt_total = 0;
             behind_last->seg_begin = carry_s;
+        }
+        if (mirror) {                  // the hand-over of stage A (what k_prep_mirror does for stage B)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(info);
+            volatile uint32_t *dst = reinterpret_cast<volatile uint32_t *>(mirror);
+            constexpr int N = (int)(offsetof(PrepInfo, seq) / 4);
+            for (int i = 0; i < N; ++i)
+                dst[i] = i == 0 ? carry_s : src[i];           // (word 0 = n_cov = *total, written a moment ago)
+            __threadfence_system();
+            mirror->seq = seq;
+            __threadfence_system();
+            info->err_row_site = info->err_cov_site = 0xffffffffu;
+            info->first_row = 0xffffffffu;
+            info->last_row = 0;
+            info->out_of_order = info->n_segs = info->ct_max = info->max_seg = info->adv_overflow = 0;
         }
     }
 }
@@ -235,11 +261,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, c
             rc.x = in.row_index ? in.row_index[s] : (uint32_t)s;
             rc.y = r + a <= in.max_cov ? (r * d + a) * 24u : 0u;
             out.rec_all[s] = rc;
-            // the panel rows the sites span (in file order: what the covered rows span at most)
-            if (s == 0)
-                info->first_row = rc.x;
-            if (s + 1 == in.n_sites)
-                info->last_row = rc.x;
             return r + a >= 1;
         },
         [&](size_t s, uint32_t j) {
@@ -596,9 +617,9 @@ void launch_prep_sites(const PrepSiteArgs &a, hipStream_t st)
     out.cov_site = a.cov_site;
     const unsigned nb = blocks_for(a.n_sites);
     hipLaunchKernelGGL(k_prep_site_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
-    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_cov, (WinConst *)nullptr);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_cov, (WinConst *)nullptr, a.info,
+                       a.mirror, a.seq);
     hipLaunchKernelGGL(k_prep_site_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, out, a.info);
-    hipLaunchKernelGGL(k_prep_mirror, dim3(1), dim3(64), 0, st, a.info, a.mirror, a.seq, 0);
 }
 
 void launch_prep_segments(const PrepSegArgs &a, const uint32_t *run_begin, uint32_t n_runs, uint32_t ring, hipStream_t st,
@@ -624,7 +645,8 @@ void launch_prep_segments(const PrepSegArgs &a, const uint32_t *run_begin, uint3
             hipLaunchKernelGGL(k_prep_win_const<false>, grid, block, 0, st2, in, a.n_win, a.nck, a.wconst, a.raw, a.info);
     }
     hipLaunchKernelGGL(k_prep_seg_count, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.info);
-    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs, a.wconst + a.n_win);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, st, a.block_tmp, nb, &a.info->n_segs, a.wconst + a.n_win,
+                       (PrepInfo *)nullptr, (PrepInfo *)nullptr, 0u);
     hipLaunchKernelGGL(k_prep_seg_scatter, dim3(nb), dim3(PREP_THREADS), 0, st, in, a.block_tmp, a.seg_first, a.seg_cap,
                        a.wconst);
     if (a.seg_cap)
