@@ -72,5 +72,7 @@ def test_gpus_2_self_launched_on_one_device():
     assert many["wall_ms_max_over_ranks"] == max(p["wall_ms"] for p in many["per_rank"])
     assert one["many_comparison_individuals"]["comparison_individuals"] == 20
     # both ranks share ONE device here, so the two-rank value says nothing about scaling; it must still be a
-    # sane rate of the same code path (between a third of and 1.5x the one-rank value)
-    assert one["value"] / 3 < two["value"] < one["value"] * 1.5
+    # sane rate of the same code path.  (The lower bound is loose on purpose: 20 steps are under 2 ms of device work per
+    # rank, and two PROCESSES on one device take turns in slices of milliseconds -- one run in a dozen came out at a
+    # fifth of the one-rank value.)
+    assert one["value"] / 30 < two["value"] < one["value"] * 1.5
