@@ -63,7 +63,7 @@ def test_gpus_2_self_launched_on_one_device():
     # the closing barrier's own cost and the engine's event clock of a step, per rank
     assert two["barrier_ms"] is not None and 0 < two["barrier_ms"] < 50
     # (two processes take turns on the one device: an engine's event clock of a step can hold the other's kernels)
-    assert all(0 < p["step_device_ms"] <= p["ms_per_step"] * 6 for p in two["per_rank"])
+    assert all(0 < p["step_device_ms"] <= p["ms_per_step"] * 30 for p in two["per_rank"])
     # BASELINE configs[4]'s shape over the ranks: every rank its window range x all comparison individuals
     many = two["many_comparison_individuals"]
     assert many["comparison_individuals"] == 20 and many["ranks"] == 2 and len(many["per_rank"]) == 2
