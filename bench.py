@@ -770,8 +770,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
-    if world > 1:
+    # BENCH_DIST_ONE_RANK=1 (rehearsal only): a single rank goes through every torch.distributed call of the N-rank run
+    # all the same -- process group over RCCL, barriers, reductions, the gather -- since a one-GPU box cannot hold two
+    # RCCL ranks; the workload and its legs stay those of N = 1
+    use_dist = world > 1 or os.environ.get("BENCH_DIST_ONE_RANK") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -843,7 +850,7 @@ def main():
     targets = [args.target]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         eng.sync()
@@ -889,7 +896,7 @@ def main():
     # what the closing barrier itself costs (it is inside the timed region above, after this rank's own steps): the same
     # barrier again with nothing to wait for, best of 5
     barrier_ms = None
-    if world > 1:
+    if use_dist:
         b_all = []
         for _ in range(5):
             tb = time.perf_counter()
@@ -910,7 +917,7 @@ def main():
                               "ld_layout": layout_timed, "relayout": relayout,
                               "note": "--timed-only: this rank's clock, no other legs"}))
         eng.close()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -1125,7 +1132,7 @@ def main():
 
     tot = torch.tensor([dt, float(n_cov), float(n_rows)], dtype=torch.float64,
                        device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone()
@@ -1141,7 +1148,7 @@ def main():
             "upload_sites_ms": up["pageable_ms"], "engine_clock_ms": engine_clock["ms"],
             "host_queue_ms_per_step": dt_host / args.steps * 1e3}
     per_rank = [mine]
-    if world > 1:
+    if use_dist:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
@@ -1211,7 +1218,7 @@ def main():
             "results_to_host": d2h,
             "per_rank": per_rank,
             "barrier_ms": barrier_ms,
-            "barrier_note": None if world == 1 else "the closing barrier of the timed region (dist.barrier + device sync) with "
+            "barrier_note": None if not use_dist else "the closing barrier of the timed region (dist.barrier + device sync) with "
                             "nothing left to wait for, best of 5: what it adds to `steps` x ms_per_step",
             "value_with_recount": n_cov / dt_recount if world == 1 else None,
             "many_comparison_individuals": many,
@@ -1262,7 +1269,7 @@ def main():
                 out["warm_e2e_vs_reference_end_to_end"] = (n_cov / warm["summary_only_s"]) / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

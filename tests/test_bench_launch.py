@@ -76,3 +76,31 @@ def test_gpus_2_self_launched_on_one_device():
     # rank, and two PROCESSES on one device take turns in slices of milliseconds -- one run in a dozen came out at a
     # fifth of the one-rank value.)
     assert one["value"] / 30 < two["value"] < one["value"] * 1.5
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl():
+    """A one-GPU box cannot hold two RCCL ranks, so the N-rank run's torch.distributed calls (process group over RCCL
+    with device_id, barriers inside and after the timed region, the MAX / SUM reductions of a float64 device tensor,
+    the per-rank gather, the orderly destroy) are rehearsed by ONE rank: BENCH_DIST_ONE_RANK=1, also under the
+    driver's launcher (torch.distributed.run with one process), whose environment the rank must accept."""
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--sites", "500000", "--no-cpu-baseline", "--no-e2e", "--no-many"]
+    bench_py = os.path.join(REPO, "bench.py")
+    plain = subprocess.run([sys.executable, bench_py] + common, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ref = json.loads(plain.stdout.strip().splitlines()[-1])
+    assert ref["barrier_ms"] is None
+    launchers = ([sys.executable, bench_py],
+                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                  "--master-addr", "127.0.0.1", "--master-port", "29617", bench_py])
+    for exe in launchers:
+        r = subprocess.run(exe + common, env=_clean_env(BENCH_DIST_ONE_RANK="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        one = json.loads(lines[0])
+        assert one["n_gpus"] == 1 and len(one["per_rank"]) == 1 and one["per_rank"][0]["rank"] == 0
+        assert one["barrier_ms"] is not None and 0 < one["barrier_ms"] < 50
+        assert one["config"]["windowed_sites"] == ref["config"]["windowed_sites"]
+        # the collectives sit at the edges of the timed region: the rate stays that of the plain run
+        assert ref["value"] / 2 < one["value"] < ref["value"] * 2
