@@ -1526,12 +1526,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const bool shift8 = (double)(c->ct_max + 1) * std::max(std::fabs(log2_rho + 8.0), std::fabs(log2_sigma)) <= 1000.0;
         const long rho_shift = shift8 ? 8 : std::lround(-log2_rho);
         const double per_read = std::max(std::fabs(log2_rho + (double)rho_shift), std::fabs(log2_sigma));
-        // (a window's reads < 2^21: the accumulators hold 2^23 + twice a sum + the window's constant as exact floats)
-        const int mx_counts = c->opt_mx_counts && rho_shift >= 0 && rho_shift <= 40 && c->ct_max < (1u << 21) &&
+        const int mx_counts = c->opt_mx_counts && rho_shift >= 0 && rho_shift <= 40 &&
                               (!c->tab_in_lds || (double)(c->ct_max + 1) * per_read <= 1000.0) &&
                               ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
         const size_t part_bytes = T * (size_t)c->n_win * c->n_chunks * 16;       // the counting kernels' sums per chunk; two halves taken in turn
-        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * ibdg::ld_popcount_wc_bytes(mx_counts)) ||
+        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||

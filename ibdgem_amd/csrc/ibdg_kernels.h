@@ -186,8 +186,7 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
 void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
                                uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
-size_t ld_popcount_rec_bytes(int mx_counts);     // bytes of one segment record in rec_ready
-size_t ld_popcount_wc_bytes(int mx_counts);      // ... and of one window's constants in wc_ready
+size_t ld_popcount_rec_bytes(int mx_counts);      // bytes of one segment record in rec_ready
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
                              int ring_slots, int multi_target);

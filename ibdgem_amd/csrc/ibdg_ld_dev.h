@@ -115,17 +115,6 @@ __device__ __forceinline__ void lds_read2(uint4 &w0, uint4 &w1, uint32_t addr0, 
                  : "memory");
 }
 
-// the same for two neighbours: one address register, the second read 16 bytes on
-__device__ __forceinline__ void lds_read2_next16(uint4 &w0, uint4 &w1, uint32_t addr)
-{
-    asm volatile("ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %2 offset:16\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w0), "=&v"(w1)
-                 : "v"(addr)
-                 : "memory");
-}
-
 // eight power-table entries (16 B each) in one round trip (ds_read_b96 of the 12 bytes that matter was
 // tried: 8-16 % slower in all three kernels)
 __device__ __forceinline__ void lds_read_pow8(uint4 (&p)[8], const uint32_t (&ad)[8])

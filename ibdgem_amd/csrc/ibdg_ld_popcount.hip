@@ -67,12 +67,6 @@
 //   flags cov0 cov1 cov2 | t0 t1 - - | four A fragments of 24 bytes: the rows' weights in FP6 for the sums
 //   <x,cov> <x,alt> <x & t0,cov> <x & t1,cov>  (k_win_target_mx; flags bit 12 there: planes beyond cov 0-2 / alt 0-2)
 #define IBDG_RECX_WORDS 32
-// ... and of a window's constants for that form (12 words): the eight above -- table offsets of 8-byte entries where the
-// tables are in LDS, and with the accumulators' float bias taken off in advance (see the window end) -- and the four
-// values the window's accumulators START from: 2^23 + the weights of the window's rows 3 mod 4 (k_win_target_mx)
-#define IBDG_WCX_WORDS 12
-// what an accumulator of that form reads as an integer when its sum is 0: the bits of 2^23 as a float
-#define IBDG_MX_BIAS 0x4B000000u
 
 namespace ibdg {
 
@@ -272,24 +266,13 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
 // words and weights).  Only the 16 lanes with l % 16 / 4 == l / 16 hold a non-zero A fragment: lanes 20 kb + sum read
 // the 24 bytes of `sum` from the segment's record, the others keep zeros.
 // Element k = 8 d + j of a lane's 32  <->  row r = 4 j + d of the tile.
-//
-// Later in round 4 the shift of dword 3 went too, and the float -> integer conversions at the window's end with it:
-//     dword 3 = (x & 0x88888888) | 0x11111111   nibble 1001 = -0.5 (bit set), 0001 = +0.5 (bit clear)
-// one v_and_or_b32.  With -w/2 in A and the block scale 4 (w, w/2, w/4 in the other dwords: every product now 2 w) a
-// row of dword 3 contributes 2 w b - w, i.e. twice its term less a constant that depends on the rows' weights alone:
-// k_win_target_mx adds the constants up per window and sum, and the window's FIRST matrix instruction takes
-//     C = 2^23 + (the window's constant)
-// instead of 0.  So an accumulator ends as the float 2^23 + 2 n, whose BITS are the integer IBDG_MX_BIAS + 2 n (every
-// partial sum is an integer in [2^23, 2^24): exact): the window end uses the registers as integers as they are -- the
-// 24-bit multiply-adds see 2 n, the bias of the shift-adds is taken off the window's constants in advance.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fp6_weight_code(uint32_t w, int d)
 {
-    // e2m3 (bias 1, exponent 0 = subnormal m/8) of w (d = 0), w/2 (d = 1), w/4 (d = 2), -w/2 (d = 3), w = 0..7, as bytes
-    // of two words
-    const uint32_t lo = (d & 1) ? 0x0c080400u : d == 2 ? 0x06040200u : 0x14100800u;
-    const uint32_t hi = (d & 1) ? 0x16141210u : d == 2 ? 0x0e0c0a08u : 0x1e1c1a18u;
-    return (((w & 4 ? hi : lo) >> (8 * (w & 3))) & 0xffu) | (d == 3 ? 0x20u : 0u);
+    // e2m3 (bias 1, exponent 0 = subnormal m/8) of w (d = 0, 3), w/2 (d = 1), w/4 (d = 2), w = 0..7, as bytes of two words
+    const uint32_t lo = d == 1 ? 0x0c080400u : d == 2 ? 0x06040200u : 0x14100800u;
+    const uint32_t hi = d == 1 ? 0x16141210u : d == 2 ? 0x0e0c0a08u : 0x1e1c1a18u;
+    return ((w & 4 ? hi : lo) >> (8 * (w & 3))) & 0xffu;
 }
 
 __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__restrict__ rec_ready,
@@ -340,7 +323,6 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
     if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w (as k_win_target)
         const uint32_t w = i >> 3;
         uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
-        uint32_t k3[4] = {0, 0, 0, 0};        // the weights (planes 0-2) of the window's rows 3 mod 4, per sum
         const uint32_t s1 = a.wconst[w + 1].seg_begin;
         for (uint32_t s = a.wconst[w].seg_begin + (i & 7); s < s1; s += 8) {
             const Seg &S = a.segs[s];
@@ -352,14 +334,6 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
                 a0alt += (uint32_t)__popc(at.x & S.alt[k]) << k;
                 a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
             }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t cv = S.cov[k] & 0x88888888u;
-                k3[0] += (uint32_t)__popc(cv) << k;
-                k3[1] += (uint32_t)__popc(S.alt[k] & 0x88888888u) << k;
-                k3[2] += (uint32_t)__popc(cv & at.x) << k;
-                k3[3] += (uint32_t)__popc(cv & at.y) << k;
-            }
         }
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) {
@@ -367,37 +341,27 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
             a1cov += __shfl_xor(a1cov, m);
             a0alt += __shfl_xor(a0alt, m);
             a1alt += __shfl_xor(a1alt, m);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                k3[q] += __shfl_xor(k3[q], m);
         }
         if ((i & 7) == 0) {
             const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);
-            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WCX_WORDS);
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WC_WORDS);
             const uint32_t AT = wcs[4];
-            // byte offsets into tables of 8-byte entries (the matrix-core form's power tables, see its window end; 16-byte
-            // entries where the tables stay in global memory).  The window end adds (accumulator bits) << (es - 1) to words
-            // 2, 3, 4, 5 once and to word 6 twice: that many biases are taken off here (modulo 2^32, like the additions)
-            const uint32_t es = a.tab_in_lds ? 3 : 4, bias = IBDG_MX_BIAS << (es - 1);
-            o[0] = make_uint4(wcs[2], AT << es, (a0cov << es) - bias, (a1cov << es) - bias);
-            o[1] = make_uint4(((AT - a0alt) << es) - bias, ((AT - a1alt) << es) - bias, 0u - 2u * bias, 0);
-            o[2] = make_uint4(IBDG_MX_BIAS + k3[0], IBDG_MX_BIAS + k3[1], IBDG_MX_BIAS + k3[2], IBDG_MX_BIAS + k3[3]);
+            // byte offsets into tables of 8-byte entries (the matrix-core form's power tables, see its window end)
+            const uint32_t sc = a.tab_in_lds ? 8 : 16;       // (16-byte entries where the tables stay in global memory)
+            o[0] = make_uint4(wcs[2], sc * AT, sc * a0cov, sc * a1cov);
+            o[1] = make_uint4(sc * (AT - a0alt), sc * (AT - a1alt), 0, 0);
         }
     }
 }
 
-// the bits of a tile word as 32 FP4 numbers (0 or 0.5 / 1 / 2 by dword, -0.5 or +0.5 in the last one, see above);
-// ones = 0x11111111, eights = 0x88888888 in vector registers (an instruction takes one scalar operand, and at half the
-// issue rate of one with vector operands only: tools/ubench/issue_rates.hip)
-__device__ __forceinline__ mx_v8i bits_to_fp4(uint32_t x, uint32_t ones, uint32_t eights)
+// the bits of a tile word as 32 FP4 numbers (0 or 0.5 / 1 / 2 / 0.5 by dword, see above)
+__device__ __forceinline__ mx_v8i bits_to_fp4(uint32_t x)
 {
     mx_v8i b = {0, 0, 0, 0, 0, 0, 0, 0};
-    b[0] = (int)(x & ones);
+    b[0] = (int)(x & 0x11111111u);
     b[1] = (int)(x & 0x22222222u);
     b[2] = (int)(x & 0x44444444u);
-    uint32_t d3;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d3) : "v"(x), "v"(eights), "v"(ones));
-    b[3] = (int)d3;
+    b[3] = (int)((x >> 3) & 0x11111111u);
     return b;
 }
 
@@ -418,24 +382,6 @@ __device__ __forceinline__ void lds_fetch_mx(uint4 &h0, uint2 &x, mx_u4 &a_lo, m
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi)
                  : "v"(rec_addr), "v"(x_addr), "v"(frag_addr), "s"((uint64_t)IBDG_MX_A_LANES)
-                 : "memory");
-}
-
-// ... and for a window's first segment, in the same round trip: the values the accumulators start from (the third
-// 16 bytes of the window's constants)
-__device__ __forceinline__ void lds_fetch_mx_first(uint4 &h0, uint2 &x, mx_u4 &a_lo, mx_u2 &a_hi, mx_v4f &c_init, uint32_t rec_addr,
-                                                   uint32_t x_addr, uint32_t frag_addr, uint32_t wc_addr)
-{
-    asm volatile("ds_read_b128 %0, %5\n\t"
-                 "ds_read_b64 %1, %6\n\t"
-                 "ds_read_b128 %4, %8 offset:32\n\t"
-                 "s_mov_b64 exec, %9\n\t"
-                 "ds_read2_b64 %2, %7 offset1:1\n\t"
-                 "ds_read_b64 %3, %7 offset:16\n\t"
-                 "s_mov_b64 exec, -1\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi), "=&v"(c_init)
-                 : "v"(rec_addr), "v"(x_addr), "v"(frag_addr), "v"(wc_addr), "s"((uint64_t)IBDG_MX_A_LANES)
                  : "memory");
 }
 
@@ -493,18 +439,12 @@ __device__ __forceinline__ double wave_sum2_dpp(double a, double b, uint32_t scr
 
 // Staging of the window constants: the table base each word indexes is added on the way into LDS
 // (i = index of the uint4 within the run's constants, two per window).
-template <bool MX>
 __device__ __forceinline__ uint4 stage_wc_base(uint4 v, uint32_t i, uint32_t tab1, uint32_t tab2)
 {
-    if (MX) {                                  // (three per window there; the third one holds no table offsets)
-        i %= 3;
-        if (i == 2)
-            return v;
-    }
     if (i & 1) {
         v.x += tab1;
         v.y += tab1;
-        v.z += tab2;
+        v.z = tab2;
     } else {
         v.y += tab1;
         v.z += tab2;
@@ -740,17 +680,13 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
     }
 
 // The same with the counts of the two haplotype words on the matrix cores (acc0 / acc1: <x,cov> <x,alt> <x&t0,cov>
-// <x&t1,cov> of x0 / x1, as the floats 2^23 + twice the sum; a window's first segment starts them from the window's
-// constants) and the three planes of <x0&x1,cov> as (mask, count) pairs.
+// <x&t1,cov> of x0 / x1 as exact integers in f32; a window's first segment starts them from zero) and the three
+// planes of <x0&x1,cov> as (mask, count) pairs.
 #define IBDG_SEGMENT_MX(FIRST)                                                                                     \
     {                                                                                                           \
         uint4 h0;                                                                                               \
         uint2 x;                                                                                                \
-        mx_v4f c_init;                                                                                          \
-        if (FIRST)                                                                                              \
-            lds_fetch_mx_first(h0, x, af_lo, af_hi, c_init, rec_addr, ring_lane + x_off, frag_addr, wc_addr);   \
-        else                                                                                                    \
-            lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                          \
+        lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                              \
         flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
         const uint32_t adv = flags >> 16;                                                                       \
         if (adv) {                                                                                              \
@@ -765,11 +701,11 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
         const uint32_t hom = x.x & x.y;                                                                         \
         {                                                                                                       \
             const mx_v8i av = {(int)af_lo.x, (int)af_lo.y, (int)af_lo.z, (int)af_lo.w, (int)af_hi.x, (int)af_hi.y, 0, 0}; \
-            /* scales: A 2^2 (byte 0 of the operand: 0x81), B 1 (byte 1: 0x7f) */                                 \
-            acc0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.x, ones, eights), FIRST ? c_init : acc0, 2, 4, \
-                                                                    0, 0x7f81, 1, 0x7f81);                      \
-            acc1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.y, ones, eights), FIRST ? c_init : acc1, 2, 4, \
-                                                                    0, 0x7f81, 1, 0x7f81);                      \
+            const mx_v4f zero = {0.f, 0.f, 0.f, 0.f};                                                           \
+            acc0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.x), FIRST ? zero : acc0, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
+            acc1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.y), FIRST ? zero : acc1, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
         }                                                                                                       \
         if (FIRST) {                                                                                            \
             ch[0] = __popc(hom & h0.y); ch[1] = __popc(hom & h0.z); ch[2] = __popc(hom & h0.w);                 \
@@ -777,26 +713,24 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
             ch[0] += __popc(hom & h0.y); ch[1] += __popc(hom & h0.z); ch[2] += __popc(hom & h0.w);              \
         }                                                                                                       \
         if (flags & (1u << 14)) {                                                                               \
-            /* planes beyond the three inside the instruction: (mask, count) pairs, TWICE their weight like everything  \
-               in the accumulators */                                                                           \
             const uint4 h1 = lds_read_b128(rec_addr + 16);                                                      \
             const uint2 at = make_uint2(h1.x, h1.y);                                                            \
             const uint32_t nn = __builtin_amdgcn_readfirstlane(h1.z), ncov = nn & 0xff, nalt = nn >> 8;         \
             for (uint32_t k = 3; k < ncov; ++k) {                                                               \
                 const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
                 const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
-                acc0[0] += (float)((uint32_t)__popc(u0) << (k + 1));                                            \
-                acc1[0] += (float)((uint32_t)__popc(u1) << (k + 1));                                            \
+                acc0[0] += (float)((uint32_t)__popc(u0) << k);                                                  \
+                acc1[0] += (float)((uint32_t)__popc(u1) << k);                                                  \
                 ch[0] += (uint32_t)__popc(hom & cov) << k;                                                      \
-                acc0[2] += (float)((uint32_t)__popc(u0 & at.x) << (k + 1));                                     \
-                acc1[2] += (float)((uint32_t)__popc(u1 & at.x) << (k + 1));                                     \
-                acc0[3] += (float)((uint32_t)__popc(u0 & at.y) << (k + 1));                                     \
-                acc1[3] += (float)((uint32_t)__popc(u1 & at.y) << (k + 1));                                     \
+                acc0[2] += (float)((uint32_t)__popc(u0 & at.x) << k);                                           \
+                acc1[2] += (float)((uint32_t)__popc(u1 & at.x) << k);                                           \
+                acc0[3] += (float)((uint32_t)__popc(u0 & at.y) << k);                                           \
+                acc1[3] += (float)((uint32_t)__popc(u1 & at.y) << k);                                           \
             }                                                                                                   \
             for (uint32_t k = 3; k < nalt; ++k) {                                                               \
                 const uint32_t alt = segs[seg0 + s].alt[k];                                                     \
-                acc0[1] += (float)((uint32_t)__popc(x.x & alt) << (k + 1));                                     \
-                acc1[1] += (float)((uint32_t)__popc(x.y & alt) << (k + 1));                                     \
+                acc0[1] += (float)((uint32_t)__popc(x.x & alt) << k);                                           \
+                acc1[1] += (float)((uint32_t)__popc(x.y & alt) << k);                                           \
             }                                                                                                   \
         }                                                                                                       \
         rec_addr += IBDG_RECX_WORDS * 4;                                                                        \
@@ -861,15 +795,15 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         return;
 
     // ---- LDS carve-up (see ld_popcount_lds_bytes)
-    constexpr uint32_t RECW = MX ? IBDG_RECX_WORDS : IBDG_REC_WORDS, WCW = MX ? IBDG_WCX_WORDS : IBDG_WC_WORDS;
+    constexpr uint32_t RECW = MX ? IBDG_RECX_WORDS : IBDG_REC_WORDS;
     uint32_t *rec_lds = reinterpret_cast<uint32_t *>(smem);                       // [max_seg][RECW]
-    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * RECW;                         // [win_per_group][WCW]
+    uint32_t *wc_lds = rec_lds + (size_t)a.max_seg * RECW;                         // [win_per_group][8]
     uint4 *tab_lds = reinterpret_cast<uint4 *>(
-        smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * WCW) * 4 + 15) & ~(size_t)15));
+        smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15) & ~(size_t)15));
     // (matrix-core form with the tables in LDS: plain doubles, 8 bytes per entry -- see the window end)
     constexpr bool PLAIN = MX && TAB_LDS;
     const size_t tab_bytes = TAB_LDS ? (size_t)a.tab_len * (PLAIN ? 16 : 32) : 0;
-    char *ring0 = smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * WCW) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
+    char *ring0 = smem + ((((size_t)a.max_seg * RECW + (size_t)a.win_per_group * IBDG_WC_WORDS) * 4 + 15 + tab_bytes + 1023) & ~(size_t)1023);
 
     // ---- prime the ring FIRST: pairs q0 .. q0+NS-1 (not past the run's last pair).  The
     // direct-to-LDS loads fly while the workgroup stages its records and tables below, so the
@@ -901,10 +835,10 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         // they stay byte offsets into the global tables
         const uint32_t stab1 = TAB_LDS ? (uint32_t)(uintptr_t)(lds_void *)tab_lds : 0u;
         const uint32_t stab2 = TAB_LDS ? stab1 + a.tab_len * (PLAIN ? 8 : 16) : 0u;
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (WCW / 4);
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wc_ready) + ((size_t)t * a.n_win + w0) * (IBDG_WC_WORDS / 4);
         uint4 *wdst = reinterpret_cast<uint4 *>(wc_lds);
-        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (WCW / 4); i += blockDim.x)
-            wdst[i] = stage_wc_base<MX>(wsrc[i], i, stab1, stab2);
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * (IBDG_WC_WORDS / 4); i += blockDim.x)
+            wdst[i] = stage_wc_base(wsrc[i], i, stab1, stab2);
         if (PLAIN) {
             // rho^n * 2^(s n) and sigma^n as plain doubles: the mantissas of the {mantissa, exponent} tables, exactly (a power
             // of two moves no bit); s = a.rho_shift keeps rho^n inside the double range for every n of the table
@@ -953,15 +887,11 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const uint32_t wc_base = (uint32_t)(uintptr_t)(lds_void *)wc_lds;
     uint32_t s = 0;
     // (matrix-core form) the two accumulators, the lane's A fragment -- zero except in the lanes 20 kb + sum, which read
-    // the 24 bytes of `sum` behind the record's header --, the address of the current window's constants and the
-    // nibble pattern of the operand's last dword, both in vector registers
+    // the 24 bytes of `sum` behind the record's header
     mx_v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     mx_u4 af_lo = {0, 0, 0, 0};
     mx_u2 af_hi = {0, 0};
     uint32_t frag_addr = rec_addr + 32 + 24 * (lane & 3);
-    uint32_t wc_addr = wc_base;
-    uint32_t ones = 0x11111111u, eights = 0x88888888u;
-    asm volatile("" : "+v"(wc_addr), "+v"(ones), "+v"(eights));
     for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
         if constexpr (MX) {
@@ -976,42 +906,34 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         {
         {
             uint4 k0, k1;                           // the window's constants, broadcast into VGPRs
-            if constexpr (MX) {
-                lds_read2_next16(k0, k1, wc_addr);
-                wc_addr += IBDG_WCX_WORDS * 4;
-            } else {
-                lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
-            }
+            lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
             const int eK = (int)k0.x;
             // table addresses of 16*AT, 16*<t0,cov>, 16*<t1,cov>, 16*(AT-<t0,alt>), 16*(AT-<t1,alt>), 0
             const uint32_t kAT = k0.y, kc0 = k0.z, kc1 = k0.w, kb0 = k1.x, kb1 = k1.y, ktab2 = k1.z;
+            uint32_t C0, C1, G00, G01, G10, G11, a0, a1;
             const uint32_t CH = planes_sum<FC>(ch);
-            // ad[2i] / ad[2i+1]: where rho^E2 / sigma^E3 of product i sit (table base + entry size * exponent), with
+            if constexpr (MX) {
+                C0 = (uint32_t)acc0[0]; a0 = (uint32_t)acc0[1]; G00 = (uint32_t)acc0[2]; G10 = (uint32_t)acc0[3];
+                C1 = (uint32_t)acc1[0]; a1 = (uint32_t)acc1[1]; G01 = (uint32_t)acc1[2]; G11 = (uint32_t)acc1[3];
+            } else {
+                C0 = planes_sum<FC>(c0); C1 = planes_sum<FC>(c1);
+                G00 = planes_sum<FC>(g00); G01 = planes_sum<FC>(g01);
+                G10 = planes_sum<FC>(g10); G11 = planes_sum<FC>(g11);
+                a0 = planes_sum<FA>(A0); a1 = planes_sum<FA>(A1);
+            }
+            // ad[2i] / ad[2i+1]: where rho^E2 / sigma^E3 of product i sit (table base + 16 * exponent), with
             //   pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH          E2 = AT - a0 - a1 + CH
             //   pDg[At+hx] (:716-719):     E3 = <t,cov> + Cx - 2 G(x,t)  E2 = AT - <t,alt> - ax + G(x,t)
             uint32_t ad[10];
-            if constexpr (MX) {
-                // The accumulators as they are: the float 2^23 + 2 n is the integer IBDG_MX_BIAS + 2 n.  As the 24-bit factor of
-                // a multiply-add that is 2 n (the bias has no bit below the 24th); shifted and added it brings bias << SH
-                // along, which k_win_target_mx took off kc*, kb* (once) and ktab2 (twice).  ES: log2 of the tables' entry size.
-                constexpr int ES = PLAIN ? 3 : 4, SH = ES - 1;
-                const uint32_t C0 = __float_as_uint(acc0[0]), a0 = __float_as_uint(acc0[1]), G00 = __float_as_uint(acc0[2]),
-                               G10 = __float_as_uint(acc0[3]);
-                const uint32_t C1 = __float_as_uint(acc1[0]), a1 = __float_as_uint(acc1[1]), G01 = __float_as_uint(acc1[2]),
-                               G11 = __float_as_uint(acc1[3]);
-                ad[0] = mad24<-(1 << SH)>(a0 + a1, lshl_add<ES>(CH, kAT));
-                if constexpr (PLAIN)
-                    ad[1] = lshl_add<SH>(C0 + C1, mad24<-16>(CH, ktab2));
-                else
-                    ad[1] = lshl_add<SH>(C0 + C1, mad24r(CH, m32, ktab2));
-                ad[2] = lshl_add<SH>(G00, mad24<-(1 << SH)>(a0, kb0));   ad[3] = mad24<-(2 << SH)>(G00, lshl_add<SH>(C0, kc0));
-                ad[4] = lshl_add<SH>(G01, mad24<-(1 << SH)>(a1, kb0));   ad[5] = mad24<-(2 << SH)>(G01, lshl_add<SH>(C1, kc0));
-                ad[6] = lshl_add<SH>(G10, mad24<-(1 << SH)>(a0, kb1));   ad[7] = mad24<-(2 << SH)>(G10, lshl_add<SH>(C0, kc1));
-                ad[8] = lshl_add<SH>(G11, mad24<-(1 << SH)>(a1, kb1));   ad[9] = mad24<-(2 << SH)>(G11, lshl_add<SH>(C1, kc1));
-            }
             if constexpr (PLAIN) {
                 // 8-byte entries; rho^E2 sits in its table as rho^E2 * 2^(s E2): the product's exponent is made up for it from
                 // the table address itself, eK - s E2 = (8 eK + s tab1 - s ad) >> 3
+                ad[0] = lshl_add<3>(CH - (a0 + a1), kAT);
+                ad[1] = lshl_add<3>(mad24<-2>(CH, C0 + C1), ktab2);
+                ad[2] = lshl_add<3>(G00, mad24<-8>(a0, kb0));   ad[3] = mad24<-16>(G00, lshl_add<3>(C0, kc0));
+                ad[4] = lshl_add<3>(G01, mad24<-8>(a1, kb0));   ad[5] = mad24<-16>(G01, lshl_add<3>(C1, kc0));
+                ad[6] = lshl_add<3>(G10, mad24<-8>(a0, kb1));   ad[7] = mad24<-16>(G10, lshl_add<3>(C0, kc1));
+                ad[8] = lshl_add<3>(G11, mad24<-8>(a1, kb1));   ad[9] = mad24<-16>(G11, lshl_add<3>(C1, kc1));
                 uint2 pq[10];
                 lds_read_pow10_b64(pq, ad);
                 const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
@@ -1041,18 +963,12 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
                 continue;
             }
-            if constexpr (!MX) {
-                const uint32_t C0 = planes_sum<FC>(c0), C1 = planes_sum<FC>(c1);
-                const uint32_t G00 = planes_sum<FC>(g00), G01 = planes_sum<FC>(g01);
-                const uint32_t G10 = planes_sum<FC>(g10), G11 = planes_sum<FC>(g11);
-                const uint32_t a0 = planes_sum<FA>(A0), a1 = planes_sum<FA>(A1);
-                ad[0] = lshl_add<4>(CH - (a0 + a1), kAT);
-                ad[1] = lshl_add<4>(mad24<-2>(CH, C0 + C1), ktab2);
-                ad[2] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[3] = mad24r(G00, m32, lshl_add<4>(C0, kc0));   // A0, h0
-                ad[4] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[5] = mad24r(G01, m32, lshl_add<4>(C1, kc0));   // A0, h1
-                ad[6] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[7] = mad24r(G10, m32, lshl_add<4>(C0, kc1));   // A1, h0
-                ad[8] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[9] = mad24r(G11, m32, lshl_add<4>(C1, kc1));   // A1, h1
-            }
+            ad[0] = lshl_add<4>(CH - (a0 + a1), kAT);
+            ad[1] = lshl_add<4>(mad24<-2>(CH, C0 + C1), ktab2);
+            ad[2] = lshl_add<4>(G00, mad24<-16>(a0, kb0));   ad[3] = mad24r(G00, m32, lshl_add<4>(C0, kc0));   // A0, h0
+            ad[4] = lshl_add<4>(G01, mad24<-16>(a1, kb0));   ad[5] = mad24r(G01, m32, lshl_add<4>(C1, kc0));   // A0, h1
+            ad[6] = lshl_add<4>(G10, mad24<-16>(a0, kb1));   ad[7] = mad24r(G10, m32, lshl_add<4>(C0, kc1));   // A1, h0
+            ad[8] = lshl_add<4>(G11, mad24<-16>(a1, kb1));   ad[9] = mad24r(G11, m32, lshl_add<4>(C1, kc1));   // A1, h1
             uint4 pw[10];                           // (not the matrix-core form with its tables in LDS: that one has left above)
             if (TAB_LDS) {
                 lds_read_pow10(pw, ad);
@@ -1492,7 +1408,6 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, Ker
 }
 
 size_t ld_popcount_rec_bytes(int mx_counts) { return (mx_counts ? IBDG_RECX_WORDS : IBDG_REC_WORDS) * 4; }
-size_t ld_popcount_wc_bytes(int mx_counts) { return (mx_counts ? IBDG_WCX_WORDS : IBDG_WC_WORDS) * 4; }
 
 // LDS of one workgroup: records + window constants (+ power tables) rounded to 1 KiB, then 8 rings.
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
@@ -1500,7 +1415,7 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
 {
     // multi_target: 0 = one comparison individual (vector-ALU counts), 1 = groups of IBDG_MT, 2 = one, counts on the matrix cores
     const size_t rec_words = multi_target == 1 ? IBDG_RECM_WORDS : multi_target == 2 ? IBDG_RECX_WORDS : IBDG_REC_WORDS;
-    const size_t wc_words = multi_target == 1 ? IBDG_WCM_WORDS : multi_target == 2 ? IBDG_WCX_WORDS : IBDG_WC_WORDS;
+    const size_t wc_words = multi_target == 1 ? IBDG_WCM_WORDS : IBDG_WC_WORDS;
     size_t head = ((size_t)max_seg * rec_words + (size_t)win_per_group * wc_words) * 4 + 15;
     if (tab_in_lds)
         head += (size_t)tab_len * (multi_target == 2 ? 16 : 32);      // (matrix-core form: plain doubles)
