@@ -125,7 +125,6 @@ template <bool FULL>
 __device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_t tgt, size_t base, size_t e, unsigned lane,
                                           double *__restrict__ buf)
 {
-    constexpr int NV = FULL ? 3 : 1;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     uint2 rc[2];
     bool live[2];
@@ -181,7 +180,7 @@ __device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_
         const unsigned g = A0 + A1;
         const double ibd2 = g == 0 ? p00[u] : (g == 1 ? p01[u] : p11[u]);
         const bool covered = rc[u].y != 0;            // table offset 0 <=> no reads
-        double *o = buf + (64 * u + lane) * NV;
+        double *o = buf + (64 * u + lane);            // value v of the row at o[128 v]: a chain's factors are neighbours
         if (FULL) {
             const double omf = 1 - f[u];
             double ibd0 = 1.0;
@@ -210,9 +209,11 @@ __device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_
                     d[2] = ibd2;
                 }
             }
-            o[0] = covered ? ibd0 : 1.0;
-            o[1] = covered ? ibd1 : 1.0;
-            o[2] = covered ? ibd2 : 1.0;
+            if (!a.ld_mode) {                          // (--LD: only the IBD2 products are taken from here, :752)
+                o[0] = covered ? ibd0 : 1.0;
+                o[128] = covered ? ibd1 : 1.0;
+            }
+            o[256] = covered ? ibd2 : 1.0;
         } else {
             o[0] = covered ? ibd2 : 1.0;
         }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 {
     constexpr int NV = FULL ? 3 : 1;                 // values per row kept for the products
     constexpr int WPW = IBDG_ROWS_WPW;
-    __shared__ double strip[4][WPW][128 * NV];
+    __shared__ __attribute__((aligned(16))) double strip[4][WPW][128 * NV];
     // (the wave's number as a scalar: the windows' bounds then come through scalar loads and live in SGPRs)
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
@@ -260,11 +261,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t n = (uint32_t)(span - off < 128 ? span - off : 128);
-            if (lane < NV * WPW) {
-                const double *src = &strip[wave][cq][cc];
-#pragma unroll 8
-                for (uint32_t j = 0; j < n; ++j)
-                    acc *= src[j * NV];
+            if (lane < NV * WPW && (!FULL || !a.ld_mode || cc == 2)) {
+                // two factors per LDS instruction (the pipeline's cost is per instruction): the strip holds a value's
+                // factors side by side, and behind an odd count sits a 1.0 or the next row's factor of a longer window
+                // of the group -- which n, the longest window's count, covers or this lane's rows_turn filled with 1.0
+                const double2 *src = reinterpret_cast<const double2 *>(&strip[wave][cq][cc * 128]);
+#pragma unroll 4
+                for (uint32_t j = 0; j < (n + 1) / 2; ++j) {
+                    const double2 v = src[j];
+                    acc *= v.x;
+                    acc *= v.y;
+                }
             }
         }
         if (lane < NV * WPW && w0 + cq < a.n_win) {
