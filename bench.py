@@ -5,9 +5,9 @@ Workload (BASELINE.json configs[3], the config the metric is quoted on):
   --LD, ~4M SNP rows, 2504-individual phased panel, window 100, 1 comparison
   individual, epsilon 0.02, max-cov 20; Poisson(2) read depth so ~13.5% of the
   rows have no informative read (printed, not windowed -- src/ibdgem.c:657-663).
-A "step" = one full pass over all rows: per-site LIBD0/1/2 (k_site), the --LD
-background loop + window averages (k_win_target, k_ld_popcount, k_ld_finalize)
-and the window products (k_window_prod); inputs resident in HBM (the packed
+A "step" = one full pass over all rows: the --LD background loop + window averages
+(k_target_weights, k_win_target_mx, k_ld_popcount, the finalising step) and, beside them on a
+second stream, per-site LIBD0/1/2 and the window products (k_rows_windows); inputs resident in HBM (the packed
 panel in its two layouts and the per-row alt-allele counts, all produced once
 by the panel upload -- they depend on the panel only, like the reference's -A
 file), results left in HBM.  value = windowed sites processed by all ranks /
@@ -27,7 +27,14 @@ kernels, the copy back), "results_to_host" (per-site results), "warm_e2e" / "col
 program ibdgem_amd/host/ibdgem from files to files), and "cpu_baseline" (the unmodified reference
 binary on a slice of the same data).
 
-One JSON line is printed by rank 0.
+The timed steps take two comparison individuals in turn (a NEW individual per step, as in the reference's loop over
+the individuals of the panel, src/ibdgem.c:522): nothing a step needs is left over from the step before it -- the
+individual's window / segment images (k_win_target_mx), its background weights and the --LD kernel all run in every
+step; a step's finalising arithmetic (k_ld_finalize's, 5 us) rides in the next step's --LD launch and the last step's
+in a launch of its own before the closing barrier.  `--same-target` times the round-4 form (one comparison run again).
+
+Rank 0 prints ONE compact JSON line (<= 4096 bytes: the contract's keys, `roofline`, `cpu_baseline`, per-rank numbers);
+everything else -- the other clocks, notes, the host-program legs -- goes to the file named in its `detail_file`.
 """
 import argparse
 import json
@@ -703,6 +710,91 @@ def traffic_bytes(args, world):
     return best, src
 
 
+# ----------------------------------------------------------------------------- the line the driver reads
+LINE_LIMIT = 4096
+
+
+def _sig(x, n=6):
+    """Numbers of the compact line: n significant digits (the full values are in the detail file)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "clock", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+CONFIG_KEYS = ("workload", "rows", "windowed_sites", "n_ids", "window", "targets", "sharding")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_site", "sites_per_launch", "kernel_ms",
+                 "dominant_kernel_only_ms", "traffic", "traffic_from_profile")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "ld_stage_only_sites_per_s")
+RANK_KEYS = ("rank", "rows", "windowed_sites", "windows", "ms_per_step", "ld_launch_ms", "step_device_ms", "many_device_ms",
+             "many_wall_ms")
+
+
+def compact_line(out, detail_file):
+    """The ONE line rank 0 prints last: the contract's keys, `roofline`, `cpu_baseline`, numbers per rank -- at most
+    LINE_LIMIT bytes whatever the number of ranks (round 4's line had grown to 22 KB and the driver could not parse it)."""
+    line = {k: out.get(k) for k in TOP_KEYS}
+    line["config"] = _pick(out.get("config"), CONFIG_KEYS)
+    line["roofline"] = _pick(out.get("roofline"), ROOFLINE_KEYS)
+    cb = _pick(out.get("cpu_baseline"), CPU_KEYS)
+    if cb and isinstance(cb.get("sample"), str) and len(cb["sample"]) > 300:
+        cb["sample"] = cb["sample"][:297] + "..."
+    line["cpu_baseline"] = cb
+    ranks = []
+    for p in out.get("per_rank") or []:
+        r = _pick(p, RANK_KEYS[:7])
+        m = p.get("many_comparison_individuals") if isinstance(p, dict) else None
+        if m:
+            r["many_device_ms"], r["many_wall_ms"] = m.get("device_ms"), m.get("wall_ms")
+        ranks.append(r)
+    line["per_rank"] = ranks
+    line["barrier_ms"] = out.get("barrier_ms")
+    ec = out.get("engine_clock") or {}
+    line["engine_sites_per_s"] = ec.get("sites_per_s")
+    line["engine_clock_ms"] = ec.get("ms")
+    line["new_individual_per_step"] = out.get("new_individual_per_step")
+    many = out.get("many_comparison_individuals") or {}
+    line["many_individuals"] = _pick(many, ("comparison_individuals", "ms_per_individual", "site_individual_pairs_per_s")) if many else None
+    for k in ("step_vs_reference_end_to_end", "engine_clock_vs_reference_end_to_end", "ld_kernels_vs_reference_ld_stage"):
+        line[k] = out.get(k)
+    line["detail_file"] = detail_file
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                       # (cannot happen at <= 8 ranks; drop the optional parts rather than the contract's)
+        for k in ("many_individuals", "ld_kernels_vs_reference_ld_stage", "engine_clock_vs_reference_end_to_end",
+                  "step_vs_reference_end_to_end", "engine_clock_ms", "new_individual_per_step"):
+            line.pop(k, None)
+        line["per_rank"] = [_pick(r, ("rank", "windowed_sites", "ms_per_step", "ld_launch_ms")) for r in line["per_rank"]]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, f"the result line is {len(text)} bytes (limit {LINE_LIMIT})"
+    return text
+
+
+def write_detail(out, world):
+    """Everything measured, notes included, as indented JSON under gpurun_out/ (merged back from a GPU box); the path is
+    relative to the repository root."""
+    rel = os.path.join("gpurun_out", "bench_detail.json" if world == 1 else f"bench_detail_{world}gpu.json")
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, rel), "w") as fh:
+            json.dump(out, fh, indent=1)
+            fh.write("\n")
+    except OSError as e:                              # a read-only checkout: the line still goes out
+        rel = f"(not written: {e.strerror})"
+    return rel
+
+
 # ----------------------------------------------------------------------------- main
 def launcher_command(n_ranks, argv):
     """The command `python bench.py --gpus N` runs when nobody launched it under torch.distributed.run: one rank
@@ -743,6 +835,9 @@ def main():
     ap.add_argument("--cpw", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--sync-steps", action="store_true", help="wait for the device after every step")
+    ap.add_argument("--same-target", action="store_true",
+                    help="every step runs the SAME comparison individual again (the timed steps of round 4: the individual's images "
+                         "are then reused from the step before); default: two individuals in turn, a new one per step")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     args = ap.parse_args()
 
@@ -848,6 +943,15 @@ def main():
     n_segments_compact = (len(cov_rows) // args.window) * ((args.window + 31) // 32) + (len(cov_rows) % args.window + 31) // 32
     del cov_rows, seg_start
     targets = [args.target]
+    # a NEW comparison individual per step (src/ibdgem.c:522 hands every individual of the panel to the same rows in turn):
+    # two panel members take turns, so no step finds its individual's images, weights or background size left by the step
+    # before.  (The reads were drawn from args.target's genotype; the cost of a step does not depend on the values.)
+    turn = [targets] if args.same_target else [targets, [(args.target + 1) % args.ids]]
+    n_run = [0]
+
+    def step():
+        eng.run(turn[n_run[0] % len(turn)], ld=True)
+        n_run[0] += 1
 
     def barrier():
         if use_dist:
@@ -861,13 +965,17 @@ def main():
     # timed steps below are steps of a site list in use, `in_place_tiles` further down is the same step before it.
     relayout = {"after_runs": None, "run_ms": None}
     layout0 = eng.ld_layout()
-    for k in range(40):
+    eng.run(targets, ld=True)
+    eng.sync()
+    # (with the counts on the matrix cores -- the default, last_count_unit 2 -- single runs add nothing towards a re-layout:
+    # they gain nothing from the compacted tiles; only the (mask, count) form, option mx_counts 0, gets there after 16 runs)
+    for k in range(40 if eng.last_count_unit() != 2 else 0):
         if eng.ld_layout() != layout0:
             break
         t_r = time.perf_counter()
         eng.run(targets, ld=True)
         eng.sync()
-        relayout = {"after_runs": k + 1, "run_ms": (time.perf_counter() - t_r) * 1e3}
+        relayout = {"after_runs": k + 2, "run_ms": (time.perf_counter() - t_r) * 1e3}
     if eng.ld_layout() == layout0:
         relayout = {"after_runs": None, "run_ms": None}
     # clock settling (untimed, before the W warm-up steps of the contract): queued steps for --prewarm-ms of wall time
@@ -876,12 +984,12 @@ def main():
     n_prewarm = 0
     while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
         for _ in range(8):
-            eng.run(targets, ld=True)
+            step()
         eng.sync()
         n_prewarm += 8
     eng.set_option("async", 0)
     for _ in range(args.warmup):
-        eng.run(targets, ld=True)
+        step()
     # The timed steps are queued back to back (the engine's "async" option: ibdg_run returns once
     # its kernels are enqueued, like any stream-ordered step loop) and the closing barrier waits
     # for all of them; each step's HIP events are read afterwards (the engine keeps the last 32).
@@ -889,7 +997,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.run(targets, ld=True)
+        step()
     dt_host = time.perf_counter() - t0          # host time to queue the steps (reported only)
     barrier()
     dt = time.perf_counter() - t0
@@ -914,7 +1022,7 @@ def main():
             print(json.dumps({"metric": "SNP-sites/sec in --LD mode, chr1, 2504-indiv panel", "value": n_cov / (dt / args.steps),
                               "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
-                              "ld_layout": layout_timed, "relayout": relayout,
+                              "ld_layout": layout_timed, "new_individual_per_step": len(turn) > 1,
                               "note": "--timed-only: this rank's clock, no other legs"}))
         eng.close()
         if use_dist:
@@ -950,7 +1058,7 @@ def main():
         eng.set_option("dispatch_events", 1)
         eng.set_option("async", 1)
         for _ in range(40):
-            eng.run(targets, ld=True)
+            step()
         eng.sync()
         ms_kernel = [eng.run_kernel_ms(b) for b in range(32)]
     except ibdgem_amd.EngineError:
@@ -1143,6 +1251,7 @@ def main():
 
     mine = {"rank": rank, "rows": int(n_rows), "windowed_sites": int(n_cov), "windows": int(eng.n_windows),
             "ms_per_step": dt / args.steps * 1e3, "ld_launch_ms": float(np.mean(ms_ld)),
+            "ld_launch_ms_min": float(np.min(ms_ld)),       # the fastest of those steps on the device's own clock
             "step_device_ms": float(np.mean([m["total"] for m in ms_all])),      # the engine's own events: both streams of a step
             "many_comparison_individuals": many_rank,
             "upload_sites_ms": up["pageable_ms"], "engine_clock_ms": engine_clock["ms"],
@@ -1157,8 +1266,10 @@ def main():
         value = cov_total / (dt_max / args.steps)
         b_site = algorithmic_bytes_per_site(args.ids, len(targets))
         ld_ms = float(np.mean(ms_ld))
-        # the roofline entry is for the dominant kernel: its own duration (dispatch events) when available
-        dom_ms = float(np.mean(ms_kernel)) if ms_kernel else ld_ms
+        # the roofline entry divides by the --LD launch time OF THE TIMED STEPS (HIP events on the engine's stream, mean over
+        # the last <= 32 of them): everything a step's --LD part launches, the dominant kernel's fused finalising
+        # workgroups included.  The kernel's own dispatch time (32 further steps of the same form) is kept beside it.
+        dom_ms = ld_ms
         achieved = b_site * n_cov / (dom_ms * 1e-3) / 1e9
         kern = {k: float(np.mean([m[k] for m in ms_all])) for k in ms_all[0]}
         out = {
@@ -1187,23 +1298,26 @@ def main():
                                          "of this workload (the file named in traffic_from_profile); counters cannot be read from "
                                          "inside the process",
                          "bytes_per_site": b_site, "sites_per_launch": n_cov, "kernel_ms": dom_ms,
-                         "kernel_ms_note": "achieved = bytes_per_site x sites_per_launch / kernel_ms; kernel_ms = "
-                                           "dominant_kernel_only_ms when the kernel could be timed alone, else launch_ms",
+                         "kernel_ms_note": "achieved = bytes_per_site x sites_per_launch / kernel_ms; kernel_ms = launch_ms",
                          "launch_ms": ld_ms,
-                         "launch_ms_note": "HIP events on the engine's stream around the --LD launches "
-                                           "(k_win_target + k_ld_popcount + k_ld_finalize), mean over the last "
-                                           f"{len(ms_ld)} timed steps",
+                         "launch_ms_note": "HIP events on the engine's stream around the --LD launches of a step "
+                                           "(k_target_weights + k_win_target_mx + k_ld_popcount with the previous step's "
+                                           "finalising workgroups in it; with --same-target k_ld_popcount only), mean over the "
+                                           f"last {len(ms_ld)} timed steps",
                          "dominant_kernel_only_ms": float(np.mean(ms_kernel)) if ms_kernel else None,
-                         "dominant_kernel_only_note": "k_ld_popcount alone, start/stop events of its own dispatch "
-                                                      "packet, 32 extra steps after the timed region",
+                         "dominant_kernel_only_note": "k_ld_popcount alone (the same fused form as in the timed steps), start/stop "
+                                                      "events of its own dispatch packet, 32 extra steps after the timed region: "
+                                                      "what rocprofv3 --kernel-trace --stats of --timed-only shows as its average",
                          "valu": valu_roofline(float(np.mean(ms_kernel)) if ms_kernel else ld_ms, int(eng.n_windows),
                                                (args.ids + 63) // 64) if world == 1 else None},
             "kernel_ms": kern,
             "ld_layout": layout_timed,
+            "new_individual_per_step": len(turn) > 1,
             "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows into compacted, "
                              "window-aligned tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
-                             "untimed; the rule: the runs on one upload add up, an individual of the counting kernels as 16, a "
-                             "group of the matrix-core kernel as 15, against compact_targets = 256 (DESIGN s4.1b)"),
+                             "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 15, an individual "
+                             "of the counting kernels as 16 with mx_counts 0 and not at all with the default mx_counts 1, against "
+                             "compact_targets = 256 (DESIGN s4.1b) -- null: no re-layout happened"),
             "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},
@@ -1267,7 +1381,7 @@ def main():
             out["cold_e2e"] = cold
             if isinstance(warm, dict) and "summary_only_s" in warm and "cpu_baseline" in out:
                 out["warm_e2e_vs_reference_end_to_end"] = (n_cov / warm["summary_only_s"]) / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(compact_line(out, write_detail(out, world)), flush=True)
     eng.close()
     if use_dist:
         dist.barrier()

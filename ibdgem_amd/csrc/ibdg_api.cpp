@@ -42,6 +42,8 @@ struct ibdg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // per-site + window-product kernels run beside the --LD kernels
+    hipStream_t stream3 = nullptr;    // what a NEW comparison individual needs before its --LD kernel (indices, weights, the
+                                      // individual's window / segment images), made under the --LD kernel of the run before
     // Timing events of the last runs (asynchronous runs are timed after the fact).  Every event
     // record is a barrier packet the command processor retires in ~5 us, so the main stream carries
     // one per run (end of the --LD launches) plus a start only when the stream may have been idle.
@@ -143,6 +145,32 @@ struct ibdg_ctx {
     std::vector<uint8_t> prev_bg;
     int prev_pu = -2, prev_has_bg = -1;
     size_t prev_lanes = 0;
+    // New comparison individuals reach the device without a host wait (the reference's loop hands every individual of the panel
+    // to the same rows in turn, src/ibdgem.c:522: a NEW individual per run is the normal case): their indices go through a
+    // small ring of page-locked slots into one of two halves of `targets` (stream2's kernel of the run before may still read
+    // the other), and the weights / background sizes that follow from them are made on the device (k_target_weights) from the
+    // run's background multiplicities `base_w`; `nrefpanel` has two halves as well -- a finalising step left to the next
+    // run reads its own run's half.
+    static constexpr int TG_SLOTS = 4;
+    uint32_t *tg_stage[TG_SLOTS] = {};
+    size_t tg_stage_cap = 0;            // comparison individuals a slot holds
+    hipEvent_t tg_stage_ev[TG_SLOTS] = {};
+    bool tg_stage_busy[TG_SLOTS] = {};
+    int tg_slot = 0;
+    int tg_half = 0;                    // the half of `targets` / `weight` / the images the current comparison individuals sit in
+    hipEvent_t tg_s2[2] = {};           // stream2's last kernel that read that half
+    bool tg_s2_pending[2] = {};
+    hipEvent_t tg_main[2] = {};         // end of the last run on the main stream that read that half
+    bool tg_main_pending[2] = {};
+    hipEvent_t tg_ready = nullptr;      // stream3: the current comparison individuals' data are complete
+    hipEvent_t ev_s3sync = nullptr;     // main stream: the prepared sites stream3's kernels read are complete
+    uint64_t s3_gen = 0;                // sites_gen stream3 has been ordered behind
+    int nref_slot = 0;                  // `nrefpanel` is a ring of four: a finalising step left to the next run reads its own run's
+    static constexpr int NREF_SLOTS = 4;
+    static constexpr size_t AHEAD_MAX_T = 64;   // runs of up to that many individuals prepare ahead (two halves of every buffer)
+    long opt_prep_ahead = 1;
+    int base_sum = 0;                   // sum of base_w
+    int wt_half = -1;                   // the half the images in wtarget / twords were made in
     // the per-target LDS images of k_win_target (segment records with the target's tile words, window constants) depend
     // on the prepared sites and the targets only: a further run over the same sites and targets reuses them
     uint64_t sites_gen = 0;            // bumped by every upload of sites and every change of layout
@@ -192,6 +220,9 @@ struct ibdg_ctx {
     long opt_sum_dpp = 1;            // ... its wave sums by DPP moves (0: ds_swizzle, as the vector-ALU form)
     long opt_mx_counts = 1;          // k_ld_popcount: the counts of a haplotype word by one matrix instruction (0: 12 (mask, count) pairs)
     long opt_reserve_compact = 1;    // their buffer is allocated with the panel's (a panel's worth x 1.3 of HBM more per context)
+    long opt_compact_align = 1;      // rows a window of the compacted tiles is rounded up to: 1 = the rows back to back (no padding; a
+                                     // window straddles tiles like on the panel's own rows), 32 = every window on a tile boundary
+                                     // (round 4's layout: 28 % padding at windows of 100 rows)
     long opt_compact_density = 4;    // compacted when fewer than 1 panel row in this many between the first and last site carries reads
                                      // (tools/density_sweep.py: one comparison at 1 row in 3: 0.82 ms in place, 0.94 compacted; in 4: 0.76 / 0.76; in 5: 0.79 / 0.65)
     long opt_compact_targets = 256;  // ... or when the runs on one upload add up to this many comparison individuals of the
@@ -265,6 +296,7 @@ int quiesce(ibdg_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     if (join_streams(c)) return 1;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream3));     // (idle whenever the main stream is: every batch on it ends in an event the main stream waits for)
     c->chain_ok = false;
     return 0;
 }
@@ -693,26 +725,32 @@ int build_segments(ibdg_ctx *c, bool compact)
     if (!c->pop_lut_ok || c->n_cov == 0)
         return 0;
     const ibdg::PrepInfo &I = *c->info_h;
-    const uint32_t tpw = (c->window + 31) / 32;        // tiles per window of the compacted layout
+    // virtual rows per window of the compacted layout: the window rounded up to the alignment asked for (1 = the rows back
+    // to back, 32 = every window on a tile boundary)
+    const uint32_t align = (uint32_t)std::min<long>(32, std::max<long>(1, c->opt_compact_align));
+    const uint64_t win_rows = ((uint64_t)c->window + align - 1) / align * align;
+    const uint64_t vtiles = ((uint64_t)c->n_win * win_rows + 31) / 32;        // tiles of all its virtual rows
+    if (compact && win_rows >= (1ull << 31))
+        return 0;
     // segments <= windows + tiles spanned when the rows are in file order (otherwise the device stops
     // writing at the capacity and the exponent-counting kernel is not used); never more than stage A cleared
     uint64_t seg_cap = c->n_cov;
     const uint32_t first_row = c->first_row, last_row = c->last_row;
     if (compact)
-        seg_cap = (uint64_t)c->n_win * tpw;
+        seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + vtiles + 1);
     else if (last_row >= first_row)
         seg_cap = std::min<uint64_t>(seg_cap, (uint64_t)c->n_win + ((last_row >> 5) - (first_row >> 5)) + 1);
     seg_cap = std::min<uint64_t>(seg_cap, c->seg_room);
     if (compact) {
         // the rows with reads, gathered and transposed into tiles that start with their window
-        const uint64_t pairs = ((uint64_t)c->n_win * tpw + 1) / 2;
+        const uint64_t pairs = (vtiles + 1) / 2;
         if (pairs >= (1ull << 31))
             return 0;
         c->n_pairs_c = (uint32_t)((pairs + 3) & ~3ull);
         if (ensure(c, c->t32c, (size_t)c->n_chunks * c->n_pairs_c * 64 * 16))
             return 1;
         ibdg::launch_gather_transpose32((const uint64_t *)c->panel.p, c->stride, (const uint2 *)c->rec_cov.p, c->n_cov,
-                                        c->window, c->n_chunks, c->n_pairs_c, (uint32_t *)c->t32c.p, c->stream);
+                                        c->window, (uint32_t)win_rows, c->n_chunks, c->n_pairs_c, (uint32_t *)c->t32c.p, c->stream);
         HIP_TRY(c, hipGetLastError());
     }
     if (ensure(c, c->wconst, ((size_t)c->n_win + 1) * sizeof(ibdg::WinConst)) ||
@@ -747,7 +785,7 @@ int build_segments(ibdg_ctx *c, bool compact)
     sa.block_tmp = (uint32_t *)c->scan_tmp.p;
     sa.info = (ibdg::PrepInfo *)c->info_dev.p;
     sa.mirror = c->info_h;
-    sa.compact = compact ? 1u : 0u;
+    sa.compact = compact ? (uint32_t)win_rows : 0u;
     c->prep_dirty = true;
     // windows per workgroup run: as many as keep the run's records within the LDS budget
     uint32_t g = (uint32_t)std::max<long>(1, c->opt_wpg);
@@ -949,6 +987,11 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
             lo = hi = 0;
         if ((e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)) != hipSuccess)
             return bail("hipStreamCreate", e);
+        if ((e = hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, hi)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->tg_ready, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->ev_s3sync, hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
     }
     for (auto &E : c->evs) {
         for (hipEvent_t *ev : {&E.start_own, &E.ld_end, &E.k_start, &E.k_stop, &E.s2_start, &E.s2[0], &E.s2[1], &E.s2[2], &E.prep})
@@ -990,6 +1033,8 @@ void ibdg_destroy(ibdg_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
+    if (c->stream3)
+        (void)hipStreamSynchronize(c->stream3);
     if (c->stream2)
         (void)hipStreamSynchronize(c->stream2);
     if (c->stream)
@@ -1019,6 +1064,17 @@ void ibdg_destroy(ibdg_ctx *c)
         for (hipEvent_t ev : {E.start_own, E.ld_end, E.k_start, E.k_stop, E.s2_start, E.s2[0], E.s2[1], E.s2[2], E.prep})
             if (ev)
                 (void)hipEventDestroy(ev);
+    for (int i = 0; i < ibdg_ctx::TG_SLOTS; ++i) {
+        if (c->tg_stage[i])
+            (void)hipHostFree(c->tg_stage[i]);
+        if (c->tg_stage_ev[i])
+            (void)hipEventDestroy(c->tg_stage_ev[i]);
+    }
+    for (hipEvent_t ev : {c->tg_ready, c->ev_s3sync})
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->stream3)
+        (void)hipStreamDestroy(c->stream3);
     if (c->stream2)
         (void)hipStreamDestroy(c->stream2);
     if (c->stream)
@@ -1092,10 +1148,10 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     c->win_bounds_valid = false;
     c->have_fo = false;
     // segments of stage B: at most one per site, and in file order at most windows + tiles of the panel
-    // (compacted tiles: ceil(window / 32) per window)
+    // (compacted tiles: windows + tiles of their virtual rows, at most window + 31 per window)
     const size_t n_win_max = (n_sites + window - 1) / window;
     const size_t seg_room = std::min<size_t>(n_sites, std::max<size_t>(n_win_max + (c->n_rows + 31) / 32 + 1,
-                                                                      n_win_max * ((window + 31) / 32)));
+                                                                      n_win_max + (n_win_max * ((size_t)window + 31) + 31) / 32 + 1));
     const bool fresh_info = !c->info_dev.p;
     if (ensure(c, c->rec_all, n_sites * 8) || ensure(c, c->rec_cov, n_sites * 8) || ensure(c, c->cov_site, n_sites * 4) ||
         ensure(c, c->scan_tmp, ibdg::prep_scan_blocks(std::max<size_t>(n_sites, 1)) * 4) ||
@@ -1261,8 +1317,14 @@ int ibdg_upload_sites_dev(ibdg_ctx *c, const void *dev_row_index, const void *de
         HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipEventRecord(c->ev_up[0], c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_up[1], c->stream));
-    return upload_sites_finish(c, upload_sites_core(c, (const uint32_t *)dev_row_index, (const uint8_t *)dev_n_ref,
-                                                    (const uint8_t *)dev_n_alt, f_override, n_sites, window), t0);
+    const int rc = upload_sites_core(c, (const uint32_t *)dev_row_index, (const uint8_t *)dev_n_ref,
+                                     (const uint8_t *)dev_n_alt, f_override, n_sites, window);
+    // the caller may free or reuse its arrays when this returns: the last kernel that reads them (k_prep_site_scatter) must
+    // be done.  Where the layout's second stage was waited for it is (nothing to wait for); a clamped table, an empty
+    // site list or a layout without segments leave that stage out
+    if (rc == 0 && n_sites)
+        HIP_TRY(c, hipEventSynchronize(c->ev_prepA));
+    return upload_sites_finish(c, rc, t0);
 }
 
 int ibdg_upload_ms(ibdg_ctx *c, float out[3])
@@ -1294,6 +1356,7 @@ void ibdg_host_free(void *p)
 
 size_t ibdg_num_sites(const ibdg_ctx *c) { return c ? c->n_sites : 0; }
 size_t ibdg_num_windows(const ibdg_ctx *c) { return c ? c->n_win : 0; }
+size_t ibdg_num_targets(const ibdg_ctx *c) { return c && c->have_results ? c->n_targets : 0; }
 
 int ibdg_get_windows(ibdg_ctx *c, uint32_t *first, uint32_t *last, uint32_t *n_covered)
 {
@@ -1340,61 +1403,117 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // --LD over several comparison individuals: one table of the rows' values for all of them (they differ by the genotype
     // picked), an individual's per-site table is put together when it is fetched (k_row_table / k_site_expand)
     const bool row_table = want_ll && ld_mode && T > 1;
-    if (ensure(c, c->targets, T * 4) || (want_ll && ensure(c, c->site_ll, (row_table ? 1 : T) * c->n_sites * 24)) ||
+    if (ensure(c, c->targets, 2 * T * 4) || (want_ll && ensure(c, c->site_ll, (row_table ? 1 : T) * c->n_sites * 24)) ||
         (row_table && ensure(c, c->row_tab, c->n_sites * 32)) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
     // targets / background weights change rarely between calls (a loop over windows sizes, repeated
     // timing steps): their device copies are rebuilt only when the inputs differ
-    const bool same_inputs = c->prev_targets.size() == T && std::equal(targets, targets + T, c->prev_targets.begin()) &&
-                             c->prev_pu == pu_id && c->prev_has_bg == (bg_count ? 1 : 0) && c->prev_lanes == lanes &&
-                             (!bg_count || (c->prev_bg.size() == c->n_ids &&
-                                            std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin()))) &&
-                             (!ld_mode || c->weight.p);
-    // a finalising step left to "the next run" is taken along only by a run over the same individuals, background and
-    // prepared sites (it reads the background counts and the windows' constants): anything else makes up for it first
-    if (c->fin_pending && (!same_inputs || !ld_mode || c->fin_sites_gen != c->sites_gen || !c->opt_fin_next || !c->opt_async) &&
+    const bool same_bg = c->prev_pu == pu_id && c->prev_has_bg == (bg_count ? 1 : 0) && c->prev_lanes == lanes &&
+                         (!bg_count || (c->prev_bg.size() == c->n_ids &&
+                                        std::equal(bg_count, bg_count + c->n_ids, c->prev_bg.begin()))) &&
+                         c->base_w.p;
+    const bool same_inputs = same_bg && c->prev_targets.size() == T && std::equal(targets, targets + T, c->prev_targets.begin()) &&
+                             c->weight.p;
+    // a finalising step left to "the next run" is taken along only by a run of the same shape over the same background and
+    // prepared sites (it reads the windows' constants and its own run's background sizes): anything else makes up for it first
+    if (c->fin_pending && (!same_bg || c->prev_targets.size() != T || !ld_mode || c->fin_sites_gen != c->sites_gen ||
+                           !c->opt_fin_next || !c->opt_async) &&
         flush_finalize(c))
         return 1;
-    if (!same_inputs) {
-        // stream2 may still read the previous targets: the main stream waits for it before overwriting
-        if (join_streams(c)) return 1;
-        HIP_TRY(c, hipMemcpyAsync(c->targets.p, targets, T * 4, hipMemcpyHostToDevice, c->stream));
-        std::vector<double> wt(T * lanes, 0.0);
-        std::vector<int> nref(T, 0);
-        // background multiplicity per individual; the target and the -N sample contribute nothing
-        // (src/ibdgem.c:714, :742-750)
-        for (size_t t = 0; t < T; ++t) {
-            int cnt = 0;
-            for (unsigned n = 0; n < c->n_ids; ++n) {
-                const unsigned k = bg_count ? bg_count[n] : 1u;
-                if ((int)n == pu_id || n == targets[t] || k == 0)
-                    continue;
-                wt[t * lanes + n] = (double)k;
-                cnt += (int)k;
-            }
-            nref[t] = cnt;
-        }
-        // the same without the comparison individual's own exclusion (k_ld_mfma applies that itself)
+    if (!same_bg) {
+        // background multiplicity per individual without any comparison individual's own exclusion; the -N sample
+        // contributes nothing (src/ibdgem.c:714, :742-750).  Rare (once per program run): a host wait is fine here.
         std::vector<double> wb(lanes, 0.0);
+        int sum = 0;
         for (unsigned n = 0; n < c->n_ids; ++n) {
             const unsigned k = bg_count ? bg_count[n] : 1u;
-            if ((int)n != pu_id && k != 0)
+            if ((int)n != pu_id && k != 0) {
                 wb[n] = (double)k;
+                sum += (int)k;
+            }
         }
-        if (ensure(c, c->weight, wt.size() * 8) || ensure(c, c->nrefpanel, T * 4) || ensure(c, c->base_w, lanes * 8))
+        if (ensure(c, c->base_w, lanes * 8))
             return 1;
-        HIP_TRY(c, hipMemcpyAsync(c->weight.p, wt.data(), wt.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->base_w.p, wb.data(), lanes * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->nrefpanel.p, nref.data(), T * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vectors go out of scope
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vector goes out of scope
         c->chain_ok = false;
-        c->prev_targets.assign(targets, targets + T);
+        c->base_sum = sum;
         c->prev_pu = pu_id;
         c->prev_has_bg = bg_count ? 1 : 0;
         c->prev_lanes = lanes;
         if (bg_count)
             c->prev_bg.assign(bg_count, bg_count + c->n_ids);
+        else
+            c->prev_bg.clear();
     }
+    // Runs of a few individuals keep two halves of everything that depends on the individuals, so that the NEXT run's can be
+    // made (on stream3) while this run's kernels still read theirs; larger runs use the buffers whole, on the main stream.
+    const bool ahead_cap = T <= ibdg_ctx::AHEAD_MAX_T;
+    bool need_ready = false;        // stream3 holds this run's preparation: the other streams wait for tg_ready before they read it
+    hipStream_t ps = c->stream;     // where this run's per-individual preparation is queued
+    if (!same_inputs) {
+        if (ensure(c, c->weight, (ahead_cap ? 2 : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 4))
+            return 1;
+        // a page-locked slot for the indices (so that the copy is a queued one), grown when a run brings more of them
+        if (c->tg_stage_cap < T) {
+            if (quiesce(c)) return 1;
+            const size_t cap = std::max<size_t>(64, T);
+            for (int i = 0; i < ibdg_ctx::TG_SLOTS; ++i) {
+                if (c->tg_stage[i])
+                    (void)hipHostFree(c->tg_stage[i]);
+                c->tg_stage[i] = nullptr;
+                HIP_TRY(c, hipHostMalloc((void **)&c->tg_stage[i], cap * 4, hipHostMallocDefault));
+                if (!c->tg_stage_ev[i])
+                    HIP_TRY(c, hipEventCreateWithFlags(&c->tg_stage_ev[i], hipEventDisableTiming));
+                c->tg_stage_busy[i] = false;
+            }
+            c->tg_stage_cap = cap;
+        }
+        const int slot = c->tg_slot;
+        c->tg_slot = (slot + 1) % ibdg_ctx::TG_SLOTS;
+        if (c->tg_stage_busy[slot])
+            HIP_TRY(c, hipEventSynchronize(c->tg_stage_ev[slot]));      // (its copy was queued TG_SLOTS runs ago)
+        std::copy(targets, targets + T, c->tg_stage[slot]);
+        const bool on_s3 = ahead_cap && c->opt_prep_ahead && c->opt_async;
+        const int half = ahead_cap ? (c->tg_half ^ 1) : 0;
+        if (on_s3) {
+            ps = c->stream3;
+            need_ready = true;
+        }
+        // whoever still reads the half this run's data go to: a run two runs back, normally long done
+        for (int h = ahead_cap ? half : 0; h <= (ahead_cap ? half : 1); ++h) {
+            if (c->tg_main_pending[h] && ps != c->stream)
+                HIP_TRY(c, hipStreamWaitEvent(ps, c->tg_main[h], 0));
+            if (c->tg_s2_pending[h])
+                HIP_TRY(c, hipStreamWaitEvent(ps, c->tg_s2[h], 0));
+            c->tg_main_pending[h] = c->tg_s2_pending[h] = false;
+        }
+        c->tg_half = half;
+        c->nref_slot = (c->nref_slot + 1) % ibdg_ctx::NREF_SLOTS;
+        uint32_t *d_tg = (uint32_t *)((char *)c->targets.p + (size_t)half * (c->targets.cap / 2));
+        int *d_nref = (int *)((char *)c->nrefpanel.p + (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
+        double *d_w = (double *)((char *)c->weight.p + (size_t)half * (c->weight.cap / 2 / 8 * 8));
+        HIP_TRY(c, hipMemcpyAsync(d_tg, c->tg_stage[slot], T * 4, hipMemcpyHostToDevice, ps));
+        HIP_TRY(c, hipEventRecord(c->tg_stage_ev[slot], ps));
+        c->tg_stage_busy[slot] = true;
+        ibdg::launch_target_weights((const double *)c->base_w.p, d_tg, (uint32_t)T, (uint32_t)lanes, c->base_sum, d_w, d_nref, ps);
+        c->prev_targets.assign(targets, targets + T);
+        c->wt_gen = 0;             // the images in wtarget / twords are another individual's
+    }
+    const uint32_t *const d_targets = (const uint32_t *)((const char *)c->targets.p + (size_t)c->tg_half * (c->targets.cap / 2));
+    const int *const d_nrefpanel = (const int *)((const char *)c->nrefpanel.p +
+                                                 (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
+    const double *const d_weight = (const double *)((const char *)c->weight.p + (size_t)c->tg_half * (c->weight.cap / 2 / 8 * 8));
+    // the other streams join stream3's preparation (once, before the first thing that reads it)
+    auto settle_ready = [&]() -> int {
+        if (!need_ready)
+            return 0;
+        need_ready = false;
+        HIP_TRY(c, hipEventRecord(c->tg_ready, c->stream3));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tg_ready, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->tg_ready, 0));
+        return 0;
+    };
 
     bool use_pop = false, s2_after_prep = false, side_fast = false;
     if (ld_mode && c->pop_lut_ok && c->pop_sites_ok && !c->compact && c->opt_compact == 0 && c->opt_variant != 1 &&
@@ -1423,6 +1542,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                            "(clamped P(D|G) table, epsilon outside (0,1), max_cov > 50 or rows out of order)");
         use_pop = can && c->opt_variant != 1 && c->opt_variant != 3 && (c->opt_variant == 2 || c->pop_dense_enough);
     }
+    // (a finalising step left to the next run is taken along by the counting kernel only: the strict kernels write the same
+    // win_ll entries themselves, and the stale sums must not land behind them)
+    if (c->fin_pending && !use_pop && flush_finalize(c))
+        return 1;
     c->last_variant = ld_mode ? (use_pop ? 2 : (c->opt_variant == 3 ? 3 : 1)) : 0;
     c->last_count_unit = 0;
     const bool recount = c->opt_count_in_run || !c->counts_valid;
@@ -1469,7 +1592,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     sa.alt_count = (const uint32_t *)c->alt_count.p;
     sa.pow_tab = (const double *)c->pow_tab.p;
     sa.fo = c->have_fo ? (const double *)c->fo.p : nullptr;
-    sa.targets = (const uint32_t *)c->targets.p;
+    sa.targets = d_targets;
     sa.t32 = c->pop_lut_ok ? (const uint4 *)c->t32.p : nullptr;
     sa.n_pairs = c->n_pairs;
     sa.cov_site = (const uint32_t *)c->cov_site.p;
@@ -1530,8 +1653,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                               (!c->tab_in_lds || (double)(c->ct_max + 1) * per_read <= 1000.0) &&
                               ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
         const size_t part_bytes = T * (size_t)c->n_win * c->n_chunks * 16;       // the counting kernels' sums per chunk; two halves taken in turn
-        if (ensure(c, c->wtarget, T_one * (size_t)c->n_win * 32) ||
-            ensure(c, c->twords, T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
+        // (the single individuals' images in two halves like the other per-individual data, see above)
+        const size_t img_halves = ahead_cap ? 2 : 1;
+        const size_t wt_cap0 = c->wtarget.cap, tw_cap0 = c->twords.cap;
+        if (ensure(c, c->wtarget, img_halves * T_one * (size_t)c->n_win * 32) ||
+            ensure(c, c->twords, img_halves * T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T_cnt ? 2 * part_bytes : 0) ||
@@ -1546,7 +1672,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.segs = (const ibdg::Seg *)c->segs.p;
         pa.n_segs = c->n_segs;
         pa.max_seg = c->max_seg;
-        pa.rec_ready = (const uint32_t *)c->twords.p;
+        if (c->wtarget.cap != wt_cap0 || c->twords.cap != tw_cap0)
+            c->wt_gen = 0;                    // new buffers: no images in them
+        pa.rec_ready = (const uint32_t *)((const char *)c->twords.p + (size_t)c->tg_half * (c->twords.cap / 2 / 16 * 16));
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
         pa.win_per_group = c->wpg;
@@ -1554,26 +1682,26 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.n_runs = c->n_runs;
         pa.n_cgroups = (c->n_chunks + 7) / 8;
         pa.waves_per_group = (c->n_chunks + pa.n_cgroups - 1) / pa.n_cgroups;   // 40 chunks: 5 x 8; 9: 5 + 4; 2: 1 x 2
-        pa.wc_ready = (const uint32_t *)c->wtarget.p;
+        pa.wc_ready = (const uint32_t *)((const char *)c->wtarget.p + (size_t)c->tg_half * (c->wtarget.cap / 2 / 16 * 16));
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
         pa.t_base = (uint32_t)T_g;
-        pa.weight = (const double *)c->weight.p;
+        pa.weight = d_weight;
         pa.lanes = (uint32_t)lanes;
         // Queued runs of single individuals (the timed steps of a shard, a caller's loop over the same comparison): this run's
         // finalising step -- one wave per window, 5 us, but a launch of its own with its gap and the event packet behind it:
         // a tenth of a step on an eighth of a chromosome -- is left to the NEXT run's --LD launch, whose first workgroups
         // do it on the way (the kernel boundary between the two launches is all the ordering it needs), and this run's
         // launch does the same for its predecessor.  The partial sums alternate between two halves of their buffer.
-        const bool fin_in_next = c->opt_fin_next && c->opt_async && T_one > 0 && T_one == T_cnt && n_gg == 0 && !dispatch_events;
+        const bool fin_in_next = c->opt_fin_next && c->opt_async && T_one > 0 && T_one == T_cnt && n_gg == 0;
         if (c->fin_pending && (!fin_in_next || c->fin_count != (unsigned)T_cnt || c->fin_args.t_base != (uint32_t)T_g) &&
             flush_finalize(c))
             return 1;
         pa.partial = (double *)((char *)c->partial.p + (fin_in_next ? (size_t)c->part_half * part_bytes : 0));
         if (c->fin_pending) {
             pa.fin_prev = c->fin_args.partial;
-            pa.n_refpanel = (const int *)c->nrefpanel.p;
+            pa.n_refpanel = c->fin_args.n_refpanel;      // (of the run that left it: its half of the buffer)
             pa.win_ll = (double *)c->win_ll.p;
             c->fin_pending = false;
         }
@@ -1591,6 +1719,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             last.stop = E.ld_end;
         }
         if (n_gg) {
+            if (settle_ready()) return 1;
             ibdg::MfmaArgs ma;
             ma.t32 = pa.t32;
             ma.n_pairs = pa.n_pairs;
@@ -1632,7 +1761,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 }
                 if (ibdg::launch_ld_mfma(ma, (unsigned)nb, c->stream, ibdg::KernelEvents()))
                     return fail(c, "[::] ERROR in ibdg_run: the matrix-core --LD kernel could not be launched");
-                ibdg::launch_ld_finalize_g(ma, (unsigned)nb, (const int *)c->nrefpanel.p, (double *)c->win_ll.p, c->stream);
+                ibdg::launch_ld_finalize_g(ma, (unsigned)nb, d_nrefpanel, (double *)c->win_ll.p, c->stream);
             }
         }
         // k_ld_mfma (4 waves per SIMD) leaves wave slots to the second stream: its kernels run in their fast forms
@@ -1640,6 +1769,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // k_ld_popcount_mt alone it makes no difference)
         side_fast = n_gg > 0;
         if (n_grp) {
+            if (settle_ready()) return 1;
             ibdg::PopArgs pm = pa;
             pm.mx_counts = 0;
             pm.rec_ready = (const uint32_t *)c->twords_mt.p;
@@ -1655,9 +1785,23 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             // a caller that runs a comparison again, e.g. timed steps: one launch of ~10 us less per run, which on an
             // eighth of a chromosome is a tenth of the step)
             const bool wt_cached = same_inputs && c->wt_gen == c->sites_gen && c->wt_first == pa.t_base &&
-                                   c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && !dispatch_events;
+                                   c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && c->wt_half == c->tg_half &&
+                                   !dispatch_events;
+            // a new individual's images: on stream3 with its weights (under the --LD kernel of the run before) unless the
+            // launch carries the run's start event (dispatch_events: that belongs on the main stream)
+            const bool wt_ahead = need_ready && !dispatch_events;
+            if (!wt_ahead && settle_ready()) return 1;
+            if (wt_ahead && c->s3_gen != c->sites_gen) {
+                // once per upload / change of layout: stream3's kernel reads the prepared sites (segments, window constants),
+                // whose kernels were queued on the main stream
+                HIP_TRY(c, hipEventRecord(c->ev_s3sync, c->stream));
+                HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_s3sync, 0));
+                c->s3_gen = c->sites_gen;
+            }
             if (!wt_cached)
-                ibdg::launch_win_target(pa, (unsigned)T_one, c->stream, first);
+                ibdg::launch_win_target(pa, (unsigned)T_one, wt_ahead ? c->stream3 : c->stream, first);
+            if (settle_ready()) return 1;
+            c->wt_half = c->tg_half;
             c->wt_gen = c->sites_gen;
             c->wt_first = pa.t_base;
             c->wt_count = (uint32_t)T_one;
@@ -1670,7 +1814,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         fa.wconst = pa.wconst;
         fa.n_win = c->n_win;
         fa.n_chunks = c->n_chunks;
-        fa.n_refpanel = (const int *)c->nrefpanel.p;
+        fa.n_refpanel = d_nrefpanel;
         fa.win_ll = (double *)c->win_ll.p;
         if (T_cnt) {
             fa.partial = pa.partial;
@@ -1682,11 +1826,14 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 c->fin_count = (unsigned)T_cnt;
                 c->fin_sites_gen = c->sites_gen;
                 c->part_half ^= 1;
+                if (dispatch_events)         // (no finalising launch to carry the run's end in its dispatch packet)
+                    HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
             } else {
                 ibdg::launch_ld_finalize(fa, (unsigned)T_cnt, c->stream, last);
             }
         }
     } else if (ld_mode) {
+        if (settle_ready()) return 1;
         ibdg::LdArgs la;
         la.panel = sa.panel;
         la.stride = c->stride;
@@ -1697,8 +1844,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         la.n_groups = c->n_groups;
         la.lut = sa.lut;
         la.targets = sa.targets;
-        la.weight = (const double *)c->weight.p;
-        la.n_refpanel = (const int *)c->nrefpanel.p;
+        la.weight = d_weight;
+        la.n_refpanel = d_nrefpanel;
         la.win_ll = (double *)c->win_ll.p;
         la.t_base = 0;
         la.vals = nullptr;
@@ -1745,6 +1892,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         } else if (ibdg::launch_ld(la, (unsigned)T, c->cpw, (unsigned)c->opt_waves, c->stream))
             return fail(c, "[::] ERROR in ibdg_run: unsupported chunks_per_wave %d", c->cpw);
     }
+    if (settle_ready()) return 1;
     if (rows_on_main) {
         if (join_streams(c)) return 1;           // an earlier run's kernel on stream2 may still write the results
         // alone on the chip: a wave per pair of windows (the default).  A resident grid whose waves walk over several windows -- even
@@ -1787,6 +1935,17 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
         c->last_s2 = E.s2[2];
         c->s2_pending = true;
+        c->tg_s2[c->tg_half] = E.s2[2];
+        c->tg_s2_pending[c->tg_half] = true;
+        if (!ahead_cap) {
+            c->tg_s2[1] = E.s2[2];
+            c->tg_s2_pending[1] = true;
+        }
+    }
+    // (who reads this run's half of the per-individual buffers on the main stream)
+    for (int h = ahead_cap ? c->tg_half : 0; h <= (ahead_cap ? c->tg_half : 1); ++h) {
+        c->tg_main[h] = E.ld_end;
+        c->tg_main_pending[h] = true;
     }
     HIP_TRY(c, hipGetLastError());
     c->ev_head = ev_slot;
@@ -1951,6 +2110,13 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         return 0;
     }
     if (!strcmp(name, "guided_runs")) { c->opt_guided = value; return 0; }
+    if (!strcmp(name, "compact_align")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
+            return fail(c, "[::] ERROR in ibdg_set_option: compact_align must be 1, 2, 4, 8, 16 or 32");
+        c->opt_compact_align = value;
+        return 0;
+    }
+    if (!strcmp(name, "prep_ahead")) { c->opt_prep_ahead = value != 0; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }
     if (!strcmp(name, "dev_inputs_ready")) { c->opt_dev_inputs_ready = value != 0; return 0; }

@@ -181,10 +181,12 @@ void launch_ld_finalize_g(const MfmaArgs &a, unsigned n_groups, const int *n_ref
 
 void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, uint32_t n_chunks,
                         uint32_t n_pairs, uint32_t *t32, hipStream_t st);
-// the compacted, window-aligned tiles of a site list: covered row j -> virtual row (j / window) * 32 * ceil(window / 32)
-// + j % window; n_pairs tile pairs per chunk (whole octs, zero beyond the last window)
+// the compacted tiles of a site list: covered row j -> virtual row (j / window) * win_rows + j % window (win_rows = window:
+// back to back; 32 * ceil(window / 32): every window on a tile boundary); n_pairs tile pairs per chunk (whole octs, zero
+// beyond the last window)
 void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
-                               uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st);
+                               uint32_t window, uint32_t win_rows, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32,
+                               hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_rec_bytes(int mx_counts);      // bytes of one segment record in rec_ready
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
@@ -246,7 +248,8 @@ struct PrepSegArgs {
     uint32_t *block_tmp;        // prep_scan_blocks(n_cov) words
     PrepInfo *info;
     PrepInfo *mirror;
-    uint32_t compact = 0;       // 1: segments of the compacted, window-aligned tiles (k_gather_transpose32)
+    uint32_t compact = 0;       // 0: segments of the panel's own tiles; otherwise of the compacted tiles of the site list
+                                // (k_gather_transpose32) with this many virtual rows per window (>= window)
 };
 
 size_t prep_scan_blocks(size_t n);
@@ -264,6 +267,9 @@ void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint
                            hipStream_t st, bool redo);
 // wconst[w].{mK, eK} = K * pow_1me[reads of w]
 void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st);
+// weight[t][n] = n == targets[t] ? 0 : base_w[n];  n_refpanel[t] = base_sum - base_w[targets[t]]  (src/ibdgem.c:714, :742-750)
+void launch_target_weights(const double *base_w, const uint32_t *targets, uint32_t n_targets, uint32_t lanes, int base_sum,
+                           double *weight, int *n_refpanel, hipStream_t st);
 void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t window, uint32_t n_win, uint32_t *first,
                             uint32_t *last, hipStream_t st);
 

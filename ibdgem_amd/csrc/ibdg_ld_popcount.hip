@@ -67,6 +67,13 @@
 //   flags cov0 cov1 cov2 | t0 t1 - - | four A fragments of 24 bytes: the rows' weights in FP6 for the sums
 //   <x,cov> <x,alt> <x & t0,cov> <x & t1,cov>  (k_win_target_mx; flags bit 12 there: planes beyond cov 0-2 / alt 0-2)
 #define IBDG_RECX_WORDS 32
+// cache policy of the tile stream's direct-to-LDS loads (aux of global_load_lds: 0 default, 2 = nt, non-temporal): every tile
+// pair is read once by one wave, 2.56 GB per launch = ten times the last-level cache.  nt measured 1.5-2 % faster per step
+// on one box, builds alternating (profiles/r05_ab_nt.txt: 0.606 / 0.607 against 0.617 / 0.615 ms with a new individual per
+// step, 0.581 / 0.586 against 0.596 / 0.596 with the same one); -DIBDG_TILE_AUX=0 brings the default policy back.
+#ifndef IBDG_TILE_AUX
+#define IBDG_TILE_AUX 2
+#endif
 
 namespace ibdg {
 
@@ -160,10 +167,13 @@ __global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// The compacted, window-aligned layout of ONE site list (once per ibdg_upload_sites, or on the first run with
-// several comparison individuals): only the rows that carry reads, in the order of the site list, every
-// window starting on a tile boundary --
-//     virtual row v = (j / W) * 32 * TPW + j % W      for covered row j (W = window, TPW = ceil(W / 32) tiles per window)
+// The compacted layout of ONE site list (once per ibdg_upload_sites, or once the runs on it have added up): only the
+// rows that carry reads, in the order of the site list --
+//     virtual row v = (j / W) * R + j % W      for covered row j (W = window, R = virtual rows per window)
+// R = W (the default since round 5): the rows back to back, v = j, no padding -- a window of 100 rows spans 3.1 tiles and
+// is cut into 4.1 segments where the panel's own tiles (13.5 % rows without reads) make it 3.6 tiles / 4.6 segments;
+// R = 32 * TPW, TPW = ceil(W / 32) (round 4, option "compact_align" 32): every window starts on a tile boundary, 4 segments
+// per window of 100 but 28 % of the tile words are padding
 // -- gathered from the site-major panel through the covered-row list and transposed like above, same uint4
 // layout, so the --LD kernels run on it unchanged (their segments are cut from the virtual rows,
 // ibdg_prep.hip).  In the reference the rows a window multiplies are the rows that passed the filter chain
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(512) void k_transpose32(const uint64_t *__restrict_
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_gather_transpose32(const uint64_t *__restrict__ panel, uint32_t stride,
                                                             const uint2 *__restrict__ rec_cov, uint32_t n_cov,
-                                                            uint32_t window, uint32_t win_rows /* 32 * TPW */,
+                                                            uint32_t window, uint32_t win_rows /* R */,
                                                             uint32_t n_chunks, uint32_t n_pairs,
                                                             uint4 *__restrict__ t32)
 {
@@ -373,16 +383,20 @@ __device__ __forceinline__ mx_v8i bits_to_fp4(uint32_t x)
 __device__ __forceinline__ void lds_fetch_mx(uint4 &h0, uint2 &x, mx_u4 &a_lo, mx_u2 &a_hi, uint32_t rec_addr, uint32_t x_addr,
                                              uint32_t frag_addr)
 {
-    asm volatile("ds_read_b128 %0, %4\n\t"
-                 "ds_read_b64 %1, %5\n\t"
-                 "s_mov_b64 exec, %7\n\t"
-                 "ds_read2_b64 %2, %6 offset1:1\n\t"
-                 "ds_read_b64 %3, %6 offset:16\n\t"
-                 "s_mov_b64 exec, -1\n\t"
+    // (EXEC is narrowed to the fragment lanes for two reads and put back to what it WAS: a caller inside a divergent
+    // branch keeps its dead lanes dead)
+    uint64_t exec_was;
+    asm volatile("ds_read_b128 %0, %5\n\t"
+                 "ds_read_b64 %1, %6\n\t"
+                 "s_mov_b64 %4, exec\n\t"
+                 "s_and_b64 exec, %4, %8\n\t"
+                 "ds_read2_b64 %2, %7 offset1:1\n\t"
+                 "ds_read_b64 %3, %7 offset:16\n\t"
+                 "s_mov_b64 exec, %4\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi)
+                 : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi), "=&s"(exec_was)
                  : "v"(rec_addr), "v"(x_addr), "v"(frag_addr), "s"((uint64_t)IBDG_MX_A_LANES)
-                 : "memory");
+                 : "memory", "scc");
 }
 
 // Two wave-wide sums at once through a 1 KiB LDS scratch of the wave: every lane writes its two
@@ -643,7 +657,7 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
             for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
                 if (q_issue <= q_last)                                                                          \
                     __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
-                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX); \
             if (q_issue - 1 <= q_last)                                                                          \
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
             else                                                                                                \
@@ -694,7 +708,7 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
                more -- so the count of loads in flight stays the nominal one and one counted wait serves */     \
             for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
                 __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(q_issue < q_last ? q_issue : q_last) * 64), \
-                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);  \
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX);  \
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                       \
         }                                                                                                       \
         x_off = flags & 0x3fff;                                                                                 \
@@ -820,7 +834,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         for (int i = 0; i < NS; ++i, ++q_issue)
             if (MX || q_issue <= q_last)              // (matrix-core form: always, see its segment)
                 __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(q_issue < q_last ? q_issue : q_last) * 64),
-                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX);
     }
 
     // ---- stage the run's records, window constants and tables (whole workgroup)
@@ -1127,7 +1141,7 @@ __device__ __forceinline__ void lds_fetch_mt(uint4 &h0, uint4 &h1, uint4 &h2, ui
             for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
                 if (q_issue <= q_last)                                                                          \
                     __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),                 \
-                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0); \
+                                                     (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX); \
             if (q_issue - 1 <= q_last)                                                                          \
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                   \
             else                                                                                                \
@@ -1214,7 +1228,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount_mt(const uint4 *__restrict_
         for (int i = 0; i < NS; ++i, ++q_issue)
             if (q_issue <= q_last)
                 __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)q_issue * 64),
-                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, 0);
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX);
     }
     {
         const uint4 *rsrc = reinterpret_cast<const uint4 *>(rec_ready) + ((size_t)g * a.n_segs + seg0) * (IBDG_RECM_WORDS / 4);
@@ -1382,12 +1396,13 @@ void launch_transpose32(const uint64_t *panel, uint32_t stride, size_t n_rows, u
 }
 
 void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uint2 *rec_cov, uint32_t n_cov,
-                               uint32_t window, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32, hipStream_t st)
+                               uint32_t window, uint32_t win_rows, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32,
+                               hipStream_t st)
 {
     if (n_pairs == 0)
         return;
     hipLaunchKernelGGL(k_gather_transpose32, dim3(n_pairs, (n_chunks + 7) / 8), dim3(512), 0, st, panel, stride, rec_cov,
-                       n_cov, window, 32u * ((window + 31) / 32), n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
+                       n_cov, window, win_rows, n_chunks, n_pairs, reinterpret_cast<uint4 *>(t32));
 }
 
 // ev.start / ev.stop (may be null): events the dispatch itself updates with the kernel's start and

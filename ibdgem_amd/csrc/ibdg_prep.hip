@@ -277,8 +277,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_site_scatter(SiteIn in, c
 // Covered row j starts a segment when it starts a window (j % window == 0) or lies in another
 // 32-row tile than row j-1.
 // With the compacted layout (k_gather_transpose32) the row of covered row j is the VIRTUAL row
-// (j / window) * win_rows + j % window, win_rows = 32 * ceil(window / 32): windows start on tile boundaries, rows
-// without reads do not exist, and the order of the rows in the panel plays no part.
+// (j / window) * win_rows + j % window: rows without reads do not exist, and the order of the rows in the panel plays no
+// part.  win_rows = window rounded up to the layout's alignment: window itself = the rows back to back (dense: v = j,
+// windows straddle tiles like on the panel's own rows), 32 * ceil(window / 32) = every window on a tile boundary.
 struct SegIn {
     const uint2 *rec_cov;
     uint32_t n_cov;
@@ -301,7 +302,7 @@ __device__ __forceinline__ bool seg_start(const SegIn &in, size_t j)
     if (k == 0)
         return true;
     if (in.win_rows)
-        return (k & 31) == 0;
+        return (seg_row(in, j) & 31) == 0;       // (consecutive virtual rows within a window: a new tile starts at a multiple of 32)
     return (in.rec_cov[j].x >> 5) != (in.rec_cov[j - 1].x >> 5);
 }
 
@@ -632,7 +633,7 @@ void launch_prep_segments(const PrepSegArgs &a, const uint32_t *run_begin, uint3
     in.n_cov = a.n_cov;
     in.window = a.window;
     in.d = a.max_cov + 1;
-    in.win_rows = a.compact ? 32u * ((a.window + 31) / 32) : 0u;
+    in.win_rows = a.compact;
     const unsigned nb = blocks_for(a.n_cov);
     // the per-window constants on the second stream, beside the three segment kernels
     {
@@ -678,6 +679,34 @@ void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t w
         return;
     hipLaunchKernelGGL(k_prep_win_bounds, dim3((n_win + 255) / 256), dim3(256), 0, st, cov_site, n_cov, window, n_win,
                        first, last);
+}
+
+// ---------------------------------------------------------------------------
+// Per comparison individual: its background multiplicities = the run's (base_w: -B list, -N sample excluded) with its own
+// lane zeroed (src/ibdgem.c:714: an individual is no background of itself), and the size of its background
+// (:742-750: n_refpanel).  On the device so that a run over NEW comparison individuals queues like any other (the host
+// used to build these arrays and wait for their copies: one host wait per comparison individual).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_target_weights(const double *__restrict__ base_w, const uint32_t *__restrict__ targets,
+                                                        uint32_t lanes, int base_sum, double *__restrict__ weight,
+                                                        int *__restrict__ n_refpanel)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.y;
+    const uint32_t tgt = targets[t];
+    if (n < lanes)
+        weight[(size_t)t * lanes + n] = n == tgt ? 0.0 : base_w[n];
+    if (n == 0)
+        n_refpanel[t] = base_sum - (int)base_w[tgt];
+}
+
+void launch_target_weights(const double *base_w, const uint32_t *targets, uint32_t n_targets, uint32_t lanes, int base_sum,
+                           double *weight, int *n_refpanel, hipStream_t st)
+{
+    if (n_targets == 0)
+        return;
+    hipLaunchKernelGGL(k_target_weights, dim3((lanes + 255) / 256, n_targets), dim3(256), 0, st, base_w, targets, lanes, base_sum,
+                       weight, n_refpanel);
 }
 
 }  // namespace ibdg

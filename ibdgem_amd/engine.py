@@ -35,6 +35,7 @@ SYMBOLS = {
     "ibdg_host_free": (None, [_P]),
     "ibdg_num_sites": (C.c_size_t, [_P]),
     "ibdg_num_windows": (C.c_size_t, [_P]),
+    "ibdg_num_targets": (C.c_size_t, [_P]),
     "ibdg_get_windows": (C.c_int, [_P, _P, _P, _P]),
     "ibdg_run": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int]),
     "ibdg_get_site_af": (C.c_int, [_P, _P]),
@@ -246,6 +247,9 @@ class Engine:
 
     def window_ll_all(self, n_targets, out=None):
         """The window tables of all `n_targets` comparison individuals of the last run in one copy: [n_targets][n_windows][3]."""
+        have = self.lib.ibdg_num_targets(self.ctx)
+        if have != n_targets:       # (the C call copies what the LAST RUN produced, whatever the caller's buffer holds)
+            raise EngineError(f"window_ll_all({n_targets}): the last run had {have} comparison individuals")
         if out is None:
             out = np.empty((n_targets, self.n_windows, 3), dtype=np.float64)
         assert out.dtype == np.float64 and out.size >= n_targets * self.n_windows * 3 and out.flags.c_contiguous

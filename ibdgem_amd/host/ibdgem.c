@@ -1541,7 +1541,8 @@ static void *shard_run(void *arg)
                 wc->batch_cap = wc->batch_ll ? need : 0;
             }
             if (wc->batch_ll && !j->want_sites) {
-                if (ibdg_get_window_ll_all(j->eng, wc->batch_ll))        /* waits for the run */
+                /* (the copy is as large as the LAST RUN's results: it must be the run of this very batch) */
+                if (ibdg_num_targets(j->eng) != j->n_targets || ibdg_get_window_ll_all(j->eng, wc->batch_ll))        /* waits for the run */
                     return NULL;
                 wc->batch_of = j->targets;
                 wc->batch_T = j->n_targets;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 4   /* 4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets; a run over new comparison individuals queues without a host wait.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
@@ -140,6 +140,9 @@ void ibdg_host_free(void *p);
 
 size_t ibdg_num_sites(const ibdg_ctx *ctx);
 size_t ibdg_num_windows(const ibdg_ctx *ctx);
+/* Comparison individuals of the last ibdg_run: what ibdg_get_window_ll_all copies is
+ * ibdg_num_targets x ibdg_num_windows x 3 doubles. */
+size_t ibdg_num_targets(const ibdg_ctx *ctx);
 
 /* Per window: index (into the uploaded site list) of its first and last
  * covered row, and NUM_SITES (src/ibdgem.c:723-730, :751-756).  Any pointer
@@ -170,7 +173,7 @@ int ibdg_get_site_af(ibdg_ctx *ctx, double *af);
 int ibdg_get_site_ll(ibdg_ctx *ctx, size_t t, double *out);
 /* LIBD0, LIBD1, LIBD2 per window of target t: out[n_windows][3] (summary columns 4-6). */
 int ibdg_get_window_ll(ibdg_ctx *ctx, size_t t, double *out);
-/* The same for every target of the last ibdg_run in one copy: out[n_targets][n_windows][3] (a caller that runs batches of
+/* The same for every target of the last ibdg_run in one copy: out[ibdg_num_targets][n_windows][3] (a caller that runs batches of
  * comparison individuals takes a batch's tables off the device at once and can queue the next batch before it goes
  * through them: the host program's --summary-only loop, reference src/ibdgem.c:522 with :751-756). */
 int ibdg_get_window_ll_all(ibdg_ctx *ctx, double *out);
@@ -245,9 +248,9 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * one panel row in "compact_density" (default 4) between the first and the last site carries reads, when the rows
  * are not in file order, or once the runs on one upload have added up to "compact_targets" (default 256) comparison
  * individuals -- the site list belongs to the pileup, src/ibdgem.c:522 runs every individual over the same rows; an
- * individual of the counting kernels counts as 16, a group of the matrix-core kernel as 15: what each saves on the
- * compacted tiles against the 1.2 ms of the gather at 4M rows, i.e. the 16th single run re-lays out -- the panel's
- * own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
+ * group of the matrix-core kernel counts as 15, an individual of the counting kernels as 16 with "mx_counts" 0 and
+ * NOT AT ALL with the default "mx_counts" 1 (those runs gain nothing from the compacted tiles): what each saves on the
+ * compacted tiles against the 1.2 ms of the gather at 4M rows -- the panel's own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "reserve_compact" (0/1, default 1, set before ibdg_upload_panel: the buffer of the compacted tiles, 1.3 x the
  * panel's, is allocated with the panel so that a re-layout never allocates);
  * "mx_counts" (0/1, default 1: see ibdg_last_count_unit; applies where a run's records of 128 bytes per (window, tile)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libibdgem_hip.so does not export {n}"
     assert sorted(E.SYMBOLS) == names, "python binding table out of sync with include/ibdgem_hip.h"
-    assert lib.ibdg_abi_version() == 4
+    assert lib.ibdg_abi_version() == 5
 
 
 def test_no_torch_types_in_header():

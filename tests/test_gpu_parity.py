@@ -691,27 +691,30 @@ def test_matrix_core_counts_give_the_bits_of_the_vector_counts(oracle, N, L, W, 
                                             (300, 3000, 64, 20, 0.4, 9), (700, 5000, 257, 40, 9.0, 17), (64, 640, 32, 20, 2.0, 5),
                                             (2504, 1300, 100, 20, 2.0, 3), (130, 4000, 31, 20, 5.0, 31)])
 def test_compacted_tiles_give_the_bits_of_the_panel_tiles(oracle, N, L, W, M, cov, T):
-    """The compacted, window-aligned tiles of a site list (rows with reads only, every window on a tile boundary)
-    against the panel's own tiles: the exponents are exact integer sums over the same rows, so every --LD kernel
-    (single, groups of four, matrix cores) returns the same bits from either; and both agree with the oracle."""
+    """The compacted tiles of a site list (rows with reads only; back to back -- option compact_align 1, the default: windows
+    straddle tiles -- or every window on a tile boundary, compact_align 32, or on a 4-row boundary) against the panel's own
+    tiles: the exponents are exact integer sums over the same rows, so every --LD kernel (single, groups of four, matrix
+    cores) returns the same bits from any of them; and all agree with the oracle."""
     alle, nr, na = synth(7000 + N + W, L, N, cov_mean=cov)
     na = np.minimum(na, M).astype(np.uint8)
     nr = np.minimum(nr, M - na.astype(int)).astype(np.uint8)
     rng = np.random.default_rng(N * W)
     targets = [int(t) for t in rng.choice(N, size=min(T, N), replace=False)]
     out = {}
-    for tiles in (-1, 1):
+    for tiles, align in ((-1, 1), (1, 1), (1, 32), (1, 4)):
         with E.Engine(0, 0.02, M) as eng:
             eng.set_option("compact_tiles", tiles)
+            eng.set_option("compact_align", align)
             eng.set_option("ld_variant", 2)          # (a thin pileup on the panel's own tiles would take the strict kernel)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, W)
             eng.run(targets, ld=True, pu_id=targets[-1] if T > 2 else -1)
             assert eng.last_ld_variant() == 2 and eng.ld_layout() == (2 if tiles == 1 else 1)
-            out[tiles] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(len(targets))]
+            out[tiles if align == 1 else align] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(len(targets))]
     for i, t in enumerate(targets):
-        assert_bits(out[1][i][0], out[-1][i][0], f"t={t} per-row values")
-        assert_bits(out[1][i][1], out[-1][i][1], f"t={t} windows")
+        for form in (1, 32, 4):
+            assert_bits(out[form][i][0], out[-1][i][0], f"t={t} per-row values, form {form}")
+            assert_bits(out[form][i][1], out[-1][i][1], f"t={t} windows, form {form}")
     for i in sorted({0, len(targets) - 1}):
         res = oracle.compare(alle, nr, na, targets[i], window=W, ld=True, pu_id=targets[-1] if T > 2 else -1, max_cov=M)
         assert_bits(out[1][i][0], res["site"], "site")
@@ -720,7 +723,7 @@ def test_compacted_tiles_give_the_bits_of_the_panel_tiles(oracle, N, L, W, M, co
 
 
 @pytest.mark.parametrize("eps,M,cov", [(0.02, 20, 2.0), (0.001, 40, 9.0), (0.3, 20, 6.0)])
-def test_plain_double_powers_in_the_matrix_core_kernel(eps, M, cov):
+def test_plain_double_powers_in_the_matrix_core_kernel(oracle, eps, M, cov):
     """k_ld_mfma looks tau^G up as a plain double (8 bytes) in windows none of whose powers leaves the double range, and
     as {mantissa, exponent} (16 bytes) otherwise: the same value, mV tau^G = (mV mtau) 2^etau; the plain form adds a lane's
     two haplotypes before it scales them, so the two forms agree to the last place or two, not bit for bit -- with a tiny
@@ -746,6 +749,11 @@ def test_plain_double_powers_in_the_matrix_core_kernel(eps, M, cov):
         assert_bits(got[1][i][:, 2], got[0][i][:, 2], f"target {targets[i]} LIBD2")
         rel = assert_ld_close(got[1][i][:, :2], got[0][i][:, :2], f"target {targets[i]}")
         assert rel <= 1e-13, rel          # the two forms round differently in the last place, no more
+        # ... and both are the reference's values (src/ibdgem.c:669-753 restated), not merely each other's
+        ref = oracle.compare(alle, nr, na, targets[i], window=100, eps=eps, max_cov=M, ld=True)
+        assert_bits(got[1][i][:, 2], ref["win"][:, 2], f"target {targets[i]} LIBD2 vs oracle")
+        for plain in (1, 0):
+            assert_ld_close(got[plain][i][:, :2], ref["win"][:, :2], f"target {targets[i]} vs oracle, mfma_plain_tau {plain}")
 
 
 def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
@@ -866,6 +874,85 @@ def test_queued_runs_leave_the_finalising_step_to_the_next_launch(oracle):
             eng.run([3], ld=True)
             assert_bits(half, eng.window_ll(0), "after new sites")
             eng.upload_sites(np.arange(L), nr, na, 100)
+
+
+def test_a_new_individual_per_queued_run(oracle):
+    """The reference hands every individual of the panel to the same rows in turn (src/ibdgem.c:522): queued runs (option
+    "async") over a NEW comparison individual each -- indices through the page-locked ring, weights and background size made on
+    the device (k_target_weights), the finalising step of run i inside the --LD launch of run i + 1 with run i's own
+    background size -- end, whatever their number, with the bits of that individual's synchronous run; the oracle agrees."""
+    N, L = 300, 5000
+    alle, nr, na = synth(4321, L, N)
+    bg = np.random.default_rng(6).integers(0, 3, size=N).astype(np.uint8)
+    bg[[3, 5]] = (2, 1)                      # the individuals' own multiplicities differ: so do their background sizes
+    people = [3, 5, 8, 299, 64, 3, 127]
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        for kw in ({}, {"bg_count": bg, "pu_id": 8}):
+            want = {}
+            for t in set(people):
+                eng.run([t], ld=True, **kw)
+                want[t] = eng.window_ll(0)
+            refids = None if not kw else [n for n in range(N) for _ in range(int(bg[n]))]
+            for t in (3, 299):
+                ref = oracle.compare(alle, nr, na, t, window=100, ld=True, refids=refids, pu_id=kw.get("pu_id", -1))
+                assert_ld_close(want[t][:, :2], ref["win"][:, :2], f"synchronous run of {t} vs oracle")
+                assert_bits(want[t][:, 2], ref["win"][:, 2], f"LIBD2 of {t} vs oracle")
+            eng.set_option("async", 1)
+            for fin_next in (1, 0):
+                eng.set_option("finalize_in_next", fin_next)
+                for n in range(1, len(people) + 1):
+                    for t in people[:n]:
+                        eng.run([t], ld=True, **kw)
+                    assert eng.last_ld_variant() == 2
+                    assert_bits(eng.window_ll(0), want[people[n - 1]], f"{n} queued runs, finalize_in_next {fin_next}, {kw.keys()}")
+                # more runs in flight than the ring of page-locked slots holds, then three individuals per run in turn
+                for k in range(23):
+                    eng.run([people[k % len(people)]], ld=True, **kw)
+                assert_bits(eng.window_ll(0), want[people[22 % len(people)]], "23 queued runs")
+                for tg in ([3, 5, 8], [5, 8, 299], [3, 5, 8]):
+                    eng.run(tg, ld=True, **kw)
+                every = eng.window_ll_all(3)
+                for i, t in enumerate([3, 5, 8]):
+                    assert_bits(every[i], want[t], f"three per run, {i}")
+            eng.set_option("async", 0)
+            eng.set_option("finalize_in_next", 1)
+        with pytest.raises(E.EngineError, match="the last run had 3"):
+            eng.window_ll_all(2)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_a_pending_finalising_step_never_lands_behind_a_strict_run(variant):
+    """A queued counting run leaves its finalising step pending; the SAME comparison run again under ld_variant 1 or 3 (strict
+    products / reference order) writes its window table itself -- the pending step must be made up for BEFORE that run, not
+    behind it (where it would overwrite the strict kernel's bits with the counting kernel's sums)."""
+    N, L = 300, 5000
+    alle, nr, na = synth(99, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.set_option("ld_variant", variant)
+        eng.run([3], ld=True)
+        strict = eng.window_ll(0)
+        eng.set_option("ld_variant", 0)
+        eng.run([3], ld=True)
+        counting = eng.window_ll(0)
+        assert not np.array_equal(bits(strict[:, :2]), bits(counting[:, :2]))      # (they agree to 1e-14, not bit for bit)
+        eng.set_option("async", 1)
+        for _ in range(3):
+            eng.run([3], ld=True)                      # ... the last one's finalising step is pending
+        eng.set_option("ld_variant", variant)
+        eng.run([3], ld=True)
+        assert eng.last_ld_variant() == variant
+        assert_bits(eng.window_ll(0), strict, f"ld_variant {variant} behind queued counting runs")
+        eng.set_option("ld_variant", 0)
+        eng.run([3], ld=True)
+        eng.run([3], ld=False)                         # a non-LD run takes no pending step along either
+        eng.sync()
+        eng.run([3], ld=True)
+        assert_bits(eng.window_ll(0), counting, "counting runs again")
+        eng.set_option("async", 0)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

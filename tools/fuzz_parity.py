@@ -60,6 +60,7 @@ for case in range(n_cases):
             eng.set_option("ld_variant", variant)
             eng.set_option("compact_tiles", tiles)
             eng.set_option("compact_targets", int(rng.choice([3, 8, 96])))
+            eng.set_option("compact_align", int(rng.choice([1, 1, 1, 32, 4, 16])))
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
             eng.set_background_order(order)
