@@ -438,7 +438,7 @@ def sparse_pileup_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, window, target, m
     eng.set_option("compact_tiles", 0)
     out["note"] = ("engine clock (host wall, best of 10 after 3 untimed; upload_sites_dev + run + all window tables to page-locked "
                    "memory in one copy, option async), the re-layout inside it; ld_variant 2 = exponent counting / matrix cores, 1 = strict fp64 "
-                   "products; ld_layout 2 = compacted window-aligned tiles of the site list, 1 = the panel's own tiles")
+                   "products; ld_layout 2 = compacted tiles of the site list, 1 = the panel's own tiles")
     return out
 
 
@@ -939,8 +939,10 @@ def main():
     seg_start = (np.arange(len(cov_rows)) % args.window == 0)
     seg_start[1:] |= (cov_rows[1:] >> 5) != (cov_rows[:-1] >> 5)
     n_segments_in_place = int(seg_start.sum())
-    # ... and on the compacted tiles: every window starts a tile
-    n_segments_compact = (len(cov_rows) // args.window) * ((args.window + 31) // 32) + (len(cov_rows) % args.window + 31) // 32
+    # ... and on the compacted tiles (the covered rows back to back: row j sits in tile j // 32)
+    jj = np.arange(len(cov_rows))
+    n_segments_compact = int(((jj % args.window == 0) | (jj % 32 == 0)).sum())
+    del jj
     del cov_rows, seg_start
     targets = [args.target]
     # a NEW comparison individual per step (src/ibdgem.c:522 hands every individual of the panel to the same rows in turn):
@@ -959,17 +961,16 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    # The engine re-lays a site list out into compacted, window-aligned tiles once the runs on it have added up to what
-    # the gather costs (16 runs of one comparison individual; DESIGN s4.1b -- the reference's own loop runs every
+    # The engine re-lays a site list out into compacted tiles (its rows with reads back to back) once the runs on it have added
+    # up to what the gather costs (22 runs of one comparison individual; DESIGN s4.1b -- the reference's own loop runs every
     # individual of the panel over the same rows, src/ibdgem.c:522).  That happens here, untimed and reported: the
     # timed steps below are steps of a site list in use, `in_place_tiles` further down is the same step before it.
     relayout = {"after_runs": None, "run_ms": None}
     layout0 = eng.ld_layout()
     eng.run(targets, ld=True)
     eng.sync()
-    # (with the counts on the matrix cores -- the default, last_count_unit 2 -- single runs add nothing towards a re-layout:
-    # they gain nothing from the compacted tiles; only the (mask, count) form, option mx_counts 0, gets there after 16 runs)
-    for k in range(40 if eng.last_count_unit() != 2 else 0):
+    # (a single run counts 12 towards compact_targets = 256 -- 16 with option mx_counts 0 --: the 22nd run re-lays out)
+    for k in range(40):
         if eng.ld_layout() != layout0:
             break
         t_r = time.perf_counter()
@@ -1170,7 +1171,7 @@ def main():
             ms = eng.last_run_ms()
             best0 = ms if best0 is None or ms["total"] < best0["total"] else best0
         eng.set_option("site_results", 1)
-        # the same run from the compacted, window-aligned tiles of the site list (the engine switches by itself from
+        # the same run from the compacted tiles of the site list (the engine switches by itself from
         # "compact_targets" = 256 comparison individuals; forced here): the re-layout is paid once, inside the first run
         eng.set_option("compact_tiles", 0)
         eng.set_option("compact_targets", 1)
@@ -1225,8 +1226,8 @@ def main():
                                          "relayout_pays_from_individuals": (
                                              (first_c_ms - best_c["total"]) / max(1e-9, (best["total"] - best_c["total"]) / T)
                                              if best["total"] > best_c["total"] else None),
-                                         "note": "rows with reads gathered and transposed into tiles that start with their window: 4 "
-                                                 "segments per window of 100 rows instead of 4.6, no rows without reads streamed"},
+                                         "note": "rows with reads gathered back to back and transposed into tiles: 4.1 segments and 3.1 tile "
+                                                 "words per window of 100 rows instead of 4.6 and 3.6, no rows without reads streamed"},
                 "note": "one ibdg_run over that many comparison individuals against the resident panel (device time, best of 3): "
                         "groups of 15 through k_ld_mfma -- the sums that depend on the comparison individual as integer matrix "
                         "products (DESIGN.md s4.2); per-site values and window products of all of them included"}
@@ -1284,7 +1285,7 @@ def main():
                        "segments_rank0": n_segments_compact if layout_timed == 2 else n_segments_in_place,
                        "segments_rank0_in_place": n_segments_in_place,
                        "window": args.window, "targets": len(targets), "epsilon": 0.02, "max_cov": 20,
-                       "tiles": ("compacted, window-aligned tiles of the site list (ld_layout 2): the engine re-laid the site list "
+                       "tiles": ("compacted tiles of the site list, its rows with reads back to back (ld_layout 2): the engine re-laid the site list "
                                  f"out by itself during run {relayout['after_runs']} on it, before the warm-up steps; "
                                  "`in_place_tiles` is the same step before that") if layout_timed == 2 else
                                 "the panel's own tiles (ld_layout 1)" if layout_timed == 1 else "none (strict kernel)",
@@ -1313,11 +1314,11 @@ def main():
             "kernel_ms": kern,
             "ld_layout": layout_timed,
             "new_individual_per_step": len(turn) > 1,
-            "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows into compacted, "
-                             "window-aligned tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
+            "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows with reads into compacted "
+                             "tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
                              "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 15, an individual "
-                             "of the counting kernels as 16 with mx_counts 0 and not at all with the default mx_counts 1, against "
-                             "compact_targets = 256 (DESIGN s4.1b) -- null: no re-layout happened"),
+                             "of the counting kernels as 12 (16 with mx_counts 0), against compact_targets = 256 (DESIGN s4.1b) -- "
+                             "null: no re-layout happened"),
             "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},

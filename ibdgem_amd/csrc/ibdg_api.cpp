@@ -228,7 +228,7 @@ struct ibdg_ctx {
     long opt_compact_targets = 256;  // ... or when the runs on one upload add up to this many comparison individuals of the
                                      // matrix-core kernel k_ld_mfma (the re-layout is paid once: one of them saves 0.007 ms of
                                      // 0.185, the gather costs 1.5; an individual of the counting kernels counts as 16 with
-                                     // (mask, count) pairs -- it saves 0.04-0.09 ms of 0.77 -- and not at all with mx_counts)
+                                     // (mask, count) pairs -- it saves 0.04-0.09 ms of 0.77 -- and as 12 with mx_counts: 0.058 of 0.606)
     long opt_site_results = 1;       // 1: per-site LIBD0/1/2 kept for ibdg_get_site_ll; 0: not -- no T x n_sites x 24 B of HBM,
                                      // no per-site stores (window results only).  (The AF column is made on demand.)
     int res_site_mode = 0;           // the mode the last run's results were produced under
@@ -1525,10 +1525,12 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // reach the point where the re-layout has paid for itself (a rent-or-buy rule: never more than twice the
         // cost of having known the number of runs beforehand).
         // (a group of the matrix-core kernel costs the same whether it holds 3 or IBDG_TG individuals)
-        // (the counting kernel with its sums on the matrix cores gains nothing from the compacted tiles -- 0.60 ms either way,
-        // profiles/r04_count_units.txt -- its runs add nothing; with (mask, count) pairs, option mx_counts 0, 0.73 against 0.77)
+        // (round 5: on the site list's rows back to back -- no padding, no rows without reads -- the counting kernel with its sums
+        // on the matrix cores takes 0.548 ms where the panel's own tiles take 0.606 and round 4's window-aligned tiles took
+        // 0.58-0.59, profiles/r05_layouts.txt: a single run saves 0.058 ms of the 1.3 ms the gather and the new segments
+        // cost, i.e. 22 runs pay for them -- an individual counts as 12; with (mask, count) pairs, option mx_counts 0, as 16)
         const bool to_mfma = c->opt_mfma_targets && c->tab_in_lds && T >= (size_t)c->opt_mfma_min;
-        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * IBDG_TG : c->opt_mx_counts ? 0u : (uint64_t)T * 16u;
+        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * IBDG_TG : (uint64_t)T * (c->opt_mx_counts ? 12u : 16u);
         if (c->relayout_credit >= (uint64_t)std::max<long>(1, c->opt_compact_targets)) {
             if (quiesce(c)) return 1;
             if (build_segments(c, true)) return 1;

@@ -156,10 +156,18 @@ __global__ __launch_bounds__(256) void k_win_slot_g(MfmaArgs a)
         a0alt += __shfl_xor(a0alt, m);
         a1alt += __shfl_xor(a1alt, m);
     }
+    // the largest <t,cov> of the group's haplotypes in this window: no G(x,t) = <x & t, cov> of the window exceeds it
+    uint32_t gmax = real ? (a0cov > a1cov ? a0cov : a1cov) : 0u;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const uint32_t o = __shfl_xor(gmax, m);
+        gmax = o > gmax ? o : gmax;
+    }
     if (l < 16) {
         // per window 32 uint4: [0..3] the exponents of U_t0 of slots 0..15, [4..7] of U_t1, [8 + q] the two mantissas of slot q
+        // (slot 15 holds no individual: its U_t0 exponent entry carries gmax)
         uint4 um = make_uint4(0, 0, 0, 0);                // empty slots: U = 0
-        int e0 = 0, e1 = 0;
+        int e0 = q == PSEUDO ? (int)gmax : 0, e1 = 0;
         if (real) {
             const PowEntry r0 = a.pow_1me[a0alt], r1 = a.pow_1me[a1alt], s0 = a.pow_eps[a0cov], s1 = a.pow_eps[a1cov];
             const double m0 = s0.m / r0.m, m1 = s1.m / r1.m;
@@ -278,30 +286,54 @@ __device__ __forceinline__ void comp_quad(const v16i &acc0, const v16i &acc1, ui
 // scaled products cost 7.  Safe: the addend of the larger exponent keeps its mantissa (>= 1/4) and every plain power is
 // >= 2^-1000, so that product is >= 2^-1002; whatever the other product loses to the double range on its way down is
 // < 2^-1074, i.e. < 2^-72 of the sum.  (The rounding differs from the general form's in the last place; the bar is 1e-10.)
+// Round 5: NO exponent in the lane's work per slot.  The slot's exponent eU is the same for every lane of the half, so it is
+// applied after the sum over the lanes (with U's mantissa, by the lanes that store); and the lanes' own exponents are brought to
+// ONE for the whole wave first -- eRef = the largest eR of a lane with a non-zero multiplicity; mVa, mVb arrive here scaled by
+// 2^(eR - eRef) -- so that the 32 addends of a slot add up as plain doubles: out[j] = mVa tau^G0 + mVb tau^G1 (a product and a
+// fused multiply-add: 2 vector instructions per slot where the form above took 5), S = sum over the lanes, and the slot's value is
+// mU S 2^(eRef + eU).  Safe because the window qualifies for this path only when tau^gmax >= 2^-480 (gmax = the largest <t,cov>
+// of the group's haplotypes in the window, k_win_slot_g: no G exceeds it): the lane that sets eRef contributes at least 2^-482 to
+// every slot's sum, and whatever a lane's scaling or product loses to the double range is below 2^-1022, i.e. < 2^-540 of the sum.
 template <int R0>
-__device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc1, uint32_t eu_addr, double mVa, double mVb,
-                                               int eR, double (&out)[4])
+__device__ __forceinline__ void comp_quad_fast(const v16i &acc0, const v16i &acc1, double mVa, double mVb, double (&out)[4])
 {
     double p[8];
-    uint4 eu;
-    asm volatile("ds_read_b64 %0, %9\n\t"
-                 "ds_read_b64 %1, %10\n\t"
-                 "ds_read_b64 %2, %11\n\t"
-                 "ds_read_b64 %3, %12\n\t"
-                 "ds_read_b64 %4, %13\n\t"
-                 "ds_read_b64 %5, %14\n\t"
-                 "ds_read_b64 %6, %15\n\t"
-                 "ds_read_b64 %7, %16\n\t"
-                 "ds_read_b128 %8, %17 offset:%18\n\t"
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %9\n\t"
+                 "ds_read_b64 %2, %10\n\t"
+                 "ds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12\n\t"
+                 "ds_read_b64 %5, %13\n\t"
+                 "ds_read_b64 %6, %14\n\t"
+                 "ds_read_b64 %7, %15\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(eu)
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
                  : "v"(acc0[R0]), "v"(acc1[R0]), "v"(acc0[R0 + 1]), "v"(acc1[R0 + 1]), "v"(acc0[R0 + 2]), "v"(acc1[R0 + 2]),
-                   "v"(acc0[R0 + 3]), "v"(acc1[R0 + 3]), "v"(eu_addr), "n"(4 * R0)
+                   "v"(acc0[R0 + 3]), "v"(acc1[R0 + 3])
                  : "memory");
-    const int e[4] = {(int)eu.x, (int)eu.y, (int)eu.z, (int)eu.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        out[j] = __builtin_ldexp(mVa * p[2 * j] + mVb * p[2 * j + 1], eR + e[j]);
+        out[j] = __builtin_fma(mVa, p[2 * j], mVb * p[2 * j + 1]);
+}
+
+// the largest value of v over the wave's lanes, in a scalar register: four exchange-and-max steps within the rows of 16 (DPP),
+// then the four rows' maxima through v_readlane
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#define IBDG_MAX_STEP(CTRL)                                                        \
+    {                                                                              \
+        const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);    \
+        v = o > v ? o : v;                                                         \
+    }
+    IBDG_MAX_STEP(0xB1)      // quad_perm [1,0,3,2]
+    IBDG_MAX_STEP(0x4E)      // quad_perm [2,3,0,1]
+    IBDG_MAX_STEP(0x141)     // row_half_mirror
+    IBDG_MAX_STEP(0x140)     // row_mirror
+#undef IBDG_MAX_STEP
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 // addend I of the lane into the wave's reduction strip: row (8 h + I), column n
@@ -315,21 +347,23 @@ __device__ __forceinline__ void strip_put(uint32_t put_addr, double v)
 // reads see the writes of strip_put); two exchange steps within the quad finish the row.  Every lane of quad s
 // ends up with the sum of row s = the sum over the 32 lanes of half s >> 3 of their addend s & 7.
 // the same with one more read in the round trip: the lane's U mantissa (8 bytes at mu_addr)
-__device__ __forceinline__ double strip_sum_mu(uint32_t get_addr, uint32_t mu_addr, double &mu)
+// ... and its U exponent (4 bytes at eu_addr)
+__device__ __forceinline__ double strip_sum_mu(uint32_t get_addr, uint32_t mu_addr, uint32_t eu_addr, double &mu, int &eu)
 {
     double r0, r1, r2, r3, r4, r5, r6, r7;
-    asm volatile("ds_read_b64 %0, %9\n\t"
-                 "ds_read_b64 %1, %9 offset:32\n\t"
-                 "ds_read_b64 %2, %9 offset:64\n\t"
-                 "ds_read_b64 %3, %9 offset:96\n\t"
-                 "ds_read_b64 %4, %9 offset:128\n\t"
-                 "ds_read_b64 %5, %9 offset:160\n\t"
-                 "ds_read_b64 %6, %9 offset:192\n\t"
-                 "ds_read_b64 %7, %9 offset:224\n\t"
-                 "ds_read_b64 %8, %10\n\t"
+    asm volatile("ds_read_b64 %0, %10\n\t"
+                 "ds_read_b64 %1, %10 offset:32\n\t"
+                 "ds_read_b64 %2, %10 offset:64\n\t"
+                 "ds_read_b64 %3, %10 offset:96\n\t"
+                 "ds_read_b64 %4, %10 offset:128\n\t"
+                 "ds_read_b64 %5, %10 offset:160\n\t"
+                 "ds_read_b64 %6, %10 offset:192\n\t"
+                 "ds_read_b64 %7, %10 offset:224\n\t"
+                 "ds_read_b64 %8, %11\n\t"
+                 "ds_read_b32 %9, %12\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(mu)
-                 : "v"(get_addr), "v"(mu_addr)
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(mu), "=&v"(eu)
+                 : "v"(get_addr), "v"(mu_addr), "v"(eu_addr)
                  : "memory");
     double t = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
     t = t + swz_get<1>(t);
@@ -401,8 +435,11 @@ void k_ld_mfma(MfmaArgs a)
     const uint32_t tau16 = (uint32_t)(uintptr_t)(lds_void *)tau;
     for (uint32_t i = threadIdx.x; i < w1 - w0; i += blockDim.x) {
         const WinConst &W = a.wconst[w0 + i];
-        // (no G(x,t) of the window exceeds its reads: when tau^reads is still an ordinary double, all its look-ups are)
-        const uint32_t plain = a.plain_tau && a.pow_tau[W.cov_total].e >= -1000 ? 1u << 31 : 0u;
+        // (no G(x,t) of the window exceeds gmax, the largest <t,cov> of the group's haplotypes in it -- the spare exponent entry of
+        // slot 15, k_win_slot_g: when tau^gmax >= 2^-480 all the window's look-ups are ordinary doubles with room to spare for
+        // the common scale of the wave's lanes, see comp_quad_fast)
+        const uint32_t gmax = reinterpret_cast<const uint32_t *>(a.wc_slot + ((size_t)grp * a.n_win + w0 + i) * 32)[PSEUDO];
+        const uint32_t plain = a.plain_tau && gmax < a.tab_len && a.pow_tau[gmax].e >= -480 ? 1u << 31 : 0u;
         wcc[i] = make_uint4((uint32_t)W.eK, 16 * W.alt_total + tab1, tab2, a.wconst[w0 + i + 1].seg_begin | plain);
     }
     {
@@ -487,6 +524,7 @@ void k_ld_mfma(MfmaArgs a)
     const uint32_t wcs_base = (uint32_t)(uintptr_t)(lds_void *)wcs;
     const uint32_t eu_lane = wcs_base + 64 * h;                      // + 512 per window: the exponents of U_t(h) of slots 0..15
     const uint32_t mu_lane = wcs_base + 128 + 16 * st_q + 8 * h;     // + 512 per window (+ 128 per turn): the mantissa of U_t(h) of the lane's row
+    const uint32_t er_lane = wcs_base + 64 * h + 4 * st_q;           // + 512 per window (+ 32 per turn): its exponent
 
     // The operands of a segment (the lane's two tile words, 16 bytes of the target image) are requested two
     // segments ahead, into two register slots that the segments of the RUN take in turn (segment s: slot s & 1,
@@ -599,9 +637,17 @@ void k_ld_mfma(MfmaArgs a)
             eV0 = eK + (int)r0.z + (int)s0.z;
             eV1 = eK + (int)r1.z + (int)s1.z;
         }
-        const uint32_t eu_addr = eu_lane + (w - w0) * 512, mu_addr = mu_lane + (w - w0) * 512;
-        const int eR = eV0 > eV1 ? eV0 : eV1;
-        const double mVa = __builtin_ldexp(mV0, eV0 - eR), mVb = __builtin_ldexp(mV1, eV1 - eR);
+        const uint32_t eu_addr = eu_lane + (w - w0) * 512, mu_addr = mu_lane + (w - w0) * 512, er_addr = er_lane + (w - w0) * 512;
+        // (plain path) the lanes' exponents brought to the wave's largest one, eRef; a lane without multiplicity (excluded, or
+        // beyond the panel's individuals) has mV = 0 and does not set the scale
+        int eRef = 0;
+        double mVa = 0.0, mVb = 0.0;
+        if (plain) {
+            const int eR = eV0 > eV1 ? eV0 : eV1;
+            eRef = wave_max_i32(wgt != 0.0 ? eR : -(1 << 28));
+            mVa = __builtin_ldexp(mV0, eV0 - eRef);
+            mVb = __builtin_ldexp(mV1, eV1 - eRef);
+        }
         // The IBD1 addends of the lane's slots (:744-745) go to the strip, eight slots per turn (a short group occupies the
         // first registers only).  In the few waves that hold one of the group's comparison individuals, that lane's
         // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
@@ -645,7 +691,7 @@ void k_ld_mfma(MfmaArgs a)
             {                                                                                                \
                 double v[4];                                                                                 \
                 if (plain)                                                                                   \
-                    comp_quad_fast<R0>(acc0, acc1, EU, mVa, mVb, eR, v);                                     \
+                    comp_quad_fast<R0>(acc0, acc1, mVa, mVb, v);                                             \
                 else                                                                                         \
                     comp_quad<R0>(acc0, acc1, EU, tau16, mV0, mV1, eV0, eV1, v);                             \
                 if (EX) {                                                                                    \
@@ -664,10 +710,12 @@ void k_ld_mfma(MfmaArgs a)
 #define IBDG_TURN_END(TURN, OK)                                                                              \
             {                                                                                                \
                 double mu;                                                                                   \
-                const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, mu);                           \
+                int er;                                                                                      \
+                const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, er_addr + 32 * TURN, mu, er);  \
                 if (!EX && TURN == 1 && lane == 28)        /* row 7 = the IBD0 sum over the half: quad 7 has it */ \
                     t0_row[(size_t)w * n_half] = S;                                                          \
-                const double part = mu * S;                                                                  \
+                /* (plain path: the sums are in units of 2^(eRef + eU of the row's slot and haplotype)) */   \
+                const double part = __builtin_ldexp(mu * S, plain ? eRef + er : 0);                          \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
                 const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
                 if (OK)                                                                                      \
