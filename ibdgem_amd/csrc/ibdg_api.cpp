@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
+#include <unistd.h>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -500,7 +502,10 @@ int prepare_panel(ibdg_ctx *c, size_t n_rows, unsigned n_ids)
 // file from the page cache, the host program's packed-panel cache: 0.18-0.28 s for 2.56 GB.
 struct StageJob {
     ibdg_ctx *c;
-    const char *src;
+    const char *src;        // rows in host memory, or
+    int fd = -1;            // ... (src == nullptr) in a file, from byte `off` on
+    uint64_t off = 0;
+    bool io_failed = false;
     size_t rw, dw, n_rows, rows_per_piece;
     int worker, n_workers;
     hipError_t err = hipSuccess;
@@ -518,7 +523,24 @@ void stage_worker(StageJob *j)
         const size_t r0 = p * j->rows_per_piece, nr = std::min(j->rows_per_piece, j->n_rows - r0);
         if ((j->err = hipEventSynchronize(c->stage_ev[b])) != hipSuccess)     // the buffer's previous piece has left
             return;
-        memcpy(c->stage[b], j->src + r0 * j->rw, nr * j->rw);
+        if (j->src) {
+            memcpy(c->stage[b], j->src + r0 * j->rw, nr * j->rw);
+        } else {
+            // straight from the file (the page cache) into the page-locked buffer: no mapping of the file, hence no page
+            // faults here and no 2.56 GB of page-table entries to take down when the process ends
+            size_t done = 0;
+            const size_t want = nr * j->rw;
+            while (done < want) {
+                const ssize_t k = pread(j->fd, (char *)c->stage[b] + done, want - done, (off_t)(j->off + r0 * j->rw + done));
+                if (k <= 0) {
+                    if (k < 0 && errno == EINTR)
+                        continue;
+                    j->io_failed = true;
+                    return;
+                }
+                done += (size_t)k;
+            }
+        }
         j->err = hipMemcpy2DAsync((char *)c->panel.p + r0 * j->dw, j->dw, c->stage[b], j->rw, j->rw, nr,
                                   hipMemcpyHostToDevice, c->stream);
         if (j->err == hipSuccess)
@@ -528,7 +550,7 @@ void stage_worker(StageJob *j)
     }
 }
 
-int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t dw)
+int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t dw, int fd = -1, uint64_t off = 0)
 {
     int T = (int)std::min<unsigned>((unsigned)c->opt_stage_workers, std::max(1u, std::thread::hardware_concurrency()));
     const size_t rows_per_piece = std::max<size_t>(1, ibdg_ctx::STAGE_BYTES / rw);
@@ -545,6 +567,8 @@ int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t
     for (int w = 0; w < T; ++w) {
         jobs[(size_t)w].c = c;
         jobs[(size_t)w].src = (const char *)src;
+        jobs[(size_t)w].fd = fd;
+        jobs[(size_t)w].off = off;
         jobs[(size_t)w].rw = rw;
         jobs[(size_t)w].dw = dw;
         jobs[(size_t)w].n_rows = n_rows;
@@ -555,9 +579,12 @@ int staged_upload(ibdg_ctx *c, const void *src, size_t n_rows, size_t rw, size_t
     }
     for (auto &t : th)
         t.join();
-    for (const StageJob &j : jobs)
+    for (const StageJob &j : jobs) {
         if (j.err != hipSuccess)
             return fail(c, "[::] ERROR in ibdg_upload_panel: staged copy: %s", hipGetErrorString(j.err));
+        if (j.io_failed)
+            return fail(c, "[::] ERROR in ibdg_upload_panel_fd: the file ends before the rows do, or cannot be read");
+    }
     return 0;
 }
 
@@ -571,14 +598,17 @@ bool is_plain_host_memory(const void *p)
     return a.type == hipMemoryTypeUnregistered;
 }
 
-int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind)
+int copy_rows(ibdg_ctx *c, const void *src, size_t n_rows, hipMemcpyKind kind, int fd = -1, uint64_t off = 0)
 {
     const size_t rw = ibdg_row_words(c->n_ids) * 8, dw = (size_t)c->stride * 8;
     if (n_rows == 0)
         return 0;
     if (rw != dw)
         HIP_TRY(c, hipMemsetAsync(c->panel.p, 0, n_rows * dw, c->stream));
-    if (kind == hipMemcpyHostToDevice && n_rows * rw >= ((size_t)256 << 20) && c->opt_staged_upload &&
+    if (fd >= 0) {
+        if (staged_upload(c, nullptr, n_rows, rw, dw, fd, off))
+            return 1;
+    } else if (kind == hipMemcpyHostToDevice && n_rows * rw >= ((size_t)256 << 20) && c->opt_staged_upload &&
         is_plain_host_memory(src)) {
         if (staged_upload(c, src, n_rows, rw, dw))
             return 1;
@@ -1121,6 +1151,15 @@ int ibdg_upload_panel(ibdg_ctx *c, const uint64_t *rows, size_t n_rows, unsigned
     if (quiesce(c)) return 1;
     if (prepare_panel(c, n_rows, n_ids)) return 1;
     return copy_rows(c, rows, n_rows, hipMemcpyHostToDevice);
+}
+
+int ibdg_upload_panel_fd(ibdg_ctx *c, int fd, uint64_t offset, size_t n_rows, unsigned n_ids)
+{
+    if (!c) return 1;
+    if (fd < 0) return fail(c, "[::] ERROR in ibdg_upload_panel_fd: not an open file");
+    if (quiesce(c)) return 1;
+    if (prepare_panel(c, n_rows, n_ids)) return 1;
+    return copy_rows(c, nullptr, n_rows, hipMemcpyHostToDevice, fd, offset);
 }
 
 int ibdg_upload_panel_dev(ibdg_ctx *c, const void *dev_rows, size_t n_rows, unsigned n_ids)

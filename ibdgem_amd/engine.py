@@ -36,6 +36,7 @@ SYMBOLS = {
     "ibdg_num_sites": (C.c_size_t, [_P]),
     "ibdg_num_windows": (C.c_size_t, [_P]),
     "ibdg_num_targets": (C.c_size_t, [_P]),
+    "ibdg_upload_panel_fd": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_size_t, C.c_uint]),
     "ibdg_get_windows": (C.c_int, [_P, _P, _P, _P]),
     "ibdg_run": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int]),
     "ibdg_get_site_af": (C.c_int, [_P, _P]),
@@ -173,6 +174,11 @@ class Engine:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         assert rows.ndim == 2 and rows.shape[1] == self.lib.ibdg_row_words(n_ids)
         self._chk(self.lib.ibdg_upload_panel(self.ctx, rows.ctypes.data, rows.shape[0], n_ids))
+        self.n_ids = n_ids
+
+    def upload_panel_fd(self, fd, offset, n_rows, n_ids):
+        """Packed rows from an open file (n_rows x ibdg_row_words(n_ids) x 8 bytes from byte `offset`)."""
+        self._chk(self.lib.ibdg_upload_panel_fd(self.ctx, int(fd), int(offset), int(n_rows), int(n_ids)))
         self.n_ids = n_ids
 
     def upload_panel_dev(self, dev_ptr, n_rows, n_ids):

@@ -39,6 +39,7 @@
 #include <stdlib.h>
 #ifdef __GLIBC__
 #include <malloc.h>
+#include <sys/mman.h>
 #endif
 #include <string.h>
 #include <time.h>
@@ -348,7 +349,32 @@ static row_t *rows;
 static size_t n_rows;
 static char *arena;
 static size_t arena_len, arena_cap;
-static uint64_t *packed;
+static uint64_t *packed;                /* the packed rows in host memory -- or, with a panel cache, NULL until something on the host
+                                         * asks for a row (packed_rows): the engine takes the rows from the cache FILE */
+static int packed_fd = -1;              /* the open panel cache and where its rows start */
+static uint64_t packed_off;
+static size_t packed_mapped_bytes;      /* > 0: `packed` is a mapping of the panel cache file of that many bytes */
+static size_t packed_file_bytes;
+static pthread_once_t packed_once = PTHREAD_ONCE_INIT;
+
+static void packed_map(void)
+{
+    packed = ingest_cache_map(packed_fd, packed_off, packed_file_bytes);
+    if (!packed) {
+        fprintf(stderr, "[::] ERROR: cannot map the panel cache.\n");
+        _exit(1);
+    }
+    packed_mapped_bytes = packed_file_bytes;
+}
+
+/* the packed rows for the few things the host itself reads them for (a row's alleles of the comparison individual in the
+ * per-site table, -v, a run without a device): with a panel cache the file is mapped at the first such call */
+static inline const uint64_t *packed_rows(void)
+{
+    if (__builtin_expect(!packed && packed_fd >= 0, 0))
+        pthread_once(&packed_once, packed_map);
+    return packed;
+}
 static size_t row_words;
 static uint32_t *alt_count_h;            /* alt alleles per panel row, counted on the host (ingest.c) or read from the cache */
 
@@ -592,8 +618,11 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
     size_t n_hap = 0;
     int rc = 1;
     if (cache_fn)
-        rc = ingest_cache_load(cache_fn, hap_fn, n_ids, &packed, &ok, &alt_count_h, &n_hap);
+        rc = ingest_cache_open(cache_fn, hap_fn, n_ids, &packed_fd, &packed_off, &ok, &alt_count_h, &n_hap);
+    if (!rc)
+        packed_file_bytes = n_hap * (size_t)row_words * 8;
     if (rc) {
+        packed_fd = -1;
         const int team = opt_threads > 0 ? opt_threads : default_threads();
         rc = ingest_hap(hap_fn, n_ids, team, &packed, &ok, &n_hap);
         if (!rc) {
@@ -622,7 +651,7 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
             return 1;
         for (size_t r = 0; r < n_rows; ++r)
             fputc(rows[r].hap_ok, f);
-        fwrite(packed, 8, n_rows * row_words, f);
+        fwrite(packed_rows(), 8, n_rows * row_words, f);
         fclose(f);
     }
     return 0;
@@ -735,7 +764,7 @@ static int is_snp(const char *ref, const char *alt)   /* one of A C G T each (sr
 
 static inline unsigned row_allele(size_t r, unsigned indiv, unsigned hap)
 {
-    return (unsigned)(packed[r * row_words + 2 * (indiv >> 6) + hap] >> (indiv & 63)) & 1u;
+    return (unsigned)(packed_rows()[r * row_words + 2 * (indiv >> 6) + hap] >> (indiv & 63)) & 1u;
 }
 
 /* The reference thins reads with libc rand(), never seeded (src/ibdgem.c:132), so its output
@@ -1821,7 +1850,10 @@ static void *upload_run(void *arg)
      * first batch on (left alone, the engine gets there by itself once its runs have added up: nine batches) */
     if (j->share_sites >= 240 && ibdg_set_option(j->eng, "compact_tiles", 1))
         return NULL;
-    if (ibdg_upload_panel(j->eng, packed + j->r0 * row_words, j->n, j->n_ids))
+    /* with a panel cache the engine reads the rows from the file itself (no mapping of 2.56 GB on this side) */
+    if (packed_fd >= 0 && !packed
+            ? ibdg_upload_panel_fd(j->eng, packed_fd, packed_off + (uint64_t)j->r0 * row_words * 8, j->n, j->n_ids)
+            : ibdg_upload_panel(j->eng, packed_rows() + j->r0 * row_words, j->n, j->n_ids))
         return NULL;
     if (j->ref_order) {                                   /* background list in the -B file's order (:741) */
         if (ibdg_set_option(j->eng, "ld_variant", 3) || (j->has_B && ibdg_set_background_order(j->eng, j->bg_idx, j->bg_n)))
@@ -2647,6 +2679,11 @@ int main(int argc, char **argv)
     if (overlap)
         phase("output files of the last individuals (written beside the engine's work on the ones after them)");
 #if !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
+    if (getenv("IBDGEM_EXIT_PROBE")) {       /* measurement only (tools/warm_phases.py): what of the process's end is the mapping */
+        if (packed_mapped_bytes)
+            munmap(packed, packed_mapped_bytes);
+        phase("probe: munmap of the panel cache");
+    }
     if (!getenv("IBDGEM_KEEP_TEARDOWN")) {
         /* every output file is closed: leave without tearing the device contexts and the runtime down -- the driver
          * reclaims the memory of a process that ends, and freeing 5 GB of it buffer by buffer plus the runtime's

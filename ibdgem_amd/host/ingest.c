@@ -537,8 +537,32 @@ static size_t cache_rows_offset(size_t n_rows)
     return (raw + CACHE_ALIGN - 1) / CACHE_ALIGN * CACHE_ALIGN;
 }
 
+uint64_t *ingest_cache_map(int fd, uint64_t rows_off, size_t bytes)
+{
+    if (bytes == 0)
+        return malloc(8);
+    /* not MAP_POPULATE: whoever reads rows touches the pages it needs */
+    void *m = mmap(NULL, bytes, PROT_READ, MAP_PRIVATE, fd, (off_t)rows_off);
+    return m == MAP_FAILED ? NULL : m;
+}
+
+static int cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed_out, int *fd_out,
+                      uint64_t *off_out, uint8_t **ok_out, uint32_t **alt_out, size_t *n_rows_out);
+
 int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed_out, uint8_t **ok_out,
                       uint32_t **alt_out, size_t *n_rows_out)
+{
+    return cache_load(cache_fn, hap_fn, n_ids, packed_out, NULL, NULL, ok_out, alt_out, n_rows_out);
+}
+
+int ingest_cache_open(const char *cache_fn, const char *hap_fn, unsigned n_ids, int *fd_out, uint64_t *off_out, uint8_t **ok_out,
+                      uint32_t **alt_out, size_t *n_rows_out)
+{
+    return cache_load(cache_fn, hap_fn, n_ids, NULL, fd_out, off_out, ok_out, alt_out, n_rows_out);
+}
+
+static int cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed_out, int *fd_out,
+                      uint64_t *off_out, uint8_t **ok_out, uint32_t **alt_out, size_t *n_rows_out)
 {
     const int fd = open(cache_fn, O_RDONLY);
     if (fd < 0)
@@ -557,7 +581,11 @@ int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, 
         alt = malloc((n ? n : 1) * sizeof *alt);
         if (ok && alt && (size_t)st.st_size >= off + bytes && pread(fd, ok, n, sizeof h) == (ssize_t)n &&
             pread(fd, alt, n * 4, (off_t)cache_counts_offset(n)) == (ssize_t)(n * 4)) {
-            if (bytes == 0) {
+            if (fd_out) {                      /* no mapping: the caller gets the open file and where its rows start */
+                *fd_out = fd;
+                *off_out = (uint64_t)off;
+                rc = 0;
+            } else if (bytes == 0) {
                 *packed_out = malloc(8);
                 rc = *packed_out ? 0 : 1;
             } else {
@@ -576,7 +604,8 @@ int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, 
             }
         }
     }
-    close(fd);
+    if (rc || !fd_out)
+        close(fd);
     if (rc) {
         free(ok);
         free(alt);

@@ -26,6 +26,13 @@ void ingest_alt_counts(const uint64_t *packed, size_t n_rows, unsigned n_ids, in
  * file by rename, which leaves an existing mapping intact).  ok and alt are malloc'ed. */
 int ingest_cache_load(const char *cache_fn, const char *hap_fn, unsigned n_ids, uint64_t **packed, uint8_t **ok,
                       uint32_t **alt, size_t *n_rows);
+/* The same without the mapping: the file stays open (*fd) and the packed rows start at byte *rows_off of it -- for a
+ * caller that hands the rows to the engine as a file (ibdg_upload_panel_fd) and maps them only if something on the host
+ * asks for a row (ingest_cache_map).  The same caveat about a file rewritten in place applies to whoever reads it. */
+int ingest_cache_open(const char *cache_fn, const char *hap_fn, unsigned n_ids, int *fd, uint64_t *rows_off, uint8_t **ok,
+                      uint32_t **alt, size_t *n_rows);
+/* read-only mapping of `bytes` bytes of the open cache file from rows_off on (NULL on failure) */
+uint64_t *ingest_cache_map(int fd, uint64_t rows_off, size_t bytes);
 int ingest_cache_store(const char *cache_fn, const char *hap_fn, unsigned n_ids, const uint64_t *packed,
                        const uint8_t *ok, const uint32_t *alt, size_t n_rows);
 #endif

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets; a run over new comparison individuals queues without a host wait.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets, ibdg_upload_panel_fd; a run over new comparison individuals queues without a host wait.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
@@ -94,6 +94,13 @@ int ibdg_pack_hap_text(const char *hap_line, unsigned n_ids, uint64_t *row);
  * (find_f_impute/find_f_vcf, src/ibd-parse.c:91-110) unless deferred to
  * ibdg_run (see ibdg_set_option "count_in_run"). */
 int ibdg_upload_panel(ibdg_ctx *ctx, const uint64_t *rows, size_t n_rows, unsigned n_ids);
+
+/* Same, with the packed rows in a FILE: n_rows x ibdg_row_words(n_ids) x 8 bytes from byte `offset` of the open file `fd`
+ * (the host program's packed-panel cache).  The engine's staging threads read the file (pread) straight into their
+ * page-locked buffers: the caller maps nothing, so there are no page faults on 2.56 GB of mapping during the upload and
+ * no page-table entries to take down when the process ends (80 ms of a 0.45 s run of the host program).  The file
+ * offset of `fd` is neither used nor changed; an error if the file ends before the rows do. */
+int ibdg_upload_panel_fd(ibdg_ctx *ctx, int fd, uint64_t offset, size_t n_rows, unsigned n_ids);
 
 /* Same, from memory that is already on this context's device
  * (e.g. a torch tensor's data_ptr()); copied device-to-device. */

@@ -333,6 +333,32 @@ def test_cli_reproduces_the_reference_on_synthetic_cases(tag, case, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,case,extra", [("synA", "ld_default", []), ("synA", "ld_varsites", []), ("synB", "ld_w37", ["--devices", "0,0,0"]),
+                                            ("synA", "nonld_all_targets_w2", []), ("synA", "ld_default", ["--summary-only"])])
+def test_cli_with_the_panel_cache_as_a_file(tag, case, extra, tmp_path):
+    """--panel-cache: the first run packs the .hap text and writes the cache, the second hands the engine the cache FILE
+    (ibdg_upload_panel_fd: its staging threads read the rows themselves, nothing is mapped on the host side unless a row's
+    alleles are asked for -- the per-site table, -v) -- with --devices every context its byte range of the file.  Both runs
+    write the reference's files byte for byte."""
+    meta = G.cases(tag)
+    cache = str(tmp_path / "panel.cache")
+    ref = os.path.join(G.GOLD, tag, case, "ref7")
+    files = sorted(f for f in os.listdir(ref) if "--summary-only" not in extra or f.endswith(".summary.txt.gz"))
+    for turn in ("cache written", "cache read"):
+        out = tmp_path / turn.replace(" ", "_")
+        out.mkdir()
+        _run_full(meta["base_args"] + meta["cases"][case] + extra + ["--panel-cache", cache], os.path.join(G.GOLD, tag, "input"), out)
+        assert os.path.getsize(cache) > 0
+        assert files and sorted(os.listdir(out)) == [f[:-3] for f in files], turn
+        for fn in files:
+            got = _read(str(out / fn[:-3]))
+            want = _read(os.path.join(ref, fn))
+            if fn.endswith(".tab.txt.gz"):
+                got = got[1:]
+            assert got == want, f"{turn}: {tag}/{case}/{fn}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,case,devices", [("synA", "ld_default", "0,0"), ("synA", "ld_downsample", "0,0,0"),
                                               ("synA", "ld_varsites", "0,0,0,0,0"), ("synA", "nonld_all_targets_w2", "0,0,0"),
                                               ("synA", "ld_bg20_w64", "0,0,0,0"), ("synA", "ld_pu_in_panel", "0,0,0"),

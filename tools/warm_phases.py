@@ -18,6 +18,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o"]
     os.makedirs(os.path.join(d, "o"))
     for label, extra_env, extra in (("--summary-only, default (_exit once the files are closed)", {}, ["--summary-only"]),
+                                    ("--summary-only, IBDGEM_EXIT_PROBE=1 (the panel cache unmapped before _exit, timed)", {"IBDGEM_EXIT_PROBE": "1"}, ["--summary-only"]),
                                     ("--summary-only, IBDGEM_KEEP_TEARDOWN=1 (ibdg_destroy, orderly exit)", {"IBDGEM_KEEP_TEARDOWN": "1"}, ["--summary-only"]),
                                     ("with the per-site table, default", {}, []),
                                     ("with the per-site table, IBDGEM_KEEP_TEARDOWN=1", {"IBDGEM_KEEP_TEARDOWN": "1"}, []),
@@ -30,4 +31,4 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
             dt = time.perf_counter() - t0
             ph = [l[8:] for l in r.stderr.splitlines() if l.startswith("## time")]
             covered = sum(float(x.rsplit(" ", 1)[1]) for x in ph)
-            print(f"  {dt:.3f} s wall, {covered:.3f} s in phases, {dt - covered:.3f} s outside |", " | ".join(ph))
+            print(f"  {dt:.3f} s wall, {covered:.3f} s in phases, {dt - covered:.3f} s outside |", " | ".join(ph[-3:] if os.environ.get("SHORT") else ph))
