@@ -159,18 +159,23 @@ struct ibdg_ctx {
     hipEvent_t tg_stage_ev[TG_SLOTS] = {};
     bool tg_stage_busy[TG_SLOTS] = {};
     int tg_slot = 0;
-    int tg_half = 0;                    // the half of `targets` / `weight` / the images the current comparison individuals sit in
-    hipEvent_t tg_s2[2] = {};           // stream2's last kernel that read that half
-    bool tg_s2_pending[2] = {};
-    hipEvent_t tg_main[2] = {};         // end of the last run on the main stream that read that half
-    bool tg_main_pending[2] = {};
+    // (round 5, later: a RING of four instead of two halves -- the preparation of run i + 1 then waits for the end of run i - 3,
+    // not of run i - 1, so it is long done when the --LD kernel of run i ends even on an eighth of a chromosome, where a step is
+    // 70 us and the chain "wait, copy, weights, images, record" on stream3 takes 40: profiles/r05_shard_steps.txt)
+    static constexpr int TG_RING = 4;
+    int tg_half = 0;                    // the slot of `targets` / `weight` / the images the current comparison individuals sit in
+    hipEvent_t tg_s2[TG_RING] = {};     // stream2's last kernel that read that slot
+    bool tg_s2_pending[TG_RING] = {};
+    hipEvent_t tg_main[TG_RING] = {};   // end of the last run on the main stream that read that slot
+    bool tg_main_pending[TG_RING] = {};
     hipEvent_t tg_ready = nullptr;      // stream3: the current comparison individuals' data are complete
     hipEvent_t ev_s3sync = nullptr;     // main stream: the prepared sites stream3's kernels read are complete
     uint64_t s3_gen = 0;                // sites_gen stream3 has been ordered behind
-    int nref_slot = 0;                  // `nrefpanel` is a ring of four: a finalising step left to the next run reads its own run's
-    static constexpr int NREF_SLOTS = 4;
+    int nref_slot = 0;                  // `nrefpanel` is a ring of its own, twice as long: a finalising step left to the next run reads
+    static constexpr int NREF_SLOTS = 2 * TG_RING;   // its own run's entry one run later than anything else of that run is read
     static constexpr size_t AHEAD_MAX_T = 64;   // runs of up to that many individuals prepare ahead (two halves of every buffer)
     long opt_prep_ahead = 1;
+    long opt_end_in_dispatch = 1;    // the end event of a run of single individuals rides in its --LD kernel's dispatch packet (0: an event packet behind it): -7 us of a 91 us step on an eighth of a chromosome, profiles/r05_shard_steps.txt
     int base_sum = 0;                   // sum of base_w
     int wt_half = -1;                   // the half the images in wtarget / twords were made in
     // the per-target LDS images of k_win_target (segment records with the target's tile words, window constants) depend
@@ -1442,7 +1447,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     // --LD over several comparison individuals: one table of the rows' values for all of them (they differ by the genotype
     // picked), an individual's per-site table is put together when it is fetched (k_row_table / k_site_expand)
     const bool row_table = want_ll && ld_mode && T > 1;
-    if (ensure(c, c->targets, 2 * T * 4) || (want_ll && ensure(c, c->site_ll, (row_table ? 1 : T) * c->n_sites * 24)) ||
+    if (ensure(c, c->targets, ibdg_ctx::TG_RING * T * 4) || (want_ll && ensure(c, c->site_ll, (row_table ? 1 : T) * c->n_sites * 24)) ||
         (row_table && ensure(c, c->row_tab, c->n_sites * 32)) || ensure(c, c->win_ll, T * (size_t)c->n_win * 24))
         return 1;
     // targets / background weights change rarely between calls (a loop over windows sizes, repeated
@@ -1491,36 +1496,41 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     bool need_ready = false;        // stream3 holds this run's preparation: the other streams wait for tg_ready before they read it
     hipStream_t ps = c->stream;     // where this run's per-individual preparation is queued
     if (!same_inputs) {
-        if (ensure(c, c->weight, (ahead_cap ? 2 : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 4))
+        if (ensure(c, c->weight, (ahead_cap ? ibdg_ctx::TG_RING : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 4))
             return 1;
-        // a page-locked slot for the indices (so that the copy is a queued one), grown when a run brings more of them
-        if (c->tg_stage_cap < T) {
-            if (quiesce(c)) return 1;
-            const size_t cap = std::max<size_t>(64, T);
-            for (int i = 0; i < ibdg_ctx::TG_SLOTS; ++i) {
-                if (c->tg_stage[i])
-                    (void)hipHostFree(c->tg_stage[i]);
-                c->tg_stage[i] = nullptr;
-                HIP_TRY(c, hipHostMalloc((void **)&c->tg_stage[i], cap * 4, hipHostMallocDefault));
-                if (!c->tg_stage_ev[i])
-                    HIP_TRY(c, hipEventCreateWithFlags(&c->tg_stage_ev[i], hipEventDisableTiming));
-                c->tg_stage_busy[i] = false;
+        // more than a few individuals: a page-locked slot for the indices (so that the copy is a queued one), grown when a run
+        // brings more of them; up to IBDG_TG_INLINE of them travel in the weights kernel's arguments instead
+        const bool inline_tg = T <= IBDG_TG_INLINE;
+        int slot = -1;
+        if (!inline_tg) {
+            if (c->tg_stage_cap < T) {
+                if (quiesce(c)) return 1;
+                const size_t cap = std::max<size_t>(64, T);
+                for (int i = 0; i < ibdg_ctx::TG_SLOTS; ++i) {
+                    if (c->tg_stage[i])
+                        (void)hipHostFree(c->tg_stage[i]);
+                    c->tg_stage[i] = nullptr;
+                    HIP_TRY(c, hipHostMalloc((void **)&c->tg_stage[i], cap * 4, hipHostMallocDefault));
+                    if (!c->tg_stage_ev[i])
+                        HIP_TRY(c, hipEventCreateWithFlags(&c->tg_stage_ev[i], hipEventDisableTiming));
+                    c->tg_stage_busy[i] = false;
+                }
+                c->tg_stage_cap = cap;
             }
-            c->tg_stage_cap = cap;
+            slot = c->tg_slot;
+            c->tg_slot = (slot + 1) % ibdg_ctx::TG_SLOTS;
+            if (c->tg_stage_busy[slot])
+                HIP_TRY(c, hipEventSynchronize(c->tg_stage_ev[slot]));      // (its copy was queued TG_SLOTS runs ago)
+            std::copy(targets, targets + T, c->tg_stage[slot]);
         }
-        const int slot = c->tg_slot;
-        c->tg_slot = (slot + 1) % ibdg_ctx::TG_SLOTS;
-        if (c->tg_stage_busy[slot])
-            HIP_TRY(c, hipEventSynchronize(c->tg_stage_ev[slot]));      // (its copy was queued TG_SLOTS runs ago)
-        std::copy(targets, targets + T, c->tg_stage[slot]);
         const bool on_s3 = ahead_cap && c->opt_prep_ahead && c->opt_async;
-        const int half = ahead_cap ? (c->tg_half ^ 1) : 0;
+        const int half = ahead_cap ? (c->tg_half + 1) % ibdg_ctx::TG_RING : 0;
         if (on_s3) {
             ps = c->stream3;
             need_ready = true;
         }
         // whoever still reads the half this run's data go to: a run two runs back, normally long done
-        for (int h = ahead_cap ? half : 0; h <= (ahead_cap ? half : 1); ++h) {
+        for (int h = ahead_cap ? half : 0; h <= (ahead_cap ? half : ibdg_ctx::TG_RING - 1); ++h) {
             if (c->tg_main_pending[h] && ps != c->stream)
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->tg_main[h], 0));
             if (c->tg_s2_pending[h])
@@ -1529,20 +1539,23 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         }
         c->tg_half = half;
         c->nref_slot = (c->nref_slot + 1) % ibdg_ctx::NREF_SLOTS;
-        uint32_t *d_tg = (uint32_t *)((char *)c->targets.p + (size_t)half * (c->targets.cap / 2));
+        uint32_t *d_tg = (uint32_t *)((char *)c->targets.p + (size_t)half * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
         int *d_nref = (int *)((char *)c->nrefpanel.p + (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
-        double *d_w = (double *)((char *)c->weight.p + (size_t)half * (c->weight.cap / 2 / 8 * 8));
-        HIP_TRY(c, hipMemcpyAsync(d_tg, c->tg_stage[slot], T * 4, hipMemcpyHostToDevice, ps));
-        HIP_TRY(c, hipEventRecord(c->tg_stage_ev[slot], ps));
-        c->tg_stage_busy[slot] = true;
-        ibdg::launch_target_weights((const double *)c->base_w.p, d_tg, (uint32_t)T, (uint32_t)lanes, c->base_sum, d_w, d_nref, ps);
+        double *d_w = (double *)((char *)c->weight.p + (size_t)half * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
+        if (!inline_tg) {
+            HIP_TRY(c, hipMemcpyAsync(d_tg, c->tg_stage[slot], T * 4, hipMemcpyHostToDevice, ps));
+            HIP_TRY(c, hipEventRecord(c->tg_stage_ev[slot], ps));
+            c->tg_stage_busy[slot] = true;
+        }
+        ibdg::launch_target_weights((const double *)c->base_w.p, d_tg, inline_tg ? targets : nullptr, (uint32_t)T, (uint32_t)lanes,
+                                    c->base_sum, d_w, d_nref, ps);
         c->prev_targets.assign(targets, targets + T);
         c->wt_gen = 0;             // the images in wtarget / twords are another individual's
     }
-    const uint32_t *const d_targets = (const uint32_t *)((const char *)c->targets.p + (size_t)c->tg_half * (c->targets.cap / 2));
+    const uint32_t *const d_targets = (const uint32_t *)((const char *)c->targets.p + (size_t)c->tg_half * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
     const int *const d_nrefpanel = (const int *)((const char *)c->nrefpanel.p +
                                                  (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
-    const double *const d_weight = (const double *)((const char *)c->weight.p + (size_t)c->tg_half * (c->weight.cap / 2 / 8 * 8));
+    const double *const d_weight = (const double *)((const char *)c->weight.p + (size_t)c->tg_half * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
     // the other streams join stream3's preparation (once, before the first thing that reads it)
     auto settle_ready = [&]() -> int {
         if (!need_ready)
@@ -1554,7 +1567,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         return 0;
     };
 
-    bool use_pop = false, s2_after_prep = false, side_fast = false;
+    bool use_pop = false, s2_after_prep = false, side_fast = false, end_recorded = false;
     if (ld_mode && c->pop_lut_ok && c->pop_sites_ok && !c->compact && c->opt_compact == 0 && c->opt_variant != 1 &&
         c->opt_variant != 3 && c->pop_dense_enough) {
         // Comparison individuals over one site list (the site list belongs to the pileup, not to the comparison
@@ -1695,7 +1708,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                               ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
         const size_t part_bytes = T * (size_t)c->n_win * c->n_chunks * 16;       // the counting kernels' sums per chunk; two halves taken in turn
         // (the single individuals' images in two halves like the other per-individual data, see above)
-        const size_t img_halves = ahead_cap ? 2 : 1;
+        const size_t img_halves = ahead_cap ? ibdg_ctx::TG_RING : 1;
         const size_t wt_cap0 = c->wtarget.cap, tw_cap0 = c->twords.cap;
         if (ensure(c, c->wtarget, img_halves * T_one * (size_t)c->n_win * 32) ||
             ensure(c, c->twords, img_halves * T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
@@ -1715,7 +1728,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.max_seg = c->max_seg;
         if (c->wtarget.cap != wt_cap0 || c->twords.cap != tw_cap0)
             c->wt_gen = 0;                    // new buffers: no images in them
-        pa.rec_ready = (const uint32_t *)((const char *)c->twords.p + (size_t)c->tg_half * (c->twords.cap / 2 / 16 * 16));
+        pa.rec_ready = (const uint32_t *)((const char *)c->twords.p + (size_t)c->tg_half * (c->twords.cap / ibdg_ctx::TG_RING / 16 * 16));
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
         pa.win_per_group = c->wpg;
@@ -1723,7 +1736,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.n_runs = c->n_runs;
         pa.n_cgroups = (c->n_chunks + 7) / 8;
         pa.waves_per_group = (c->n_chunks + pa.n_cgroups - 1) / pa.n_cgroups;   // 40 chunks: 5 x 8; 9: 5 + 4; 2: 1 x 2
-        pa.wc_ready = (const uint32_t *)((const char *)c->wtarget.p + (size_t)c->tg_half * (c->wtarget.cap / 2 / 16 * 16));
+        pa.wc_ready = (const uint32_t *)((const char *)c->wtarget.p + (size_t)c->tg_half * (c->wtarget.cap / ibdg_ctx::TG_RING / 16 * 16));
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
@@ -1848,6 +1861,12 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->wt_count = (uint32_t)T_one;
             c->wt_mx = mx_counts;
             c->last_count_unit = mx_counts ? 2 : 1;
+            // (option "end_in_dispatch": the run's end event is the --LD kernel's own completion signal -- no event packet
+            // of its own behind the kernel -- where that kernel is the run's last launch on the main stream)
+            if (c->opt_end_in_dispatch && fin_in_next && !dispatch_events && T_one == T) {
+                dominant.stop = E.ld_end;
+                end_recorded = true;
+            }
             if (ibdg::launch_ld_popcount(pa, (unsigned)T_one, c->planes, c->stream, dominant))
                 return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
         }
@@ -1944,7 +1963,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             blocks = std::max<unsigned>(1u, (unsigned)((size_t)c->n_cu * c->opt_rows_blocks / T));
         ibdg::launch_rows_windows(sa, (unsigned)T, c->stream, blocks);
     }
-    if (!dispatch_events)
+    if (!dispatch_events && !end_recorded)
         HIP_TRY(c, hipEventRecord(E.ld_end, c->stream));
 
     if (!rows_on_main) {
@@ -1978,13 +1997,14 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         c->s2_pending = true;
         c->tg_s2[c->tg_half] = E.s2[2];
         c->tg_s2_pending[c->tg_half] = true;
-        if (!ahead_cap) {
-            c->tg_s2[1] = E.s2[2];
-            c->tg_s2_pending[1] = true;
-        }
+        if (!ahead_cap)
+            for (int h = 1; h < ibdg_ctx::TG_RING; ++h) {
+                c->tg_s2[h] = E.s2[2];
+                c->tg_s2_pending[h] = true;
+            }
     }
     // (who reads this run's half of the per-individual buffers on the main stream)
-    for (int h = ahead_cap ? c->tg_half : 0; h <= (ahead_cap ? c->tg_half : 1); ++h) {
+    for (int h = ahead_cap ? c->tg_half : 0; h <= (ahead_cap ? c->tg_half : ibdg_ctx::TG_RING - 1); ++h) {
         c->tg_main[h] = E.ld_end;
         c->tg_main_pending[h] = true;
     }
@@ -2157,6 +2177,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_compact_align = value;
         return 0;
     }
+    if (!strcmp(name, "end_in_dispatch")) { c->opt_end_in_dispatch = value != 0; return 0; }
     if (!strcmp(name, "prep_ahead")) { c->opt_prep_ahead = value != 0; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }
     if (!strcmp(name, "async")) { c->opt_async = value != 0; return 0; }

@@ -268,8 +268,14 @@ void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint
 // wconst[w].{mK, eK} = K * pow_1me[reads of w]
 void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st);
 // weight[t][n] = n == targets[t] ? 0 : base_w[n];  n_refpanel[t] = base_sum - base_w[targets[t]]  (src/ibdgem.c:714, :742-750)
-void launch_target_weights(const double *base_w, const uint32_t *targets, uint32_t n_targets, uint32_t lanes, int base_sum,
-                           double *weight, int *n_refpanel, hipStream_t st);
+// (inline_targets != NULL and n_targets <= IBDG_TG_INLINE: the indices travel as kernel arguments and the kernel writes
+// `targets` too; otherwise `targets` must hold them already)
+#define IBDG_TG_INLINE 16
+struct TargetsInline {
+    uint32_t v[IBDG_TG_INLINE];
+};
+void launch_target_weights(const double *base_w, uint32_t *targets, const uint32_t *inline_targets, uint32_t n_targets,
+                           uint32_t lanes, int base_sum, double *weight, int *n_refpanel, hipStream_t st);
 void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t window, uint32_t n_win, uint32_t *first,
                             uint32_t *last, hipStream_t st);
 

@@ -576,9 +576,15 @@ void k_ld_mfma(MfmaArgs a)
             B0 = v4i{(int)(y0 & 0x01010101u), (int)(y0 & 0x02020202u), (int)(y0 & 0x04040404u), (int)(y0 & 0x08080808u)};
             B1 = v4i{(int)(y1 & 0x01010101u), (int)(y1 & 0x02020202u), (int)(y1 & 0x04040404u), (int)(y1 & 0x08080808u)};
         }
+#ifdef IBDG_EXP_NOP2
+        uint32_t ch = 0;
+        if (0) {
+            const uint32_t hom = 0;
+#else
         const uint32_t hom = x.x & x.y;
         uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
-        if (ctl & (1u << 24)) {              // deep rows (cov >= 8): max_cov < 128, seven planes at most
+        if (ctl & (1u << 24)) {
+#endif              // deep rows (cov >= 8): max_cov < 128, seven planes at most
             const uint4 r1 = rec_p[1];
             ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
                   ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
@@ -631,7 +637,11 @@ void k_ld_mfma(MfmaArgs a)
                          : "=&v"(p1), "=&v"(p2), "=&v"(r0), "=&v"(s0), "=&v"(r1), "=&v"(s1)
                          : "v"(ad1), "v"(ad2), "v"(ad3), "v"(ad4), "v"(ad5), "v"(ad6)
                          : "memory");
+#ifdef IBDG_EXP_NOP2
+            wP2 = 0.0;
+#else
             wP2 = wgt * ld_value(eK, p1, p2);                  // :743
+#endif
             mV0 = wgt * (__hiloint2double((int)r0.y, (int)r0.x) * __hiloint2double((int)s0.y, (int)s0.x));
             mV1 = wgt * (__hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)s1.y, (int)s1.x));
             eV0 = eK + (int)r0.z + (int)s0.z;

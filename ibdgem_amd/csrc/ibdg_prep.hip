@@ -687,26 +687,35 @@ void launch_prep_win_bounds(const uint32_t *cov_site, uint32_t n_cov, uint32_t w
 // (:742-750: n_refpanel).  On the device so that a run over NEW comparison individuals queues like any other (the host
 // used to build these arrays and wait for their copies: one host wait per comparison individual).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_target_weights(const double *__restrict__ base_w, const uint32_t *__restrict__ targets,
-                                                        uint32_t lanes, int base_sum, double *__restrict__ weight,
-                                                        int *__restrict__ n_refpanel)
+// A few individuals (<= IBDG_TG_INLINE, the usual run of ONE new individual) arrive as kernel ARGUMENTS and the kernel
+// writes the index array as well: no host-to-device copy (a blit kernel and an event of its own) in front of it.
+__global__ __launch_bounds__(256) void k_target_weights(const double *__restrict__ base_w, uint32_t *__restrict__ targets,
+                                                        TargetsInline inl, uint32_t n_inline, uint32_t lanes, int base_sum,
+                                                        double *__restrict__ weight, int *__restrict__ n_refpanel)
 {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = blockIdx.y;
-    const uint32_t tgt = targets[t];
+    const uint32_t tgt = n_inline ? inl.v[t] : targets[t];
     if (n < lanes)
         weight[(size_t)t * lanes + n] = n == tgt ? 0.0 : base_w[n];
-    if (n == 0)
+    if (n == 0) {
         n_refpanel[t] = base_sum - (int)base_w[tgt];
+        if (n_inline)
+            targets[t] = tgt;
+    }
 }
 
-void launch_target_weights(const double *base_w, const uint32_t *targets, uint32_t n_targets, uint32_t lanes, int base_sum,
-                           double *weight, int *n_refpanel, hipStream_t st)
+void launch_target_weights(const double *base_w, uint32_t *targets, const uint32_t *inline_targets, uint32_t n_targets,
+                           uint32_t lanes, int base_sum, double *weight, int *n_refpanel, hipStream_t st)
 {
     if (n_targets == 0)
         return;
-    hipLaunchKernelGGL(k_target_weights, dim3((lanes + 255) / 256, n_targets), dim3(256), 0, st, base_w, targets, lanes, base_sum,
-                       weight, n_refpanel);
+    TargetsInline inl = {};
+    const uint32_t n_inline = inline_targets && n_targets <= IBDG_TG_INLINE ? n_targets : 0u;
+    for (uint32_t t = 0; t < n_inline; ++t)
+        inl.v[t] = inline_targets[t];
+    hipLaunchKernelGGL(k_target_weights, dim3((lanes + 255) / 256, n_targets), dim3(256), 0, st, base_w, targets, inl, n_inline, lanes,
+                       base_sum, weight, n_refpanel);
 }
 
 }  // namespace ibdg

@@ -619,8 +619,11 @@ static int read_genotypes(const char *hap_fn, const char *legend_fn, unsigned n_
     int rc = 1;
     if (cache_fn)
         rc = ingest_cache_open(cache_fn, hap_fn, n_ids, &packed_fd, &packed_off, &ok, &alt_count_h, &n_hap);
-    if (!rc)
+    if (!rc) {
         packed_file_bytes = n_hap * (size_t)row_words * 8;
+        if (getenv("IBDGEM_CACHE_MAP"))         /* measurement only: the rows as a mapping from the start, as until round 4 */
+            (void)packed_rows();
+    }
     if (rc) {
         packed_fd = -1;
         const int team = opt_threads > 0 ? opt_threads : default_threads();

@@ -1,6 +1,8 @@
-# A/B of two builds of the library on one box: tools/multi_target.py with IBDG_LIB alternating
+# A/B of several builds of the library on one box: tools/multi_target.py with IBDG_LIB in turn, three rounds
+#   bash tools/ab_multi.sh "<lib> <lib> ..." [T ...]
+libs="$1"; shift
 for r in 1 2 3; do
-  for lib in build/libibdgem_hip_prev.so ibdgem_amd/libibdgem_hip.so; do
-    echo "== $lib"; IBDG_LIB=$PWD/$lib python tools/multi_target.py 4000000 15 60 2>&1 | grep -v amdgpu
+  for lib in $libs; do
+    echo "== $lib"; IBDG_LIB=$PWD/$lib python tools/multi_target.py 4000000 "${@:-60}" 2>&1 | grep -v amdgpu
   done
 done

@@ -18,7 +18,9 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     base = [exe, "-H", "p.hap", "-L", "p.legend", "-I", "p.indv", "-P", "p.pileup", "-s", "ind7", "--LD", "--threads", "16", "--panel-cache", "p.cache", "-O", "o"]
     os.makedirs(os.path.join(d, "o"))
     for label, extra_env, extra in (("--summary-only, default (_exit once the files are closed)", {}, ["--summary-only"]),
-                                    ("--summary-only, IBDGEM_EXIT_PROBE=1 (the panel cache unmapped before _exit, timed)", {"IBDGEM_EXIT_PROBE": "1"}, ["--summary-only"]),
+                                    ("--summary-only, IBDGEM_CACHE_MAP=1 (the panel cache mapped and uploaded from the mapping, as until round 4)", {"IBDGEM_CACHE_MAP": "1"}, ["--summary-only"]),
+                                    ("--summary-only, default again", {}, ["--summary-only"]),
+                                    ("--summary-only, IBDGEM_CACHE_MAP=1 again", {"IBDGEM_CACHE_MAP": "1"}, ["--summary-only"]),
                                     ("--summary-only, IBDGEM_KEEP_TEARDOWN=1 (ibdg_destroy, orderly exit)", {"IBDGEM_KEEP_TEARDOWN": "1"}, ["--summary-only"]),
                                     ("with the per-site table, default", {}, []),
                                     ("with the per-site table, IBDGEM_KEEP_TEARDOWN=1", {"IBDGEM_KEEP_TEARDOWN": "1"}, []),
