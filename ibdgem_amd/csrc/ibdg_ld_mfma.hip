@@ -392,6 +392,10 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
     return t;
 }
 
+// cache policy of the tile-word loads (aux of the buffer load: 0 default, 2 = nt): a group streams its chunk's tile words once
+#ifndef IBDG_MFMA_TILE_AUX
+#define IBDG_MFMA_TILE_AUX 0
+#endif
 #ifndef IBDG_MFMA_WAVES
 #define IBDG_MFMA_WAVES 8           /* waves = half chunks per workgroup: 8 share one copy of the tables (4: the strips'
                                        LDS leaves room for 3 waves per SIMD only, 12 % slower) */
@@ -537,7 +541,7 @@ void k_ld_mfma(MfmaArgs a)
     uint2 xq0, xq1;
     uint4 aq0, aq1;
     auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
-        const auto xv = __builtin_amdgcn_raw_buffer_load_b64(xt_rsrc, x_lane, (tile >> 1) * 1024 + (tile & 1) * 8, 0);
+        const auto xv = __builtin_amdgcn_raw_buffer_load_b64(xt_rsrc, x_lane, (tile >> 1) * 1024 + (tile & 1) * 8, IBDG_MFMA_TILE_AUX);
         const auto av = __builtin_amdgcn_raw_buffer_load_b128(ai_rsrc, a_lane, seg * 1024, 0);
         xq = make_uint2(xv[0], xv[1]);
         aq = make_uint4(av[0], av[1], av[2], av[3]);

@@ -14,7 +14,7 @@ i=0
 for counters in "$@"; do
   i=$((i + 1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "gpurun_out/${tag}_p$i" -- \
-      "$PY" bench.py --timed-only --steps 3 --warmup 1 > "gpurun_out/${tag}_p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "gpurun_out/${tag}_p$i.log"; }
+      "$PY" bench.py --timed-only --steps 3 --warmup 1 $BENCH_FLAGS > "gpurun_out/${tag}_p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "gpurun_out/${tag}_p$i.log"; }
 done
 "$PY" - "$tag" <<'PY'
 import collections, csv, glob, json, sys

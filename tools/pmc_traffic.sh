@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 PY=$(python3 -c 'import os, sys; print(os.path.realpath(sys.executable))')
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "gpurun_out/$1_$c" -- \
-      "$PY" bench.py --timed-only --steps 3 --warmup 1 > "gpurun_out/$1_$c.log" 2>&1
+      "$PY" bench.py --timed-only --steps 3 --warmup 1 $BENCH_FLAGS > "gpurun_out/$1_$c.log" 2>&1
 done
 "$PY" - "$1" <<'PY'
 import collections, csv, glob, json, sys
