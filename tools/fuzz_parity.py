@@ -64,8 +64,27 @@ for case in range(n_cases):
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
             eng.set_background_order(order)
+            # queued runs (option async) of OTHER comparison individuals in front of the one that is checked: the ring of
+            # per-individual buffers, the preparation on the third stream, a finalising step left to the next launch
+            queued = int(rng.integers(0, 7)) if rng.random() < 0.5 else 0
+            if queued:
+                eng.set_option("async", 1)
+                eng.set_option("prep_ahead", int(rng.choice([1, 1, 0])))
+                eng.set_option("end_in_dispatch", int(rng.choice([1, 1, 0])))
+                for _ in range(queued):
+                    other = [int(t) for t in rng.choice(N, size=int(rng.choice([1, 1, 1, T, min(N, T + 1)])), replace=False)]
+                    try:
+                        eng.run(other, ld=bool(rng.random() < 0.9), bg_count=bg if order is not None or rng.random() < 0.8 else None, pu_id=pu)
+                    except E.EngineError as e:
+                        if variant == 2 and "not applicable" in str(e):
+                            break
+                        raise
+                    if rng.random() < 0.15:
+                        eng.window_ll(0)
             try:
                 eng.run(targets, ld=True, bg_count=bg, pu_id=pu)
+                if queued and rng.random() < 0.5:
+                    eng.run(targets, ld=True, bg_count=bg, pu_id=pu)
             except E.EngineError as e:
                 if variant == 2 and "not applicable" in str(e):
                     continue                      # forced exponent counting where the table is clamped etc.
