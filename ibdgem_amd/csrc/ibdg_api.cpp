@@ -149,10 +149,10 @@ struct ibdg_ctx {
     size_t prev_lanes = 0;
     // New comparison individuals reach the device without a host wait (the reference's loop hands every individual of the panel
     // to the same rows in turn, src/ibdgem.c:522: a NEW individual per run is the normal case): their indices go through a
-    // small ring of page-locked slots into one of two halves of `targets` (stream2's kernel of the run before may still read
-    // the other), and the weights / background sizes that follow from them are made on the device (k_target_weights) from the
-    // run's background multiplicities `base_w`; `nrefpanel` has two halves as well -- a finalising step left to the next
-    // run reads its own run's half.
+    // weights kernel's arguments (a small ring of page-locked slots beyond IBDG_TG_INLINE of them) into one slot of a ring of
+    // `targets` buffers (the kernels of earlier runs may still read the others), and the weights / background sizes that follow
+    // from them are made on the device (k_target_weights) from the run's background multiplicities `base_w`; `nrefpanel` is a
+    // ring as well -- a finalising step left to the next run reads its own run's entry.
     static constexpr int TG_SLOTS = 4;
     uint32_t *tg_stage[TG_SLOTS] = {};
     size_t tg_stage_cap = 0;            // comparison individuals a slot holds
@@ -163,7 +163,7 @@ struct ibdg_ctx {
     // not of run i - 1, so it is long done when the --LD kernel of run i ends even on an eighth of a chromosome, where a step is
     // 70 us and the chain "wait, copy, weights, images, record" on stream3 takes 40: profiles/r05_shard_steps.txt)
     static constexpr int TG_RING = 4;
-    int tg_half = 0;                    // the slot of `targets` / `weight` / the images the current comparison individuals sit in
+    int tg_cur = 0;                    // the slot of `targets` / `weight` / the images the current comparison individuals sit in
     hipEvent_t tg_s2[TG_RING] = {};     // stream2's last kernel that read that slot
     bool tg_s2_pending[TG_RING] = {};
     hipEvent_t tg_main[TG_RING] = {};   // end of the last run on the main stream that read that slot
@@ -177,7 +177,9 @@ struct ibdg_ctx {
     long opt_prep_ahead = 1;
     long opt_end_in_dispatch = 1;    // the end event of a run of single individuals rides in its --LD kernel's dispatch packet (0: an event packet behind it): -7 us of a 91 us step on an eighth of a chromosome, profiles/r05_shard_steps.txt
     int base_sum = 0;                   // sum of base_w
-    int wt_half = -1;                   // the half the images in wtarget / twords were made in
+    int wt_slot = -1;                   // the slot the images in wtarget / twords were made in
+    bool s3_unsettled = false;          // stream3 holds a preparation the other streams have not been made to wait for yet (an
+                                        // ibdg_run that failed half way): the next run settles it before anything else
     // the per-target LDS images of k_win_target (segment records with the target's tile words, window constants) depend
     // on the prepared sites and the targets only: a further run over the same sites and targets reuses them
     uint64_t sites_gen = 0;            // bumped by every upload of sites and every change of layout
@@ -1490,10 +1492,16 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         else
             c->prev_bg.clear();
     }
-    // Runs of a few individuals keep two halves of everything that depends on the individuals, so that the NEXT run's can be
-    // made (on stream3) while this run's kernels still read theirs; larger runs use the buffers whole, on the main stream.
+    // Runs of a few individuals keep a ring of TG_RING copies of everything that depends on the individuals, so that the NEXT
+    // run's can be made (on stream3) while the runs before still read theirs; larger runs use the buffers whole, on the main stream.
+    if (c->s3_unsettled) {          // (left by a run that failed after it had queued its preparation)
+        HIP_TRY(c, hipEventRecord(c->tg_ready, c->stream3));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tg_ready, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->tg_ready, 0));
+        c->s3_unsettled = false;
+    }
     const bool ahead_cap = T <= ibdg_ctx::AHEAD_MAX_T;
-    bool need_ready = false;        // stream3 holds this run's preparation: the other streams wait for tg_ready before they read it
+    bool &need_ready = c->s3_unsettled;   // stream3 holds this run's preparation: the other streams wait for tg_ready before they read it
     hipStream_t ps = c->stream;     // where this run's per-individual preparation is queued
     if (!same_inputs) {
         if (ensure(c, c->weight, (ahead_cap ? ibdg_ctx::TG_RING : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 4))
@@ -1524,24 +1532,24 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             std::copy(targets, targets + T, c->tg_stage[slot]);
         }
         const bool on_s3 = ahead_cap && c->opt_prep_ahead && c->opt_async;
-        const int half = ahead_cap ? (c->tg_half + 1) % ibdg_ctx::TG_RING : 0;
+        const int rs = ahead_cap ? (c->tg_cur + 1) % ibdg_ctx::TG_RING : 0;
         if (on_s3) {
             ps = c->stream3;
             need_ready = true;
         }
-        // whoever still reads the half this run's data go to: a run two runs back, normally long done
-        for (int h = ahead_cap ? half : 0; h <= (ahead_cap ? half : ibdg_ctx::TG_RING - 1); ++h) {
+        // whoever still reads the ring slot this run's data go to: the run four new individuals back, long done
+        for (int h = ahead_cap ? rs : 0; h <= (ahead_cap ? rs : ibdg_ctx::TG_RING - 1); ++h) {
             if (c->tg_main_pending[h] && ps != c->stream)
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->tg_main[h], 0));
             if (c->tg_s2_pending[h])
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->tg_s2[h], 0));
             c->tg_main_pending[h] = c->tg_s2_pending[h] = false;
         }
-        c->tg_half = half;
+        c->tg_cur = rs;
         c->nref_slot = (c->nref_slot + 1) % ibdg_ctx::NREF_SLOTS;
-        uint32_t *d_tg = (uint32_t *)((char *)c->targets.p + (size_t)half * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
+        uint32_t *d_tg = (uint32_t *)((char *)c->targets.p + (size_t)rs * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
         int *d_nref = (int *)((char *)c->nrefpanel.p + (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
-        double *d_w = (double *)((char *)c->weight.p + (size_t)half * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
+        double *d_w = (double *)((char *)c->weight.p + (size_t)rs * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
         if (!inline_tg) {
             HIP_TRY(c, hipMemcpyAsync(d_tg, c->tg_stage[slot], T * 4, hipMemcpyHostToDevice, ps));
             HIP_TRY(c, hipEventRecord(c->tg_stage_ev[slot], ps));
@@ -1552,10 +1560,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         c->prev_targets.assign(targets, targets + T);
         c->wt_gen = 0;             // the images in wtarget / twords are another individual's
     }
-    const uint32_t *const d_targets = (const uint32_t *)((const char *)c->targets.p + (size_t)c->tg_half * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
+    const uint32_t *const d_targets = (const uint32_t *)((const char *)c->targets.p + (size_t)c->tg_cur * (c->targets.cap / ibdg_ctx::TG_RING / 4 * 4));
     const int *const d_nrefpanel = (const int *)((const char *)c->nrefpanel.p +
                                                  (size_t)c->nref_slot * (c->nrefpanel.cap / ibdg_ctx::NREF_SLOTS / 4 * 4));
-    const double *const d_weight = (const double *)((const char *)c->weight.p + (size_t)c->tg_half * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
+    const double *const d_weight = (const double *)((const char *)c->weight.p + (size_t)c->tg_cur * (c->weight.cap / ibdg_ctx::TG_RING / 8 * 8));
     // the other streams join stream3's preparation (once, before the first thing that reads it)
     auto settle_ready = [&]() -> int {
         if (!need_ready)
@@ -1708,10 +1716,10 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                               ibdg::ld_popcount_lds_bytes(c->max_seg, c->wpg, c->ct_max + 1, c->tab_in_lds, c->seg_ring, 2) <= 150 * 1024;
         const size_t part_bytes = T * (size_t)c->n_win * c->n_chunks * 16;       // the counting kernels' sums per chunk; two halves taken in turn
         // (the single individuals' images in two halves like the other per-individual data, see above)
-        const size_t img_halves = ahead_cap ? ibdg_ctx::TG_RING : 1;
+        const size_t img_slots = ahead_cap ? ibdg_ctx::TG_RING : 1;
         const size_t wt_cap0 = c->wtarget.cap, tw_cap0 = c->twords.cap;
-        if (ensure(c, c->wtarget, img_halves * T_one * (size_t)c->n_win * 32) ||
-            ensure(c, c->twords, img_halves * T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
+        if (ensure(c, c->wtarget, img_slots * T_one * (size_t)c->n_win * 32) ||
+            ensure(c, c->twords, img_slots * T_one * (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
             ensure(c, c->wtarget_mt, n_grp * (size_t)c->n_win * ibdg::ld_popcount_mt_wc_bytes()) ||
             ensure(c, c->twords_mt, n_grp * (size_t)c->n_segs * ibdg::ld_popcount_mt_rec_bytes()) ||
             ensure(c, c->partial, T_cnt ? 2 * part_bytes : 0) ||
@@ -1728,7 +1736,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.max_seg = c->max_seg;
         if (c->wtarget.cap != wt_cap0 || c->twords.cap != tw_cap0)
             c->wt_gen = 0;                    // new buffers: no images in them
-        pa.rec_ready = (const uint32_t *)((const char *)c->twords.p + (size_t)c->tg_half * (c->twords.cap / ibdg_ctx::TG_RING / 16 * 16));
+        pa.rec_ready = (const uint32_t *)((const char *)c->twords.p + (size_t)c->tg_cur * (c->twords.cap / ibdg_ctx::TG_RING / 16 * 16));
         pa.wconst = (const ibdg::WinConst *)c->wconst.p;
         pa.n_win = c->n_win;
         pa.win_per_group = c->wpg;
@@ -1736,7 +1744,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.n_runs = c->n_runs;
         pa.n_cgroups = (c->n_chunks + 7) / 8;
         pa.waves_per_group = (c->n_chunks + pa.n_cgroups - 1) / pa.n_cgroups;   // 40 chunks: 5 x 8; 9: 5 + 4; 2: 1 x 2
-        pa.wc_ready = (const uint32_t *)((const char *)c->wtarget.p + (size_t)c->tg_half * (c->wtarget.cap / ibdg_ctx::TG_RING / 16 * 16));
+        pa.wc_ready = (const uint32_t *)((const char *)c->wtarget.p + (size_t)c->tg_cur * (c->wtarget.cap / ibdg_ctx::TG_RING / 16 * 16));
         pa.pow_1me = (const ibdg::PowEntry *)c->pow1.p;
         pa.pow_eps = (const ibdg::PowEntry *)c->pow2.p;
         pa.targets = sa.targets;
@@ -1755,7 +1763,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         pa.partial = (double *)((char *)c->partial.p + (fin_in_next ? (size_t)c->part_half * part_bytes : 0));
         if (c->fin_pending) {
             pa.fin_prev = c->fin_args.partial;
-            pa.n_refpanel = c->fin_args.n_refpanel;      // (of the run that left it: its half of the buffer)
+            pa.n_refpanel = c->fin_args.n_refpanel;      // (of the run that left it: its entry of the ring)
             pa.win_ll = (double *)c->win_ll.p;
             c->fin_pending = false;
         }
@@ -1839,7 +1847,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             // a caller that runs a comparison again, e.g. timed steps: one launch of ~10 us less per run, which on an
             // eighth of a chromosome is a tenth of the step)
             const bool wt_cached = same_inputs && c->wt_gen == c->sites_gen && c->wt_first == pa.t_base &&
-                                   c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && c->wt_half == c->tg_half &&
+                                   c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && c->wt_slot == c->tg_cur &&
                                    !dispatch_events;
             // a new individual's images: on stream3 with its weights (under the --LD kernel of the run before) unless the
             // launch carries the run's start event (dispatch_events: that belongs on the main stream)
@@ -1855,7 +1863,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             if (!wt_cached)
                 ibdg::launch_win_target(pa, (unsigned)T_one, wt_ahead ? c->stream3 : c->stream, first);
             if (settle_ready()) return 1;
-            c->wt_half = c->tg_half;
+            c->wt_slot = c->tg_cur;
             c->wt_gen = c->sites_gen;
             c->wt_first = pa.t_base;
             c->wt_count = (uint32_t)T_one;
@@ -1995,16 +2003,16 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipEventRecord(E.s2[2], c->stream2));
         c->last_s2 = E.s2[2];
         c->s2_pending = true;
-        c->tg_s2[c->tg_half] = E.s2[2];
-        c->tg_s2_pending[c->tg_half] = true;
+        c->tg_s2[c->tg_cur] = E.s2[2];
+        c->tg_s2_pending[c->tg_cur] = true;
         if (!ahead_cap)
             for (int h = 1; h < ibdg_ctx::TG_RING; ++h) {
                 c->tg_s2[h] = E.s2[2];
                 c->tg_s2_pending[h] = true;
             }
     }
-    // (who reads this run's half of the per-individual buffers on the main stream)
-    for (int h = ahead_cap ? c->tg_half : 0; h <= (ahead_cap ? c->tg_half : ibdg_ctx::TG_RING - 1); ++h) {
+    // (who reads this run's slot of the per-individual buffers on the main stream)
+    for (int h = ahead_cap ? c->tg_cur : 0; h <= (ahead_cap ? c->tg_cur : ibdg_ctx::TG_RING - 1); ++h) {
         c->tg_main[h] = E.ld_end;
         c->tg_main_pending[h] = true;
     }

@@ -173,6 +173,22 @@ def test_config3_chr1_2504_individuals(chr1, oracle):
         words = chr1["panel"][int(r)].cpu().numpy().view(np.uint64)
         assert eng.alt_counts(int(r), 1)[0] == sum(bin(int(x)).count("1") for x in words)
 
+    # (f) the layout of bench.py's timed steps: the engine re-lays the site list out by itself once the runs on it have added up
+    # (the 22nd single run) -- the rows with reads back to back -- and queued runs over a NEW individual each end with the bits of
+    # that individual's synchronous run on the panel's own tiles (checked against the oracle on every window above)
+    other = (t + 1) % N
+    eng.run([other], ld=True)
+    win_other = eng.window_ll(0)
+    assert eng.ld_layout() == 1
+    eng.set_option("async", 1)
+    for k in range(30):
+        eng.run([t if k & 1 else other], ld=True)
+    assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2 and eng.last_count_unit() == 2
+    assert (bits(eng.window_ll(0)) == bits(win)).all() and (bits(eng.site_ll(0)) == bits(site)).all()
+    eng.run([other], ld=True)
+    assert (bits(eng.window_ll(0)) == bits(win_other)).all()
+    eng.set_option("async", 0)
+
     # (c) two shards cut at a window boundary reproduce the whole (the multi-GPU decomposition)
     cuts = shard_rows(nr, na, 100, 2)
     parts = []
