@@ -541,6 +541,10 @@ void k_ld_mfma(MfmaArgs a)
     uint2 xq0, xq1;
     uint4 aq0, aq1;
     auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
+#ifdef IBDG_EXP_SAMETILE            /* timing experiment: every request hits the same lines (what the memory latency costs) */
+        seg = seg0;
+        tile = a.segs[seg0].tile;
+#endif
         const auto xv = __builtin_amdgcn_raw_buffer_load_b64(xt_rsrc, x_lane, (tile >> 1) * 1024 + (tile & 1) * 8, IBDG_MFMA_TILE_AUX);
         const auto av = __builtin_amdgcn_raw_buffer_load_b128(ai_rsrc, a_lane, seg * 1024, 0);
         xq = make_uint2(xv[0], xv[1]);
