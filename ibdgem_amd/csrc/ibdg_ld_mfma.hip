@@ -396,6 +396,9 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 #ifndef IBDG_MFMA_TILE_AUX
 #define IBDG_MFMA_TILE_AUX 0
 #endif
+#ifndef IBDG_MFMA_XCD
+#define IBDG_MFMA_XCD 1             /* the workgroups of a run on one XCD (0: in launch order round the XCDs) */
+#endif
 #ifndef IBDG_MFMA_WAVES
 #define IBDG_MFMA_WAVES 8           /* waves = half chunks per workgroup: 8 share one copy of the tables (4: the strips'
                                        LDS leaves room for 3 waves per SIMD only, 12 % slower) */
@@ -419,7 +422,18 @@ void k_ld_mfma(MfmaArgs a)
     const unsigned lane = threadIdx.x & 63;
     const unsigned grp = blockIdx.z;
     const uint32_t n_half = 2 * a.n_chunks, n_hgroups = (n_half + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
+#if IBDG_MFMA_XCD
+    // The workgroups of ONE run (its n_hgroups groups of half chunks) read the same target image, 1 KiB per segment: they are
+    // dealt to ONE XCD, so that its L2 serves the image to all but the first of them.  Consecutive workgroup ids go round
+    // the 8 XCDs: workgroup b runs on XCD b % 8 as its (b / 8)-th; XCD x takes the runs x, x + 8, x + 16, ... in that order
+    // (the launch holds 8 * n_hgroups * ceil(n_runs / 8) workgroups; those past the last run leave at once).
+    const uint32_t xcd = blockIdx.x & 7, nth = blockIdx.x >> 3;
+    const uint32_t run = xcd + 8 * (nth / n_hgroups), hgroup = nth % n_hgroups;
+    if (run >= a.n_runs)
+        return;
+#else
     const uint32_t run = blockIdx.x / n_hgroups, hgroup = blockIdx.x - run * n_hgroups;
+#endif
     const uint32_t w0 = a.run_begin[run], w1 = a.run_begin[run + 1];
     const uint32_t seg0 = a.wconst[w0].seg_begin, seg1 = a.wconst[w1].seg_begin;
     if (seg1 == seg0)
@@ -541,9 +555,11 @@ void k_ld_mfma(MfmaArgs a)
     uint2 xq0, xq1;
     uint4 aq0, aq1;
     auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
-#ifdef IBDG_EXP_SAMETILE            /* timing experiment: every request hits the same lines (what the memory latency costs) */
-        seg = seg0;
-        tile = a.segs[seg0].tile;
+#ifdef IBDG_EXP_SAMETILE            /* timing experiment: every request hits the same lines (what the memory latency costs); 1: both, 2: the tile words only, 3: the target image only */
+        if (IBDG_EXP_SAMETILE != 2)
+            seg = seg0;
+        if (IBDG_EXP_SAMETILE != 3)
+            tile = a.segs[seg0].tile;
 #endif
         const auto xv = __builtin_amdgcn_raw_buffer_load_b64(xt_rsrc, x_lane, (tile >> 1) * 1024 + (tile & 1) * 8, IBDG_MFMA_TILE_AUX);
         const auto av = __builtin_amdgcn_raw_buffer_load_b128(ai_rsrc, a_lane, seg * 1024, 0);
@@ -853,7 +869,12 @@ int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelE
                             (int)lds) != hipSuccess)
         return 1;
     const uint32_t n_hgroups = (2 * a.n_chunks + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
-    hipExtLaunchKernelGGL(k_ld_mfma, dim3(a.n_runs * n_hgroups, 1, n_groups), dim3(64 * IBDG_MFMA_WAVES), (uint32_t)lds, st, ev.start,
+#if IBDG_MFMA_XCD
+    const uint32_t n_blocks = 8 * n_hgroups * ((a.n_runs + 7) / 8);
+#else
+    const uint32_t n_blocks = a.n_runs * n_hgroups;
+#endif
+    hipExtLaunchKernelGGL(k_ld_mfma, dim3(n_blocks, 1, n_groups), dim3(64 * IBDG_MFMA_WAVES), (uint32_t)lds, st, ev.start,
                           ev.stop, 0, a);
     return 0;
 }
