@@ -266,8 +266,17 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * ds_swizzle -- same additions, same bits);
  * "finalize_in_next" (0/1, default 1; with "async" only: a run of single comparison individuals leaves its finalising
  * step -- the sum over the chunks and the background average, src/ibdgem.c:751-752 -- to the next run's --LD launch when
- * that run is over the same individuals, background and prepared sites; whoever reads results or replaces inputs first
- * gets a launch of its own for it: one launch, its gap and an event packet less per queued run, same results);
+ * that run has the same shape, background and prepared sites (ABI 5: the individuals may differ); whoever reads results or
+ * replaces inputs first gets a launch of its own for it: one launch, its gap and an event packet less per queued run, same
+ * results);
+ * "compact_align" (1, 2, 4, 8, 16 or 32, default 1, set before ibdg_upload_sites: the rows a window of the compacted tiles
+ * is rounded up to -- 1 = the site list's rows with reads back to back, no padding; 32 = every window on a tile boundary,
+ * round 4's layout);
+ * "prep_ahead" (0/1, default 1; with "async" only: what a NEW comparison individual needs before its --LD kernel -- its
+ * background weights and window / segment images -- is made on a third stream into a ring of four buffers while the runs
+ * before still read theirs; 0: on the main stream, in front of the kernel);
+ * "end_in_dispatch" (0/1, default 1: the end event of a run of single individuals is its --LD kernel's own completion
+ * signal instead of an event packet behind the kernel -- 7 us less between two queued runs);
  * "chunks_per_wave" (strict kernel tiling, set before ibdg_upload_panel),
  * "waves_per_block" (strict kernel), "windows_per_wave", "guided_runs",
   * "ring_slots" (2, 3, 4 or 8), "record_lds_bytes" (exponent-counting kernel;
