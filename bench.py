@@ -751,6 +751,10 @@ def compact_line(out, detail_file):
     if cb and isinstance(cb.get("sample"), str) and len(cb["sample"]) > 300:
         cb["sample"] = cb["sample"][:297] + "..."
     line["cpu_baseline"] = cb
+    # (the parity gate that goes with the number: the reference's summary file of the sample against the GPU's windows, 7 digits)
+    line["parity"] = {"reference_summary_equals_gpu_windows_7digits": (out.get("cpu_baseline") or {}).get("summary_matches_gpu_7digits"),
+                      "host_program_summary_equals_engine_windows_7digits": (out.get("warm_e2e") or {}).get("summary_equals_engine_windows_7digits")
+                      if isinstance(out.get("warm_e2e"), dict) else None}
     ranks = []
     for p in out.get("per_rank") or []:
         r = _pick(p, RANK_KEYS[:7])
@@ -772,7 +776,7 @@ def compact_line(out, detail_file):
     line = _sig(line)
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:                       # (cannot happen at <= 8 ranks; drop the optional parts rather than the contract's)
-        for k in ("many_individuals", "ld_kernels_vs_reference_ld_stage", "engine_clock_vs_reference_end_to_end",
+        for k in ("parity", "many_individuals", "ld_kernels_vs_reference_ld_stage", "engine_clock_vs_reference_end_to_end",
                   "step_vs_reference_end_to_end", "engine_clock_ms", "new_individual_per_step"):
             line.pop(k, None)
         line["per_rank"] = [_pick(r, ("rank", "windowed_sites", "ms_per_step", "ld_launch_ms")) for r in line["per_rank"]]
