@@ -1050,6 +1050,40 @@ def test_results_are_the_bits_of_round_1():
 
 
 # --------------------------------------------------------------------------- site preparation on the device
+def test_panel_from_a_file(tmp_path):
+    """ibdg_upload_panel_fd: the packed rows in an open file from a byte offset on (the host program's panel cache) -- the
+    staging threads read the file themselves.  Same alt counts and the same bits of a run as the panel from host memory; a
+    file that ends before the rows do is an error, not a short panel."""
+    N, L = 2504, 30_000                     # 30 000 rows x 640 bytes = 19 MB: three 8 MB pieces for the staging threads
+    alle, nr, na = synth(31, L, N)
+    packed = E.pack_alleles_fast(alle)
+    fn = tmp_path / "rows.bin"
+    off = 4096 + 24
+    with open(fn, "wb") as fh:
+        fh.write(b"\xa5" * off)
+        fh.write(packed.tobytes())
+    with E.Engine() as eng:
+        eng.upload_panel(packed, N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        eng.run([5, 9], ld=True)
+        want = [eng.window_ll(i) for i in range(2)]
+        counts = eng.alt_counts(0, L)
+        fd = os.open(fn, os.O_RDONLY)
+        try:
+            eng.upload_panel_fd(fd, off, L, N)
+            assert (eng.alt_counts(0, L) == counts).all()
+            eng.upload_sites(np.arange(L), nr, na, 100)
+            eng.run([5, 9], ld=True)
+            for i in range(2):
+                assert_bits(eng.window_ll(i), want[i], f"panel from the file, individual {i}")
+            with pytest.raises(E.EngineError, match="file ends before the rows do"):
+                eng.upload_panel_fd(fd, off + 8, L, N)
+            with pytest.raises(E.EngineError, match="not an open file"):
+                eng.upload_panel_fd(-1, 0, L, N)
+        finally:
+            os.close(fd)
+
+
 def test_one_engine_two_panels(oracle):
     """A context that uploads a second panel with another number of individuals (same lane count) and
     runs the same comparison individuals must not reuse the background weights of the first."""
