@@ -631,8 +631,7 @@ void k_ld_mfma(MfmaArgs a)
         fetch(s + 1 < seg_last ? s + 1 : seg_last, ctl & 0xffffffu, xq, aq);         // (s has been advanced: the segment two ahead)
 #endif
     };
-    auto window_end_all = [&]() {
-        const uint4 kc = wcc[w - w0];
+    auto window_end_all = [&](const uint4 kc) {
         // ---- the window's end: every lane finishes its individual against one haplotype of the 15 comparison individuals
         // register 15 = the weights' own rows: 16 C(x) in the lower half of the wave, 16 A(x) in the upper
         const auto w0s = __builtin_amdgcn_permlane32_swap((uint32_t)acc0[15], (uint32_t)acc0[15], false, false);
@@ -782,7 +781,8 @@ void k_ld_mfma(MfmaArgs a)
     // whether it had an odd number of segments: the next window then starts from the other slot -- the same code with the
     // slots' roles exchanged (nothing moves: the loads in flight land where the next segments look for them).
     auto window = [&](uint2 &xa, uint4 &aa, uint2 &xb, uint4 &ab) -> bool {
-        const uint32_t n_more = (__builtin_amdgcn_readfirstlane(wcc[w - w0].w) & 0x7fffffffu) - s - 1;     // segments behind the first
+        const uint4 kc = wcc[w - w0];        // (read once per window: the segment count now, the rest at the window's end)
+        const uint32_t n_more = (__builtin_amdgcn_readfirstlane(kc.w) & 0x7fffffffu) - s - 1;     // segments behind the first
         segment(xa, aa, std::true_type());
         for (uint32_t i = n_more >> 1; i > 0; --i) {
             segment(xb, ab, std::false_type());
@@ -790,7 +790,7 @@ void k_ld_mfma(MfmaArgs a)
         }
         if (n_more & 1)
             segment(xb, ab, std::false_type());
-        window_end_all();
+        window_end_all(kc);
         return !(n_more & 1);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);          // (vmcnt(0): the first two segments' operands, so that the loop's first wait is a counted one on every path into it)
