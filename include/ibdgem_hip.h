@@ -254,10 +254,11 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * "compact_tiles" (set before ibdg_upload_sites: 0, the default = the compacted tiles of ibdg_ld_layout when fewer than
  * one panel row in "compact_density" (default 4) between the first and the last site carries reads, when the rows
  * are not in file order, or once the runs on one upload have added up to "compact_targets" (default 256) comparison
- * individuals -- the site list belongs to the pileup, src/ibdgem.c:522 runs every individual over the same rows; an
- * group of the matrix-core kernel counts as 15, an individual of the counting kernels as 16 with "mx_counts" 0 and
- * NOT AT ALL with the default "mx_counts" 1 (those runs gain nothing from the compacted tiles): what each saves on the
- * compacted tiles against the 1.2 ms of the gather at 4M rows -- the panel's own tiles otherwise; 1 = always; -1 = never: sparse or unordered site lists then take the strict kernel);
+ * individuals -- the site list belongs to the pileup, src/ibdgem.c:522 runs every individual over the same rows; a
+ * group of the matrix-core kernel counts as 15, an individual of the counting kernels as 12 (16 with "mx_counts" 0): what
+ * each saves on the compacted tiles -- a single run 0.058 of 0.606 ms at chr1 x 2504 -- against the 1.3 ms of the gather
+ * and the new segments, i.e. the 22nd single run on an upload re-lays it out -- the panel's own tiles otherwise; 1 =
+ * always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "reserve_compact" (0/1, default 1, set before ibdg_upload_panel: the buffer of the compacted tiles, 1.3 x the
  * panel's, is allocated with the panel so that a re-layout never allocates);
  * "mx_counts" (0/1, default 1: see ibdg_last_count_unit; applies where a run's records of 128 bytes per (window, tile)
