@@ -217,11 +217,12 @@ int ibdg_last_ld_variant(const ibdg_ctx *ctx);
 
 /* Which tiles the exponent-counting / matrix-core --LD kernels read for the site list at hand: 0 none prepared
  * (no sites, or only the strict kernel applies), 1 the panel's own 32-row tiles (every tile between a window's
- * first and last panel row is streamed), 2 the compacted, window-aligned tiles of this site list: only the rows
- * that carry reads (the rows the reference's window loop multiplies, src/ibdgem.c:596-601, :657-663), gathered
- * and transposed once per ibdg_upload_sites -- or by the ibdg_run with which the runs on this upload have added up to
- * "compact_targets" comparison individuals -- so that a window costs ceil(window / 32) tile words whatever the pileup's
- * density.  Chosen per upload and per run (option "compact_tiles"); the results are the same bits from either. */
+ * first and last panel row is streamed), 2 the compacted tiles of this site list: only the rows that carry reads (the
+ * rows the reference's window loop multiplies, src/ibdgem.c:596-601, :657-663), back to back (option "compact_align" 1, the
+ * default since ABI 5; 32 = every window on a tile boundary), gathered and transposed once per ibdg_upload_sites -- or by
+ * the ibdg_run with which the runs on this upload have added up to "compact_targets" comparison individuals -- so that a
+ * window costs window / 32 tile words whatever the pileup's density.  Chosen per upload and per run (option
+ * "compact_tiles"); the results are the same bits from either. */
 int ibdg_ld_layout(const ibdg_ctx *ctx);
 
 /* How the last ibdg_run's exponent-counting launches for single comparison individuals (k_ld_popcount: one individual,
