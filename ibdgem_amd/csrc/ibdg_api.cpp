@@ -116,7 +116,7 @@ struct ibdg_ctx {
     bool up_ms_pending = false;         // the first two are still to be read from the events
 
     // fast --LD variant (exponent counting, ibdg_ld_popcount.hip)
-    // the compacted, window-aligned tiles of the current site list (k_gather_transpose32) and whether the segments,
+    // the compacted tiles of the current site list (k_gather_transpose32) and whether the segments,
     // window constants and control words at hand were cut from them (true) or from the panel's own tiles (false)
     DevBuf t32c;
     uint32_t n_pairs_c = 0;

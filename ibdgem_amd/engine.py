@@ -298,7 +298,7 @@ class Engine:
         return self.lib.ibdg_last_count_unit(self.ctx)
 
     def ld_layout(self):
-        """0 none, 1 the panel's own tiles, 2 the compacted, window-aligned tiles of the site list."""
+        """0 none, 1 the panel's own tiles, 2 the compacted tiles of the site list (its rows with reads back to back)."""
         return self.lib.ibdg_ld_layout(self.ctx)
 
     def sync(self):
