@@ -197,11 +197,16 @@ __global__ __launch_bounds__(512) void k_gather_transpose32(const uint64_t *__re
         return;
     const uint32_t pair = blockIdx.x;
     const uint64_t v = (uint64_t)pair * 64 + lane;
-    const uint64_t win = v / win_rows;
-    const uint32_t k = (uint32_t)(v - win * win_rows);
-    const uint64_t j = win * window + k;
+    uint64_t j = v;                      // rows back to back (win_rows == window, the default): virtual row = covered row
+    bool in_window = true;
+    if (win_rows != window) {            // (wave-uniform: an alignment was asked for)
+        const uint64_t win = v / win_rows;
+        const uint32_t k = (uint32_t)(v - win * win_rows);
+        j = win * window + k;
+        in_window = k < window;
+    }
     uint4 w = make_uint4(0, 0, 0, 0);
-    if (k < window && j < n_cov)
+    if (in_window && j < n_cov)
         w = *reinterpret_cast<const uint4 *>(panel + (size_t)rec_cov[j].x * stride + 2 * c);
     t32[((size_t)c * n_pairs + pair) * 64 + lane] = transpose_pair(w, lane);
 }
