@@ -966,7 +966,7 @@ def main():
         eng.sync()
 
     # The engine re-lays a site list out into compacted tiles (its rows with reads back to back) once the runs on it have added
-    # up to what the gather costs (22 runs of one comparison individual; DESIGN s4.1b -- the reference's own loop runs every
+    # up to what the gather costs (22 runs of one comparison individual; DESIGN s3, s4.1 -- the reference's own loop runs every
     # individual of the panel over the same rows, src/ibdgem.c:522).  That happens here, untimed and reported: the
     # timed steps below are steps of a site list in use, `in_place_tiles` further down is the same step before it.
     relayout = {"after_runs": None, "run_ms": None}
@@ -1321,7 +1321,7 @@ def main():
             "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows with reads into compacted "
                              "tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
                              "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 15, an individual "
-                             "of the counting kernels as 12 (16 with mx_counts 0), against compact_targets = 256 (DESIGN s4.1b) -- "
+                             "of the counting kernels as 12 (16 with mx_counts 0), against compact_targets = 256 (DESIGN s3, s4.1) -- "
                              "null: no re-layout happened"),
             "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,

@@ -35,7 +35,7 @@
 // Round 4: for ONE comparison individual per workgroup the four sums of a haplotype word that a lane needs --
 // <x,cov> <x,alt> <x & t0,cov> <x & t1,cov> -- come from one v_mfma_scale_f32_16x16x128_f8f6f4 with a block-diagonal FP6
 // weight matrix and the word's bits as FP4 numbers (k_win_target_mx, lds_fetch_mx, IBDG_SEGMENT_MX; template parameter MX
-// of k_ld_popcount); only <x0 & x1,cov> is still three (mask, count) pairs.  The sums are the same
+// of k_ld_popcount; DESIGN.md s4.1, docs/DESIGN_rounds_1-4.md s4.1c); only <x0 & x1,cov> is still three (mask, count) pairs.  The sums are the same
 // integers, the results the same bits.  The pairs described above remain the form of option mx_counts 0 and of the kernel
 // for groups of four comparison individuals (k_ld_popcount_mt).
 #include "ibdg_kernels.h"
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
 }
 
 // ---------------------------------------------------------------------------
-// The same for the counts on the matrix cores (round 4).
+// The same for the counts on the matrix cores (round 4; DESIGN.md s4.1, docs/DESIGN_rounds_1-4.md s4.1c).
 //
 // v_mfma_scale_f32_16x16x128_f8f6f4 multiplies a 16 x 128 matrix A by a 128 x 16 matrix B; lane l holds 32 K-elements
 // of row (A) / column (B) l % 16: k = 32 (l / 16) .. + 31.  A is made block diagonal,

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total)
 // bits instead; tools/ubench/shift64_top_vgpr.hip: 7 % of executions, never with the amount one register lower), hipcc
 // does not work around it for this target, and where the register allocator puts a lane number is not ours to decide.
 // That is what made a variant of k_prep_site_scatter with 24 instead of 22 VGPRs scatter some waves' rows to wrong
-// ranks in round 3; tools/audit_shift64.py checks every kernel's ISA for the pattern.
+// ranks in round 3 (docs/DESIGN_rounds_1-4.md s4.4); tools/audit_shift64.py checks every kernel's ISA for the pattern.
 __device__ __forceinline__ uint32_t bits_below_lane(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

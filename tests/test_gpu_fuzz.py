@@ -7,7 +7,7 @@ records at thousands of cases, here at a size that takes seconds, with fixed see
   * tools/fuzz_cli_full.py: the whole host program against the unmodified reference binary, output files byte for
     byte -- only where oracle/_ref/ibdgem travelled with the tree (it is built by __graft_entry__.build() wherever
     /root/reference exists).  Its seed is one whose cases contain none of the seventh-digit %e ties on 2-3-site
-    windows that DESIGN.md s2 describes (about one file in 400 in a random sweep)."""
+    windows that DESIGN.md s8 (docs/DESIGN_rounds_1-4.md s2) describes (about one file in 400 in a random sweep)."""
 import os
 import subprocess
 import sys

@@ -1,4 +1,4 @@
-"""Audit of the kernels' ISA for the 64-bit-shift hazard found in round 4 (tools/ubench/shift64_top_vgpr.hip):
+"""Audit of the kernels' ISA for the 64-bit-shift hazard found in round 4 (docs/DESIGN_rounds_1-4.md s4.4, tools/ubench/shift64_top_vgpr.hip):
 on gfx950 a v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 whose shift AMOUNT sits in the last VGPR of the wave's
 allocation reads it wrongly in ~7 % of executions (the amount comes from v0 instead) -- LLVM knows this as the
 "Shift64HighRegBug" of gfx11 and works around it there; hipcc does not for gfx950.  Like LLVM's workaround this audit is

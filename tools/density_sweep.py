@@ -1,5 +1,5 @@
 """Engine clock of one comparison against the density of the pileup, from the panel's own tiles and from the compacted
-tiles of the site list: the measurement behind the option "compact_density" (DESIGN.md s4.1b).
+tiles of the site list: the measurement behind the option "compact_density" (docs/DESIGN_rounds_1-4.md s4.1b).
 
     python tools/density_sweep.py [panel_rows]
 
