@@ -127,6 +127,13 @@ struct ibdg_ctx {
     // many comparison individuals (k_ld_mfma): target operands of a batch of groups, window constants per slot,
     // partial sums per half chunk, background multiplicities without the comparison individual's exclusion
     DevBuf aimg, wc_slot, partial_h, base_w;
+    // ... and what does NOT depend on the comparison individuals (round 5): every background individual's weighted product of
+    // its own genotype factors per window (src/ibdgem.c:715, :743 -- the IBD0 terms) and their sums per chunk, from one pass of
+    // k_ld_popcount per site list and background (with some individual's images: the product does not look at them)
+    DevBuf p2w, p2c, p2_tw, p2_wt;
+    uint64_t p2_gen = 0, p2_bg_gen = 0;     // sites_gen / bg_gen the pass was made for
+    int p2_mx = -1;
+    uint64_t bg_gen = 1;                    // bumped whenever the background multiplicities change
     // pow1/pow2: rho^n, sigma^n as {f64 mantissa, i32 exponent}; powb: (1-eps)^n in the x87 format
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
@@ -1078,7 +1085,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->row_tab, &c->t32, &c->t32c, &c->seg_first,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w,
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w, &c->p2w, &c->p2c, &c->p2_tw, &c->p2_wt,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
         release(*b);
@@ -1483,6 +1490,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         HIP_TRY(c, hipMemcpyAsync(c->base_w.p, wb.data(), lanes * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));          // the host vector goes out of scope
         c->chain_ok = false;
+        ++c->bg_gen;
         c->base_sum = sum;
         c->prev_pu = pu_id;
         c->prev_has_bg = bg_count ? 1 : 0;
@@ -1803,12 +1811,36 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.plain_tau = c->opt_mfma_plain_tau ? 1u : 0u;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
+            if (c->p2_gen != c->sites_gen || c->p2_bg_gen != c->bg_gen || c->p2_mx != mx_counts) {
+                // the IBD0 terms of this site list and background, once: a pass of the counting kernel that keeps every lane's
+                // weighted product (p2_out) and its sums per chunk; the images it reads are those of the run's first individual
+                if (ensure(c, c->p2w, (size_t)c->n_win * lanes * 8) || ensure(c, c->p2c, (size_t)c->n_win * c->n_chunks * 16) ||
+                    ensure(c, c->p2_tw, (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
+                    ensure(c, c->p2_wt, (size_t)c->n_win * 32))
+                    return 1;
+                ibdg::PopArgs pp = pa;
+                pp.rec_ready = (const uint32_t *)c->p2_tw.p;
+                pp.wc_ready = (const uint32_t *)c->p2_wt.p;
+                pp.weight = (const double *)c->base_w.p;
+                pp.t_base = 0;
+                pp.partial = (double *)c->p2c.p;
+                pp.p2_out = (double *)c->p2w.p;
+                pp.fin_prev = nullptr;
+                ibdg::launch_win_target(pp, 1, c->stream);
+                if (ibdg::launch_ld_popcount(pp, 1, c->planes, c->stream))
+                    return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
+                c->p2_gen = c->sites_gen;
+                c->p2_bg_gen = c->bg_gen;
+                c->p2_mx = mx_counts;
+            }
+            ma.p2w = (const double *)c->p2w.p;
+            ma.p2c = (const double *)c->p2c.p;
+            ma.lanes = (uint32_t)lanes;
             {
                 // one batch's partial sums: t1 [groups][windows][half chunks][16], t0 [groups][windows][half chunks], ov [groups][windows][16]
                 const size_t nh = (size_t)c->n_chunks * 2;
                 ma.part_t1 = (double *)c->partial_h.p;
-                ma.part_t0 = ma.part_t1 + gg_batch * (size_t)c->n_win * nh * 16;
-                ma.part_ov = ma.part_t0 + gg_batch * (size_t)c->n_win * nh;
+                (void)nh;
             }
             for (size_t g0 = 0; g0 < n_gg; g0 += gg_batch) {
                 const size_t nb = n_gg - g0 < gg_batch ? n_gg - g0 : gg_batch;

@@ -127,6 +127,9 @@ struct PopArgs {
     double *win_ll = nullptr;
     uint32_t sum_dpp = 0;       // ... and whose wave sums exchange by DPP moves instead of ds_swizzle
     uint32_t mx_counts = 0;     // 1: k_ld_popcount takes the counts of a haplotype word on the matrix cores (records of 128 bytes)
+    double *p2_out = nullptr;   // k_ld_popcount: [n_win][lanes] every lane's weighted product of its individual's OWN genotype
+                                // factors (src/ibdgem.c:715, :743) -- what does not depend on the comparison individual; the
+                                // matrix-core kernel's launches take it from there (once per site list and background)
 };
 
 // events a dispatch updates with its own start / stop time (either may be null)
@@ -170,8 +173,11 @@ struct MfmaArgs {
     const double *base_weight;  // [lanes] background multiplicity without the comparison individual's exclusion
     // partial sums of the launch's groups per window and half chunk (2 * n_chunks of them), see k_ld_mfma:
     double *part_t1;            // [groups][n_win][2 * n_chunks][16 slots]  IBD1 sums
-    double *part_t0;            // [groups][n_win][2 * n_chunks]            IBD0 sum, common to the slots
-    double *part_ov;            // [groups][n_win][16 slots]                IBD0 sum of the half chunk that holds the slot's own individual
+    // IBD0 does not depend on the comparison individual except for its own exclusion: the products and their sums per chunk of
+    // 64 individuals come from ONE pass of k_ld_popcount per site list and background (PopArgs::p2_out and its partial sums)
+    const double *p2w;          // [n_win][lanes] weight x product of every background individual
+    const double *p2c;          // [n_win][n_chunks][2]: [0] = the chunk's sum of p2w
+    uint32_t lanes;
 };
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st);

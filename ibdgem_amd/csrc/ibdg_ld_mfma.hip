@@ -522,22 +522,10 @@ void k_ld_mfma(MfmaArgs a)
     const bool st_lane = (lane & 35) == 0;                          // p = 0, h = 0
     const bool st_ok0 = st_lane && st_q < cnt, st_ok1 = st_lane && st_q + 8 < cnt;      // (slot 15 never: cnt <= 15)
     // Partial sums of this wave (half chunk hc) per window, for k_ld_finalize_g:
-    //   t1[group][window][hc][16 slots]  the IBD1 sums -- the eight storing lanes of a turn write 64 consecutive bytes;
-    //   t0[group][window][hc]            the IBD0 sum over the wave's individuals, the same for every slot ...
-    //   ov[group][window][16 slots]      ... except the slot whose comparison individual sits in this wave (no individual
-    //                                    is in its own background, ibdgem.c:714): that slot's sum without it, in place of t0
-    // (round 3 stored {t0, t1} per slot and half chunk, 16 bytes each at a stride of 1280: 2.7 GB per 60 comparison
-    // individuals written in 16-byte pieces and read back by the finalising kernel -- a tenth of the run.)
+    //   t1[group][window][hc][16 slots]  the IBD1 sums -- the eight storing lanes of a turn write 64 consecutive bytes.
+    // (The IBD0 sums are not this kernel's: MfmaArgs::p2w / p2c.)
     double *const t1_row = a.part_t1 + (((size_t)grp * a.n_win) * n_half + hc) * 16 + st_q;          // + window * n_half * 16 (+ 8 per turn)
-    double *const t0_row = a.part_t0 + ((size_t)grp * a.n_win) * n_half + hc;                        // + window * n_half
-    double *const ov_row = a.part_ov + ((size_t)grp * a.n_win) * 16 + (lane >> 2);                   // + window * 16
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
-    uint32_t ex_slots = 0;                                           // slots whose comparison individual is one of the wave's lanes
-    if (any_excl)
-        for (uint32_t q = 0; q < cnt; ++q)
-            if (__builtin_amdgcn_ballot_w64((excl >> q) & 1) != 0)
-                ex_slots |= 1u << q;
-    const bool ov_ok = (lane & 3) == 0 && ((ex_slots >> (lane >> 2)) & 1);
     const uint32_t n_quads = (cnt + 3) / 4;                          // groups of four slots that hold comparison individuals
     const uint32_t wcs_base = (uint32_t)(uintptr_t)(lds_void *)wcs;
     const uint32_t eu_lane = wcs_base + 64 * h;                      // + 512 per window: the exponents of U_t(h) of slots 0..15
@@ -573,7 +561,6 @@ void k_ld_mfma(MfmaArgs a)
     }
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v16i acc0, acc1;
-    uint32_t CH;
     uint32_t w = w0, s = seg0;
     const uint32_t seg_last = seg1 - 1;
     const uint4 *rec_p = rec;            // the record of the NEXT segment is read while this one is worked on
@@ -600,29 +587,17 @@ void k_ld_mfma(MfmaArgs a)
             B0 = v4i{(int)(y0 & 0x01010101u), (int)(y0 & 0x02020202u), (int)(y0 & 0x04040404u), (int)(y0 & 0x08080808u)};
             B1 = v4i{(int)(y1 & 0x01010101u), (int)(y1 & 0x02020202u), (int)(y1 & 0x04040404u), (int)(y1 & 0x08080808u)};
         }
-#ifdef IBDG_EXP_NOP2
-        uint32_t ch = 0;
-        if (0) {
-            const uint32_t hom = 0;
-#else
-        const uint32_t hom = x.x & x.y;
-        uint32_t ch = (uint32_t)__popc(hom & r0.y) + ((uint32_t)__popc(hom & r0.z) << 1) + ((uint32_t)__popc(hom & r0.w) << 2);
-        if (ctl & (1u << 24)) {
-#endif              // deep rows (cov >= 8): max_cov < 128, seven planes at most
-            const uint4 r1 = rec_p[1];
-            ch += ((uint32_t)__popc(hom & r1.x) << 3) + ((uint32_t)__popc(hom & r1.y) << 4) +
-                  ((uint32_t)__popc(hom & r1.z) << 5) + ((uint32_t)__popc(hom & r1.w) << 6);
-        }
+        // (<x0 & x1, cov> and the product of an individual's OWN genotype factors that needs it -- src/ibdgem.c:715, the IBD0
+        // term -- do not depend on the comparison individuals: round 5 takes them from ONE pass of k_ld_popcount per site list
+        // and background, MfmaArgs::p2w / p2c, instead of counting them again in every group's launch)
         rec_p += 2;
         ++s;
         if constexpr (decltype(first)::value) {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, zero16, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, zero16, 0, 0, 0);
-            CH = ch;
         } else {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B1, acc1, 0, 0, 0);
-            CH += ch;
         }
         // the slot's refill is requested only now, behind the matrix instructions that read it: issued before them, the
         // old and the new operand would both be live, hipcc would land the new one in other registers and move it over
@@ -639,32 +614,21 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t C0s = 2 * w0s[0], A0s = 2 * w0s[1], C1s = 2 * w1s[0], A1s = 2 * w1s[1];   // 16 C(x0), 16 A(x0), 16 C(x1), 16 A(x1)
         const bool plain = (__builtin_amdgcn_readfirstlane(kc.w) >> 31) != 0;
         const int eK = (int)kc.x;
-        double wP2, mV0, mV1;
+        double mV0, mV1;
         int eV0, eV1;
         {
-            // pDg[x0+x1] (ibdgem.c:715): E3 = C0 + C1 - 2 CH, E2 = AT - a0 - a1 + CH;
             // V_x = K' rho^(AT - A(x)) sigma^C(x) with the lane's background multiplicity folded into its mantissa
-            uint4 p1, p2, r0, s0, r1, s1;
-            uint32_t m32 = (uint32_t)-32;
-            asm volatile("" : "+v"(m32));
-            const uint32_t ad1 = lshl_add<4>(CH, kc.y - (A0s + A1s)), ad2 = mad24r(CH, m32, kc.z + (C0s + C1s));
+            uint4 r0, s0, r1, s1;
             const uint32_t ad3 = kc.y - A0s, ad4 = kc.z + C0s;
             const uint32_t ad5 = kc.y - A1s, ad6 = kc.z + C1s;
-            asm volatile("ds_read_b128 %0, %6\n\t"
-                         "ds_read_b128 %1, %7\n\t"
-                         "ds_read_b128 %2, %8\n\t"
-                         "ds_read_b128 %3, %9\n\t"
-                         "ds_read_b128 %4, %10\n\t"
-                         "ds_read_b128 %5, %11\n\t"
+            asm volatile("ds_read_b128 %0, %4\n\t"
+                         "ds_read_b128 %1, %5\n\t"
+                         "ds_read_b128 %2, %6\n\t"
+                         "ds_read_b128 %3, %7\n\t"
                          "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(p1), "=&v"(p2), "=&v"(r0), "=&v"(s0), "=&v"(r1), "=&v"(s1)
-                         : "v"(ad1), "v"(ad2), "v"(ad3), "v"(ad4), "v"(ad5), "v"(ad6)
+                         : "=&v"(r0), "=&v"(s0), "=&v"(r1), "=&v"(s1)
+                         : "v"(ad3), "v"(ad4), "v"(ad5), "v"(ad6)
                          : "memory");
-#ifdef IBDG_EXP_NOP2
-            wP2 = 0.0;
-#else
-            wP2 = wgt * ld_value(eK, p1, p2);                  // :743
-#endif
             mV0 = wgt * (__hiloint2double((int)r0.y, (int)r0.x) * __hiloint2double((int)s0.y, (int)s0.x));
             mV1 = wgt * (__hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)s1.y, (int)s1.x));
             eV0 = eK + (int)r0.z + (int)s0.z;
@@ -691,35 +655,6 @@ void k_ld_mfma(MfmaArgs a)
             // at the next window's first segment instead -- behind the stores of this window end, whose number it cannot
             // count (they sit under conditions) and whose latency the wave would then sit out once per window.
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            double t0lo = 0.0, t0hi = 0.0;
-            if (!EX) {
-                // the IBD0 addends are the same for all comparison individuals: with more than eight of them the sum rides in
-                // the second turn's spare row (the 16th slot holds no individual); otherwise one butterfly over the half
-                if (n_quads <= 2) {
-                    double s0 = wP2;
-                    s0 = s0 + swz_get<1>(s0);
-                    s0 = s0 + swz_get<2>(s0);
-                    s0 = swz_add<4>(s0);
-                    s0 = swz_add<8>(s0);
-                    s0 = swz_add<16>(s0);
-                    t0lo = t0hi = s0;
-                    if (lane == 0)
-                        t0_row[(size_t)w * n_half] = s0;
-                }
-            } else {
-                // the IBD0 addend of a lane counts for all comparison individuals but itself: one turn of the strip, half h
-                // of the wave (the same individuals as the other half) for slots 8 h .. 8 h + 7
-#define IBDG_PUT0(I) strip_put<I>(put_addr, (excl >> (8 * h + I)) & 1 ? 0.0 : wP2);
-                IBDG_PUT0(0) IBDG_PUT0(1) IBDG_PUT0(2) IBDG_PUT0(3) IBDG_PUT0(4) IBDG_PUT0(5) IBDG_PUT0(6) IBDG_PUT0(7)
-#undef IBDG_PUT0
-                const double t = strip_sum(get_addr);          // quad s: slot s; slot 15 holds no individual: the sum over all lanes
-                if (ov_ok)
-                    ov_row[(size_t)w * 16] = t;
-                if (lane == 60)
-                    t0_row[(size_t)w * n_half] = t;
-                (void)t0lo;
-                (void)t0hi;
-            }
 #define IBDG_QUAD(R0, EU)                                                                                    \
             {                                                                                                \
                 double v[4];                                                                                 \
@@ -745,8 +680,6 @@ void k_ld_mfma(MfmaArgs a)
                 double mu;                                                                                   \
                 int er;                                                                                      \
                 const double S = strip_sum_mu(get_addr, mu_addr + 128 * TURN, er_addr + 32 * TURN, mu, er);  \
-                if (!EX && TURN == 1 && lane == 28)        /* row 7 = the IBD0 sum over the half: quad 7 has it */ \
-                    t0_row[(size_t)w * n_half] = S;                                                          \
                 /* (plain path: the sums are in units of 2^(eRef + eU of the row's slot and haplotype)) */   \
                 const double part = __builtin_ldexp(mu * S, plain ? eRef + er : 0);                          \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
@@ -754,12 +687,10 @@ void k_ld_mfma(MfmaArgs a)
                 if (OK)                                                                                      \
                     t1_row[(size_t)w * n_half * 16 + 8 * TURN] = part + __hiloint2double((int)phi, (int)plo); \
             }
-            if (n_quads > 2) {                         // slots 8..15 first (their turn brings the IBD0 sum along)
+            if (n_quads > 2) {
                 IBDG_QUAD(8, eu_addr)
                 if (n_quads > 3)
                     IBDG_QUAD(12, eu_addr)
-                if (!EX)
-                    strip_put<7>(put_addr, wP2);
                 IBDG_TURN_END(1, st_ok1)
             }
             {
@@ -803,40 +734,35 @@ void k_ld_mfma(MfmaArgs a)
     }
 }
 
-// The window averages of a group's comparison individuals from the half chunks' partial sums (src/ibdgem.c:736-753):
-// a wave per (window, group).  IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four
-// part sums of a slot meet as ((j0 + j1) + j2) + j3.  IBD0: lane q < 16 adds t0[hc] over all half chunks in order, with the
-// slot's own value ov[q] in place of the half chunk its comparison individual sits in.  Fixed orders: the same bits every run.
+// The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group).
+// IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four part sums of a slot meet as
+// ((j0 + j1) + j2) + j3.  IBD0 does not depend on the comparison individual except for its own exclusion (:714): lane q < 16
+// adds the chunks' sums of the one pass over the site list (p2c, in chunk order) with, in place of the chunk its individual
+// sits in, that chunk's 63 other products (p2w, in lane order).  Fixed orders: the same bits every run.
 __global__ __launch_bounds__(64) void k_ld_finalize_g(MfmaArgs a, const int *__restrict__ n_refpanel, double *__restrict__ win_ll)
 {
-    __shared__ double t0s[256];
     const uint32_t w = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
     const uint32_t n_half = 2 * a.n_chunks, q = lane & 15, j = lane >> 4;
     const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
     const double *t1 = a.part_t1 + (((size_t)grp * a.n_win + w) * n_half) * 16;
-    const double *t0 = a.part_t0 + ((size_t)grp * a.n_win + w) * n_half;
     double acc = 0.0;
     for (uint32_t hc = j; hc < n_half; hc += 4)
         acc += t1[(size_t)hc * 16 + q];
     const double a1 = __shfl(acc, q + 16), a2 = __shfl(acc, q + 32), a3 = __shfl(acc, q + 48);
     const double s1 = ((acc + a1) + a2) + a3;                  // (lanes 0..15 hold the totals)
-    double s0 = 0.0;
     const bool real = lane < cnt;
-    const uint32_t tgt = real ? a.targets[a.t_base + grp * TG + lane] : 0u;
-    const uint32_t hc_own = tgt >> 5;                            // the half chunk (32 individuals) the slot's own individual sits in
-    const double ov = real ? a.part_ov[((size_t)grp * a.n_win + w) * 16 + lane] : 0.0;
-    for (uint32_t base = 0; base < n_half; base += 256) {      // (2 x chunks half chunks: 80 at 2504 individuals)
-        const uint32_t n = n_half - base < 256 ? n_half - base : 256;
-        __syncthreads();
-        for (uint32_t i = lane; i < n; i += 64)
-            t0s[i] = t0[base + i];
-        __syncthreads();
-        if (real)
-            for (uint32_t i = 0; i < n; ++i)
-                s0 += base + i == hc_own ? ov : t0s[i];
-    }
     if (real) {
         const uint32_t t = a.t_base + grp * TG + lane;
+        const uint32_t tgt = a.targets[t];
+        const uint32_t c_own = tgt >> 6;                         // the chunk (64 individuals) the slot's own individual sits in
+        const double *pc = a.p2c + (size_t)w * a.n_chunks * 2;
+        const double *pw = a.p2w + (size_t)w * a.lanes + 64 * (size_t)c_own;
+        double own = 0.0;
+        for (uint32_t i = 0; i < 64; ++i)
+            own += 64 * c_own + i == tgt ? 0.0 : pw[i];
+        double s0 = 0.0;
+        for (uint32_t c = 0; c < a.n_chunks; ++c)
+            s0 += c == c_own ? own : pc[2 * c];
         const int nref = n_refpanel[t];
         const double mK = a.wconst[w].mK;             // mantissa of K' (its exponent went into every term)
         double *o = win_ll + ((size_t)t * a.n_win + w) * 3;

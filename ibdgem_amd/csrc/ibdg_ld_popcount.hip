@@ -976,6 +976,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     }
                 }
                 double s0 = wgt * val[0];                                   // :743
+                if (a.p2_out)
+                    a.p2_out[(size_t)w * a.lanes + c * 64 + lane] = s0;
                 double s1 = wgt * (((val[1] + val[2]) + val[3]) + val[4]);  // :744-745
                 const double tot = a.sum_dpp ? wave_sum2_dpp(s0, s1, scr_w, scr_r) : wave_sum2(s0, s1, scr_w, scr_r);
                 if ((lane & 31) == 31)
@@ -1005,6 +1007,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             const double Q11 = ld_value(eK, pw[8], pw[9]);
             double s0 = wgt * P2;                                   // :743
             double s1 = wgt * (((Q00 + Q01) + Q10) + Q11);          // :744-745
+            if (a.p2_out)
+                a.p2_out[(size_t)w * a.lanes + c * 64 + lane] = s0;
             const double tot = wave_sum2(s0, s1, scr_w, scr_r);      // first half: sum of s0, second half: of s1
             if ((lane & 31) == 31)
                 a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + (lane >> 5)] = tot;
