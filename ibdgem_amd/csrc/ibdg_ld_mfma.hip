@@ -209,6 +209,23 @@ __device__ __forceinline__ double swz_get(double v)
     return __hiloint2double(hi, lo);
 }
 
+// An 8-byte store by the lanes of `mask` only, as ONE asm statement (EXEC narrowed and put back inside it).  On purpose out of
+// hipcc's sight: a store under a C++ condition is a branch, behind which hipcc cannot count the vector-memory operations in
+// flight any more and drains them all (s_waitcnt vmcnt(0)) at the next use of a requested operand -- round 4 therefore
+// drained the requests at the START of every window end, where the last one had just been issued.  An operation hipcc does
+// not know of only makes its counted waits wait for more, never for less (the queue retires in order).
+__device__ __forceinline__ void store_f64_lanes(uint64_t mask, double *p, double v)
+{
+    uint64_t exec_was;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, %0, %3\n\t"
+                 "global_store_dwordx2 %1, %2, off\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(exec_was)
+                 : "v"(p), "v"(v), "s"(mask)
+                 : "memory", "scc");
+}
+
 constexpr uint32_t SS = 36;          // doubles per row of the reduction strip: 32 lanes + 4 of padding (reads two-way at most)
 
 // (a << 4) + b with b in a scalar register (the tau table's LDS address is the same for the whole workgroup)
@@ -396,6 +413,14 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 #ifndef IBDG_MFMA_TILE_AUX
 #define IBDG_MFMA_TILE_AUX 0
 #endif
+#ifndef IBDG_MFMA_AHEAD
+#define IBDG_MFMA_AHEAD 2           /* operand slots = segments a request runs ahead of its use.  3 (round 5, measured at
+                                       compile time only): the three window instances' slots meet in phis the register
+                                       allocator resolves with copies -- 56 spilled VGPRs, a full drain at every copy */
+#endif
+#ifndef IBDG_MFMA_DRAIN
+#define IBDG_MFMA_DRAIN 0           /* 1: round 4's wait for every request at the start of a window end */
+#endif
 #ifndef IBDG_MFMA_XCD
 #define IBDG_MFMA_XCD 1             /* the workgroups of a run on one XCD (0: in launch order round the XCDs) */
 #endif
@@ -477,7 +502,7 @@ void k_ld_mfma(MfmaArgs a)
     // run's last tile at the end), bit 24 cov planes beyond three, bit 25 first, bit 26 last segment of its window
     for (uint32_t i = threadIdx.x; i < seg1 - seg0; i += blockDim.x) {
         const Seg &S = a.segs[seg0 + i];
-        const uint32_t ahead = seg0 + i + 2 < seg1 ? seg0 + i + 2 : seg1 - 1;
+        const uint32_t ahead = seg0 + i + IBDG_MFMA_AHEAD < seg1 ? seg0 + i + IBDG_MFMA_AHEAD : seg1 - 1;
         const uint32_t first = (i == 0 || a.segs[seg0 + i - 1].last) ? 1u << 25 : 0u;
         const uint32_t deep = ((S.flags >> 16) & 0xff) > 3 ? 1u << 24 : 0u;
         const uint32_t wide = (((S.flags >> 16) & 0xff) > 4 || (S.flags >> 24) > 4) ? 1u << 27 : 0u;       // a weight of 16 or more: k_win_target_g
@@ -520,7 +545,8 @@ void k_ld_mfma(MfmaArgs a)
     // row s = lane >> 2 is haplotype h = s >> 3 of slot (s & 7) + 8 turn; lane p = 0 of the quads of half 0 stores
     const uint32_t st_q = (lane >> 2) & 7;
     const bool st_lane = (lane & 35) == 0;                          // p = 0, h = 0
-    const bool st_ok0 = st_lane && st_q < cnt, st_ok1 = st_lane && st_q + 8 < cnt;      // (slot 15 never: cnt <= 15)
+    // (the lanes that store a turn's sums, as EXEC masks)
+    const uint64_t st_ok0 = __builtin_amdgcn_ballot_w64(st_lane && st_q < cnt), st_ok1 = __builtin_amdgcn_ballot_w64(st_lane && st_q + 8 < cnt);      // (slot 15 never: cnt <= 15)
     // Partial sums of this wave (half chunk hc) per window, for k_ld_finalize_g:
     //   t1[group][window][hc][16 slots]  the IBD1 sums -- the eight storing lanes of a turn write 64 consecutive bytes.
     // (The IBD0 sums are not this kernel's: MfmaArgs::p2w / p2c.)
@@ -540,8 +566,8 @@ void k_ld_mfma(MfmaArgs a)
     // record says which tile that is -- so that hipcc can count the loads in flight (s_waitcnt vmcnt(2)); with the
     // request under a condition, and the slots swapped after windows of an odd number of segments, it drained
     // them all (vmcnt(0)) at every window start and every swap, and a segment paid three LDS round trips.
-    uint2 xq0, xq1;
-    uint4 aq0, aq1;
+    uint2 xq0, xq1, xq2;
+    uint4 aq0, aq1, aq2;
     auto fetch = [&](uint32_t seg, uint32_t tile, uint2 &xq, uint4 &aq) {
 #ifdef IBDG_EXP_SAMETILE            /* timing experiment: every request hits the same lines (what the memory latency costs); 1: both, 2: the tile words only, 3: the target image only */
         if (IBDG_EXP_SAMETILE != 2)
@@ -558,6 +584,10 @@ void k_ld_mfma(MfmaArgs a)
         const uint32_t t0 = a.segs[seg0].tile, s1 = seg0 + 1 < seg1 ? seg0 + 1 : seg0, t1 = a.segs[s1].tile;
         fetch(seg0, t0, xq0, aq0);
         fetch(s1, t1, xq1, aq1);
+#if IBDG_MFMA_AHEAD == 3
+        const uint32_t s2 = seg0 + 2 < seg1 ? seg0 + 2 : seg1 - 1;
+        fetch(s2, a.segs[s2].tile, xq2, aq2);
+#endif
     }
     const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     v16i acc0, acc1;
@@ -603,7 +633,7 @@ void k_ld_mfma(MfmaArgs a)
         // old and the new operand would both be live, hipcc would land the new one in other registers and move it over
         // at the end of the loop body -- behind a wait for every load in flight (s_waitcnt vmcnt(0))
 #ifndef IBDG_EXP_NOFETCH
-        fetch(s + 1 < seg_last ? s + 1 : seg_last, ctl & 0xffffffu, xq, aq);         // (s has been advanced: the segment two ahead)
+        fetch(s + (IBDG_MFMA_AHEAD - 1) < seg_last ? s + (IBDG_MFMA_AHEAD - 1) : seg_last, ctl & 0xffffffu, xq, aq);   // (s has been advanced: the segment IBDG_MFMA_AHEAD ahead)
 #endif
     };
     auto window_end_all = [&](const uint4 kc) {
@@ -650,11 +680,12 @@ void k_ld_mfma(MfmaArgs a)
         // addends for itself are left out: no individual is in its own background (ibdgem.c:714).
         auto window_end = [&](auto with_excl) {
             constexpr bool EX = decltype(with_excl)::value;
-            // The operands of the next two segments were requested during the window's last segments and have landed by
-            // now; saying so here (vmcnt(0), a wait hipcc's counter understands) keeps it from draining the memory queue
-            // at the next window's first segment instead -- behind the stores of this window end, whose number it cannot
-            // count (they sit under conditions) and whose latency the wave would then sit out once per window.
+            // (Round 5: no wait for the operand requests here.  The window end's two stores are asm statements hipcc does not
+            // count, store_f64_lanes, so the requests of the window's last segments stay in flight through the whole window
+            // end -- round 4 drained them at this point, a memory latency per window: 9 % of the kernel.)
+#if IBDG_MFMA_DRAIN
             __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
 #define IBDG_QUAD(R0, EU)                                                                                    \
             {                                                                                                \
                 double v[4];                                                                                 \
@@ -684,8 +715,7 @@ void k_ld_mfma(MfmaArgs a)
                 const double part = __builtin_ldexp(mu * S, plain ? eRef + er : 0);                          \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
                 const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
-                if (OK)                                                                                      \
-                    t1_row[(size_t)w * n_half * 16 + 8 * TURN] = part + __hiloint2double((int)phi, (int)plo); \
+                store_f64_lanes(OK, t1_row + ((size_t)w * n_half * 16 + 8 * TURN), part + __hiloint2double((int)phi, (int)plo)); \
             }
             if (n_quads > 2) {
                 IBDG_QUAD(8, eu_addr)
@@ -708,6 +738,44 @@ void k_ld_mfma(MfmaArgs a)
             window_end(std::false_type());
         ++w;
     };
+#if IBDG_MFMA_AHEAD == 3
+    // Round 5: THREE operand slots, taken in turn by the segments of the run (segment s: slot s mod 3), each refilled for the
+    // segment three ahead -- a timing build whose requests all hit the same lines ran 9 % faster (profiles/r05_ab_mfma.txt):
+    // that much was the latency of requests two segments ahead.  (The registers for the third slot came from the IBD0 terms
+    // leaving the kernel: 126 -> 117 -> 123.)  A window that starts from slot k runs the same code with the slots' roles
+    // rotated; which instance comes next is a uniform switch -- nothing is in flight across it, every window end waits for
+    // all requests (they have landed long before).
+    auto window = [&](uint2 &xa, uint4 &aa, uint2 &xb, uint4 &ab, uint2 &xc, uint4 &ac) -> uint32_t {
+        const uint4 kc = wcc[w - w0];        // (read once per window: the segment count now, the rest at the window's end)
+        const uint32_t n_more = (__builtin_amdgcn_readfirstlane(kc.w) & 0x7fffffffu) - s - 1;     // segments behind the first
+        segment(xa, aa, std::true_type());
+        uint32_t left = n_more;
+        for (; left >= 3; left -= 3) {
+            segment(xb, ab, std::false_type());
+            segment(xc, ac, std::false_type());
+            segment(xa, aa, std::false_type());
+        }
+        if (left >= 1)
+            segment(xb, ab, std::false_type());
+        if (left == 2)
+            segment(xc, ac, std::false_type());
+        window_end_all(kc);
+        return left + 1 == 3 ? 0u : left + 1;         // slots the run has moved on by, modulo 3
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // (vmcnt(0): the first three segments' operands)
+    uint32_t slot = 0;
+    while (w < w1) {
+        uint32_t adv;
+        if (slot == 0)
+            adv = window(xq0, aq0, xq1, aq1, xq2, aq2);
+        else if (slot == 1)
+            adv = window(xq1, aq1, xq2, aq2, xq0, aq0);
+        else
+            adv = window(xq2, aq2, xq0, aq0, xq1, aq1);
+        slot += adv;
+        slot = slot >= 3 ? slot - 3 : slot;
+    }
+#else
     // One window whose first segment finds its operands in slot (xa, aa); its segments take the two slots in turn.  Returns
     // whether it had an odd number of segments: the next window then starts from the other slot -- the same code with the
     // slots' roles exchanged (nothing moves: the loads in flight land where the next segments look for them).
@@ -732,6 +800,9 @@ void k_ld_mfma(MfmaArgs a)
             }
         }
     }
+    (void)xq2;
+    (void)aq2;
+#endif
 }
 
 // The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group).
