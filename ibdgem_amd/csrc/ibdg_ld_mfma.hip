@@ -805,14 +805,17 @@ void k_ld_mfma(MfmaArgs a)
 #endif
 }
 
-// The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group).
-// IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four part sums of a slot meet as
-// ((j0 + j1) + j2) + j3.  IBD0 does not depend on the comparison individual except for its own exclusion (:714): lane q < 16
-// adds the chunks' sums of the one pass over the site list (p2c, in chunk order) with, in place of the chunk its individual
-// sits in, that chunk's 63 other products (p2w, in lane order).  Fixed orders: the same bits every run.
-__global__ __launch_bounds__(64) void k_ld_finalize_g(MfmaArgs a, const int *__restrict__ n_refpanel, double *__restrict__ win_ll)
+// The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group), four windows
+// a workgroup.  IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four part sums of a
+// slot meet as ((j0 + j1) + j2) + j3.  IBD0 does not depend on the comparison individual except for its own exclusion
+// (:714): for each slot in turn the wave reads, one lane an individual, the 64 products of the chunk the slot's individual
+// sits in (p2w of the one pass over the site list; its own lane counts 0) and, one lane a chunk, the other chunks' sums
+// (p2c), and adds the 64 lanes up in the fixed order of wave_sum_to_lane63.  Fixed orders: the same bits every run.
+__global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__restrict__ n_refpanel, double *__restrict__ win_ll)
 {
-    const uint32_t w = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), grp = blockIdx.y, lane = threadIdx.x & 63;
+    if (w >= a.n_win)
+        return;
     const uint32_t n_half = 2 * a.n_chunks, q = lane & 15, j = lane >> 4;
     const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
     const double *t1 = a.part_t1 + (((size_t)grp * a.n_win + w) * n_half) * 16;
@@ -821,19 +824,25 @@ __global__ __launch_bounds__(64) void k_ld_finalize_g(MfmaArgs a, const int *__r
         acc += t1[(size_t)hc * 16 + q];
     const double a1 = __shfl(acc, q + 16), a2 = __shfl(acc, q + 32), a3 = __shfl(acc, q + 48);
     const double s1 = ((acc + a1) + a2) + a3;                  // (lanes 0..15 hold the totals)
-    const bool real = lane < cnt;
-    if (real) {
+    const double *pc = a.p2c + (size_t)w * a.n_chunks * 2;
+    const double *pw = a.p2w + (size_t)w * a.lanes;
+    const double pc_lane = lane < a.n_chunks ? pc[2 * lane] : 0.0;
+    double s0 = 0.0;                                           // lane qq: slot qq's sum
+    for (uint32_t qq = 0; qq < cnt; ++qq) {
+        const uint32_t tgt = a.targets[a.t_base + grp * TG + qq];      // (the same for the whole wave)
+        const uint32_t c_own = tgt >> 6;                       // the chunk (64 individuals) the slot's own individual sits in
+        double v = pw[64 * (size_t)c_own + lane];
+        v = lane == (tgt & 63) ? 0.0 : v;
+        v += lane == c_own ? 0.0 : pc_lane;
+        for (uint32_t c = lane + 64; c < a.n_chunks; c += 64)  // (panels of more than 4096 individuals)
+            v += c == c_own ? 0.0 : pc[2 * c];
+        const double tot = wave_sum_to_lane63(v);
+        const double all = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 63),
+                                            __builtin_amdgcn_readlane(__double2loint(tot), 63));
+        s0 = lane == qq ? all : s0;
+    }
+    if (lane < cnt) {
         const uint32_t t = a.t_base + grp * TG + lane;
-        const uint32_t tgt = a.targets[t];
-        const uint32_t c_own = tgt >> 6;                         // the chunk (64 individuals) the slot's own individual sits in
-        const double *pc = a.p2c + (size_t)w * a.n_chunks * 2;
-        const double *pw = a.p2w + (size_t)w * a.lanes + 64 * (size_t)c_own;
-        double own = 0.0;
-        for (uint32_t i = 0; i < 64; ++i)
-            own += 64 * c_own + i == tgt ? 0.0 : pw[i];
-        double s0 = 0.0;
-        for (uint32_t c = 0; c < a.n_chunks; ++c)
-            s0 += c == c_own ? own : pc[2 * c];
         const int nref = n_refpanel[t];
         const double mK = a.wconst[w].mK;             // mantissa of K' (its exponent went into every term)
         double *o = win_ll + ((size_t)t * a.n_win + w) * 3;
@@ -846,7 +855,7 @@ void launch_ld_finalize_g(const MfmaArgs &a, unsigned n_groups, const int *n_ref
 {
     if (a.n_win == 0 || n_groups == 0)
         return;
-    hipLaunchKernelGGL(k_ld_finalize_g, dim3(a.n_win, n_groups), dim3(64), 0, st, a, n_refpanel, win_ll);
+    hipLaunchKernelGGL(k_ld_finalize_g, dim3((a.n_win + 3) / 4, n_groups), dim3(256), 0, st, a, n_refpanel, win_ll);
 }
 
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st)
