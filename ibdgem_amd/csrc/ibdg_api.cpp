@@ -134,6 +134,11 @@ struct ibdg_ctx {
     uint64_t p2_gen = 0, p2_bg_gen = 0;     // sites_gen / bg_gen the pass was made for
     int p2_mx = -1;
     uint64_t bg_gen = 1;                    // bumped whenever the background multiplicities change
+    // single comparison individuals take their IBD0 terms from that pass too once their runs on one upload and background
+    // have added up to "ibd0_after" individuals (the pass costs about one run and saves a fifth of every later one)
+    long opt_ibd0_after = 8;                // 0: never
+    uint64_t ibd0_runs = 0, ibd0_bg_gen = 0;
+    int wt_ibd1 = -1;                       // form of the images in wtarget / twords
     // pow1/pow2: rho^n, sigma^n as {f64 mantissa, i32 exponent}; powb: (1-eps)^n in the x87 format
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
@@ -1223,6 +1228,7 @@ static int upload_sites_core(ibdg_ctx *c, const uint32_t *d_row, const uint8_t *
     }
     ++c->sites_gen;
     c->relayout_credit = 0;
+    c->ibd0_runs = 0;
     c->seg_room = c->pop_lut_ok ? seg_room : 0;
     c->compact = false;
     if (n_sites) {
@@ -1767,6 +1773,54 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // a tenth of a step on an eighth of a chromosome -- is left to the NEXT run's --LD launch, whose first workgroups
         // do it on the way (the kernel boundary between the two launches is all the ordering it needs), and this run's
         // launch does the same for its predecessor.  The partial sums alternate between two halves of their buffer.
+        // The IBD0 terms of this site list and background, once: a pass of the counting kernel that keeps every lane's weighted
+        // product (p2_out) and its sums per chunk; the images it reads are those of the run's first individual.
+        const bool p2_stale = c->p2_gen != c->sites_gen || c->p2_bg_gen != c->bg_gen || c->p2_mx != mx_counts;
+        auto ibd0_pass = [&]() -> int {
+            if (c->fin_pending && flush_finalize(c))
+                return 1;
+            if (settle_ready())
+                return 1;
+            if (ensure(c, c->p2w, (size_t)c->n_win * lanes * 8) || ensure(c, c->p2c, (size_t)c->n_win * c->n_chunks * 16) ||
+                ensure(c, c->p2_tw, (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
+                ensure(c, c->p2_wt, (size_t)c->n_win * 32))
+                return 1;
+            ibdg::PopArgs pp = pa;
+            pp.rec_ready = (const uint32_t *)c->p2_tw.p;
+            pp.wc_ready = (const uint32_t *)c->p2_wt.p;
+            pp.weight = (const double *)c->base_w.p;
+            pp.t_base = 0;
+            pp.partial = (double *)c->p2c.p;
+            pp.p2_out = (double *)c->p2w.p;
+            pp.fin_prev = nullptr;
+            pp.ibd1 = 0;
+            pp.ring_slots = (uint32_t)c->seg_ring;
+            pp.tab_len = c->ct_max + 1;
+            pp.tab_in_lds = (uint32_t)c->tab_in_lds;
+            pp.mx_counts = (uint32_t)mx_counts;
+            pp.rho_shift = (uint32_t)rho_shift;
+            pp.sum_dpp = (uint32_t)c->opt_sum_dpp;
+            ibdg::launch_win_target(pp, 1, c->stream);
+            if (ibdg::launch_ld_popcount(pp, 1, c->planes, c->stream))
+                return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
+            c->p2_gen = c->sites_gen;
+            c->p2_bg_gen = c->bg_gen;
+            c->p2_mx = mx_counts;
+            return 0;
+        };
+        // single individuals in the IBD1 form (counts on the matrix cores, tables in LDS): at once where the pass exists,
+        // otherwise when the runs on this upload and background have added up
+        bool ibd1 = false;
+        if (T_one && mx_counts && c->tab_in_lds && c->opt_ibd0_after > 0) {
+            if (c->ibd0_bg_gen != c->bg_gen) {
+                c->ibd0_bg_gen = c->bg_gen;
+                c->ibd0_runs = 0;
+            }
+            c->ibd0_runs += T_one;
+            ibd1 = !p2_stale || (n_gg > 0) || c->ibd0_runs >= (uint64_t)c->opt_ibd0_after;
+        }
+        if (p2_stale && (n_gg > 0 || ibd1) && ibd0_pass())
+            return 1;
         const bool fin_in_next = c->opt_fin_next && c->opt_async && T_one > 0 && T_one == T_cnt && n_gg == 0;
         if (c->fin_pending && (!fin_in_next || c->fin_count != (unsigned)T_cnt || c->fin_args.t_base != (uint32_t)T_g) &&
             flush_finalize(c))
@@ -1776,6 +1830,9 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             pa.fin_prev = c->fin_args.partial;
             pa.n_refpanel = c->fin_args.n_refpanel;      // (of the run that left it: its entry of the ring)
             pa.win_ll = (double *)c->win_ll.p;
+            pa.fin_p2c = c->fin_args.p2c;                // (non-null: that run was of the IBD1 form)
+            pa.fin_p2w = c->fin_args.p2w;
+            pa.fin_targets = c->fin_args.targets;
             c->fin_pending = false;
         }
         pa.ring_slots = (uint32_t)c->seg_ring;
@@ -1814,28 +1871,6 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.plain_tau = c->opt_mfma_plain_tau ? 1u : 0u;
             ma.targets = pa.targets;
             ma.base_weight = (const double *)c->base_w.p;
-            if (c->p2_gen != c->sites_gen || c->p2_bg_gen != c->bg_gen || c->p2_mx != mx_counts) {
-                // the IBD0 terms of this site list and background, once: a pass of the counting kernel that keeps every lane's
-                // weighted product (p2_out) and its sums per chunk; the images it reads are those of the run's first individual
-                if (ensure(c, c->p2w, (size_t)c->n_win * lanes * 8) || ensure(c, c->p2c, (size_t)c->n_win * c->n_chunks * 16) ||
-                    ensure(c, c->p2_tw, (size_t)c->n_segs * ibdg::ld_popcount_rec_bytes(mx_counts)) ||
-                    ensure(c, c->p2_wt, (size_t)c->n_win * 32))
-                    return 1;
-                ibdg::PopArgs pp = pa;
-                pp.rec_ready = (const uint32_t *)c->p2_tw.p;
-                pp.wc_ready = (const uint32_t *)c->p2_wt.p;
-                pp.weight = (const double *)c->base_w.p;
-                pp.t_base = 0;
-                pp.partial = (double *)c->p2c.p;
-                pp.p2_out = (double *)c->p2w.p;
-                pp.fin_prev = nullptr;
-                ibdg::launch_win_target(pp, 1, c->stream);
-                if (ibdg::launch_ld_popcount(pp, 1, c->planes, c->stream))
-                    return fail(c, "[::] ERROR in ibdg_run: unsupported number of weight bit-planes %d", c->planes);
-                c->p2_gen = c->sites_gen;
-                c->p2_bg_gen = c->bg_gen;
-                c->p2_mx = mx_counts;
-            }
             ma.p2w = (const double *)c->p2w.p;
             ma.p2c = (const double *)c->p2c.p;
             ma.lanes = (uint32_t)lanes;
@@ -1883,7 +1918,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             // eighth of a chromosome is a tenth of the step)
             const bool wt_cached = same_inputs && c->wt_gen == c->sites_gen && c->wt_first == pa.t_base &&
                                    c->wt_count == (uint32_t)T_one && c->wt_mx == mx_counts && c->wt_slot == c->tg_cur &&
-                                   !dispatch_events;
+                                   c->wt_ibd1 == (int)ibd1 && !dispatch_events;
+            pa.ibd1 = ibd1 ? 1u : 0u;
             // a new individual's images: on stream3 with its weights (under the --LD kernel of the run before) unless the
             // launch carries the run's start event (dispatch_events: that belongs on the main stream)
             const bool wt_ahead = need_ready && !dispatch_events;
@@ -1903,7 +1939,8 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             c->wt_first = pa.t_base;
             c->wt_count = (uint32_t)T_one;
             c->wt_mx = mx_counts;
-            c->last_count_unit = mx_counts ? 2 : 1;
+            c->wt_ibd1 = (int)ibd1;
+            c->last_count_unit = mx_counts ? (ibd1 ? 3 : 2) : 1;
             // (option "end_in_dispatch": the run's end event is the --LD kernel's own completion signal -- no event packet
             // of its own behind the kernel -- where that kernel is the run's last launch on the main stream)
             if (c->opt_end_in_dispatch && fin_in_next && !dispatch_events && T_one == T) {
@@ -1923,6 +1960,12 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             fa.partial = pa.partial;
             fa.t_base = (uint32_t)T_g;
             fa.halves = 0;
+            if (ibd1) {                      // (whatever kernel made an individual's IBD1 sums)
+                fa.p2c = (const double *)c->p2c.p;
+                fa.p2w = (const double *)c->p2w.p;
+                fa.targets = pa.targets;
+                fa.lanes = (uint32_t)lanes;
+            }
             if (fin_in_next) {
                 c->fin_pending = true;
                 c->fin_args = fa;
@@ -2220,6 +2263,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_compact_align = value;
         return 0;
     }
+    if (!strcmp(name, "ibd0_after")) { c->opt_ibd0_after = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "end_in_dispatch")) { c->opt_end_in_dispatch = value != 0; return 0; }
     if (!strcmp(name, "prep_ahead")) { c->opt_prep_ahead = value != 0; return 0; }
     if (!strcmp(name, "dispatch_events")) { c->opt_dispatch_events = value != 0; return 0; }

@@ -130,6 +130,12 @@ struct PopArgs {
     double *p2_out = nullptr;   // k_ld_popcount: [n_win][lanes] every lane's weighted product of its individual's OWN genotype
                                 // factors (src/ibdgem.c:715, :743) -- what does not depend on the comparison individual; the
                                 // matrix-core kernel's launches take it from there (once per site list and background)
+    // Round 5: with that pass made, a single comparison individual's launch leaves the IBD0 terms out altogether
+    // (k_ld_popcount<.., IBD1 = true>): its matrix instructions return the table exponents of the four IBD1 products
+    // themselves, and the finalising step takes IBD0 from the pass (ibd0_from_pass in ibdg_ld_dev.h).
+    uint32_t ibd1 = 0;          // 1: images (k_win_target_mx) and kernel of that form; needs mx_counts and tab_in_lds
+    const double *fin_p2c = nullptr, *fin_p2w = nullptr;   // fin_prev's run was of that form: the pass's sums per chunk / per individual
+    const uint32_t *fin_targets = nullptr;                 // ... and its comparison individuals (that run's entry of the ring)
 };
 
 // events a dispatch updates with its own start / stop time (either may be null)
@@ -146,6 +152,9 @@ struct PopFinalArgs {
     uint32_t t_base = 0;        // first comparison individual of the launch
     uint32_t halves = 0;        // 1: partial sums per half chunk (k_ld_mfma); a chunk's sum is half 0 + half 1
     uint32_t p_t0 = 0;          // comparison individual whose partial sums come first in `partial`
+    const double *p2c = nullptr, *p2w = nullptr;   // non-null: IBD0 from the one pass over the site list (PopArgs::ibd1 runs)
+    const uint32_t *targets = nullptr;
+    uint32_t lanes = 0;
 };
 
 // ---- many comparison individuals against one panel: the G(x,t) sums as integer matrix products ----------

@@ -38,6 +38,28 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     return v;
 }
 
+// IBD0 of window w for comparison individual tgt from the ONE pass over the site list that keeps what does not depend on the
+// comparison individual (src/ibdgem.c:714-715, :743: its own exclusion is all that does): the chunks' sums p2c[w][chunk][2]
+// with, in place of the chunk the individual sits in, that chunk's 63 other weighted products p2w[w][lanes] -- masked, not
+// subtracted: the own term can dominate the sum.  The additions are those of a launch that counts the IBD0 terms itself, in
+// its order -- a chunk's 64 products meet in the balanced tree over the lane number's bits that wave_sum2 and
+// wave_sum_to_lane63 share, the chunks' sums one lane a chunk and then in that tree again (k_ld_finalize) --, so the result is
+// the same BITS whichever form a run took.  The total ends up in lane 63.
+__device__ __forceinline__ double ibd0_from_pass(const double *__restrict__ p2c, const double *__restrict__ p2w, uint32_t lanes,
+                                                 uint32_t n_chunks, uint32_t w, uint32_t tgt, uint32_t lane)
+{
+    const uint32_t c_own = tgt >> 6;
+    const double *pc = p2c + (size_t)w * n_chunks * 2;
+    double v = p2w[(size_t)w * lanes + 64 * (size_t)c_own + lane];
+    v = wave_sum_to_lane63(lane == (tgt & 63) ? 0.0 : v);
+    const double own = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                                        __builtin_amdgcn_readlane(__double2loint(v), 63));
+    double t0 = 0.0;
+    for (uint32_t c = lane; c < n_chunks; c += 64)
+        t0 += c == c_own ? own : pc[2 * c];
+    return wave_sum_to_lane63(t0);
+}
+
 // v + (v of lane ^ X within the 32-lane half) through the LDS crossbar (ds_swizzle, bit mode): no VALU
 // move, no LDS memory -- the exchange is issued on the LDS port beside other waves' arithmetic.
 template <int X>

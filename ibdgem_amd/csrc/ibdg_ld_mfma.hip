@@ -809,8 +809,9 @@ void k_ld_mfma(MfmaArgs a)
 // a workgroup.  IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four part sums of a
 // slot meet as ((j0 + j1) + j2) + j3.  IBD0 does not depend on the comparison individual except for its own exclusion
 // (:714): for each slot in turn the wave reads, one lane an individual, the 64 products of the chunk the slot's individual
-// sits in (p2w of the one pass over the site list; its own lane counts 0) and, one lane a chunk, the other chunks' sums
-// (p2c), and adds the 64 lanes up in the fixed order of wave_sum_to_lane63.  Fixed orders: the same bits every run.
+// sits in (p2w of the one pass over the site list; its own lane counts 0), adds them up, and then, one lane a chunk, that
+// sum and the other chunks' sums (p2c) -- the additions of ibd0_from_pass (ibdg_ld_dev.h), which are those of a single
+// comparison individual's own launch: IBD0 is the same bits whichever kernel served the individual.
 __global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__restrict__ n_refpanel, double *__restrict__ win_ll)
 {
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), grp = blockIdx.y, lane = threadIdx.x & 63;
@@ -832,11 +833,13 @@ __global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__
         const uint32_t tgt = a.targets[a.t_base + grp * TG + qq];      // (the same for the whole wave)
         const uint32_t c_own = tgt >> 6;                       // the chunk (64 individuals) the slot's own individual sits in
         double v = pw[64 * (size_t)c_own + lane];
-        v = lane == (tgt & 63) ? 0.0 : v;
-        v += lane == c_own ? 0.0 : pc_lane;
+        v = wave_sum_to_lane63(lane == (tgt & 63) ? 0.0 : v);
+        const double own = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+        double t0 = lane == c_own ? own : pc_lane;
         for (uint32_t c = lane + 64; c < a.n_chunks; c += 64)  // (panels of more than 4096 individuals)
-            v += c == c_own ? 0.0 : pc[2 * c];
-        const double tot = wave_sum_to_lane63(v);
+            t0 += c == c_own ? own : pc[2 * c];
+        const double tot = wave_sum_to_lane63(t0);
         const double all = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 63),
                                             __builtin_amdgcn_readlane(__double2loint(tot), 63));
         s0 = lane == qq ? all : s0;

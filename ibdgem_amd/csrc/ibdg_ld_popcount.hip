@@ -302,18 +302,30 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
         const Seg &S = a.segs[sg];
         const uint2 at = tile_words(tt, S.tile);
         uint32_t p0, p1, p2;
-        if (sum == 1) {
+        if (sum == 1 && !a.ibd1) {
             p0 = S.alt[0]; p1 = S.alt[1]; p2 = S.alt[2];
         } else {
-            const uint32_t m = sum == 0 ? 0xffffffffu : sum == 2 ? at.x : at.y;
+            const uint32_t m = a.ibd1 ? 0xffffffffu : sum == 0 ? 0xffffffffu : sum == 2 ? at.x : at.y;
             p0 = S.cov[0] & m; p1 = S.cov[1] & m; p2 = S.cov[2] & m;
         }
+        // (ibd1: the four sums are the table exponents of the IBD1 products themselves, up to the window's constants --
+        //  sums 0 / 1: <x, cov (1 - 2 t)> = C(x) - 2 G(x,t) for t = t0 / t1, sums 2 / 3: <x, t cov - alt> = G(x,t) - A(x):
+        //  signed weights of magnitude <= 7, the sign is bit 5 of the e2m3 code)
+        const uint32_t tb = (sum & 1) ? at.y : at.x;
         uint32_t f[6] = {0, 0, 0, 0, 0, 0};   // 32 x 6 bits
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             const int d = k >> 3, r = 4 * (k & 7) + d;
-            const uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
-            const uint32_t code = fp6_weight_code(w, d);
+            uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
+            uint32_t neg = 0;
+            if (a.ibd1) {
+                const int tr = (int)((tb >> r) & 1u);
+                const int av = (int)(((S.alt[0] >> r) & 1u) | (((S.alt[1] >> r) & 1u) << 1) | (((S.alt[2] >> r) & 1u) << 2));
+                const int sv = sum < 2 ? (tr ? -(int)w : (int)w) : (tr ? (int)w : 0) - av;
+                neg = sv < 0 ? 0x20u : 0u;
+                w = (uint32_t)(sv < 0 ? -sv : sv);
+            }
+            const uint32_t code = fp6_weight_code(w, d) | neg;
             const int pos = 6 * k, wd = pos >> 5, sh = pos & 31;
             f[wd] |= code << sh;
             if (sh > 26)
@@ -363,8 +375,11 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
             const uint32_t AT = wcs[4];
             // byte offsets into tables of 8-byte entries (the matrix-core form's power tables, see its window end)
             const uint32_t sc = a.tab_in_lds ? 8 : 16;       // (16-byte entries where the tables stay in global memory)
-            o[0] = make_uint4(wcs[2], sc * AT, sc * a0cov, sc * a1cov);
-            o[1] = make_uint4(sc * (AT - a0alt), sc * (AT - a1alt), 0, 0);
+            // (ibd1: the sums reach the window end as the bits of 1.5 * 2^23 + sum, whose low 24 bits are 2^22 + sum: the constants
+            //  take 8 * 2^22 back, modulo 2^32 like the address arithmetic they enter)
+            const uint32_t bias = a.ibd1 ? 1u << 25 : 0u;
+            o[0] = make_uint4(wcs[2], sc * AT, sc * a0cov - bias, sc * a1cov - bias);
+            o[1] = make_uint4(sc * (AT - a0alt) - bias, sc * (AT - a1alt) - bias, 0, 0);
         }
     }
 }
@@ -757,7 +772,81 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
         ++s;                                                                                                    \
     }
 
-template <int NS, bool TAB_LDS, bool MX>
+// The IBD1 form (PopArgs::ibd1): no counts for the individual's own genotype factors -- their products come from the one pass
+// over the site list --, and the four sums of a word are the table exponents themselves (k_win_target_mx); a window's first
+// segment starts the accumulators from 1.5 * 2^23, so that their BITS hold the (signed) sums.
+#define IBDG_SEGMENT_X1(FIRST)                                                                                     \
+    {                                                                                                           \
+        uint4 h0;                                                                                               \
+        uint2 x;                                                                                                \
+        lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                              \
+        flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
+        const uint32_t adv = flags >> 16;                                                                       \
+        if (adv) {                                                                                              \
+            for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
+                __builtin_amdgcn_global_load_lds((const void *)(xt + (size_t)(q_issue < q_last ? q_issue : q_last) * 64), \
+                                                 (lds_void *)(ring + ((q_issue - q0) % NS) * 1024), 16, 0, IBDG_TILE_AUX);  \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 1) : "memory");                                       \
+        }                                                                                                       \
+        x_off = flags & 0x3fff;                                                                                 \
+        {                                                                                                       \
+            const mx_v8i av = {(int)af_lo.x, (int)af_lo.y, (int)af_lo.z, (int)af_lo.w, (int)af_hi.x, (int)af_hi.y, 0, 0}; \
+            acc0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.x), FIRST ? bias4 : acc0, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
+            acc1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bits_to_fp4(x.y), FIRST ? bias4 : acc1, 2, 4, 0, \
+                                                                    0x7f80, 1, 0x7f80);                         \
+        }                                                                                                       \
+        if (flags & (1u << 14)) {                                                                               \
+            const uint4 h1 = lds_read_b128(rec_addr + 16);                                                      \
+            const uint2 at = make_uint2(h1.x, h1.y);                                                            \
+            const uint32_t nn = __builtin_amdgcn_readfirstlane(h1.z), ncov = nn & 0xff, nalt = nn >> 8;         \
+            for (uint32_t k = 3; k < ncov; ++k) {                                                               \
+                const uint32_t cov = segs[seg0 + s].cov[k];              /* uniform: scalar load */             \
+                const uint32_t u0 = x.x & cov, u1 = x.y & cov;                                                  \
+                const int c0 = __popc(u0), c1 = __popc(u1), m = 1 << k;                                         \
+                const int g00 = __popc(u0 & at.x), g01 = __popc(u1 & at.x);                                     \
+                const int g10 = __popc(u0 & at.y), g11 = __popc(u1 & at.y);                                     \
+                acc0[0] += (float)((c0 - 2 * g00) * m);                                                         \
+                acc0[1] += (float)((c0 - 2 * g10) * m);                                                         \
+                acc0[2] += (float)(g00 * m);                                                                    \
+                acc0[3] += (float)(g10 * m);                                                                    \
+                acc1[0] += (float)((c1 - 2 * g01) * m);                                                         \
+                acc1[1] += (float)((c1 - 2 * g11) * m);                                                         \
+                acc1[2] += (float)(g01 * m);                                                                    \
+                acc1[3] += (float)(g11 * m);                                                                    \
+            }                                                                                                   \
+            for (uint32_t k = 3; k < nalt; ++k) {                                                               \
+                const uint32_t alt = segs[seg0 + s].alt[k];                                                     \
+                const float a0 = (float)((uint32_t)__popc(x.x & alt) << k), a1 = (float)((uint32_t)__popc(x.y & alt) << k); \
+                acc0[2] -= a0;                                                                                  \
+                acc0[3] -= a0;                                                                                  \
+                acc1[2] -= a1;                                                                                  \
+                acc1[3] -= a1;                                                                                  \
+            }                                                                                                   \
+        }                                                                                                       \
+        rec_addr += IBDG_RECX_WORDS * 4;                                                                        \
+        frag_addr += IBDG_RECX_WORDS * 4;                                                                       \
+        ++s;                                                                                                    \
+    }
+
+// eight 8-byte power-table entries (the four IBD1 products of the IBD1 form)
+__device__ __forceinline__ void lds_read_pow8_b64(uint2 (&p)[8], const uint32_t (&ad)[8])
+{
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %9\n\t"
+                 "ds_read_b64 %2, %10\n\t"
+                 "ds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12\n\t"
+                 "ds_read_b64 %5, %13\n\t"
+                 "ds_read_b64 %6, %14\n\t"
+                 "ds_read_b64 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                 : "memory");
+}
+
+template <int NS, bool TAB_LDS, bool MX, bool IBD1 = false>
 __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t32,
                                                      const Seg *__restrict__ segs,
                                                      const uint32_t *__restrict__ rec_ready,
@@ -792,7 +881,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     t0 += v.x;
                     t1 += v.y;
                 }
-                t0 = wave_sum_to_lane63(t0);
+                t0 = a.fin_p2c ? ibd0_from_pass(a.fin_p2c, a.fin_p2w, a.lanes, a.n_chunks, w, a.fin_targets[tt], lane)
+                               : wave_sum_to_lane63(t0);
                 t1 = wave_sum_to_lane63(t1);
                 if (lane == 63) {
                     const int nref = a.n_refpanel[tt];
@@ -911,6 +1001,62 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     mx_u4 af_lo = {0, 0, 0, 0};
     mx_u2 af_hi = {0, 0};
     uint32_t frag_addr = rec_addr + 32 + 24 * (lane & 3);
+    if constexpr (IBD1) {
+        static_assert(MX && TAB_LDS, "the IBD1 form exists with the counts on the matrix cores and the tables in LDS");
+        // 1.5 * 2^23 in four registers that stay: the start value of a window's accumulators (an inline constant it is not)
+        mx_v4f bias4 = {12582912.f, 12582912.f, 12582912.f, 12582912.f};
+        asm volatile("" : "+v"(bias4));
+        const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+        // one window: its segments, then the four IBD1 products of the lane's individual (:716-719, :744-745) times its multiplicity
+        auto window_sum = [&](uint32_t w) __attribute__((always_inline)) -> double {
+            uint32_t flags;
+            IBDG_SEGMENT_X1(true)
+            while (!(flags & (1u << 15)))
+                IBDG_SEGMENT_X1(false)
+            uint4 k0, k1;
+            lds_read2(k0, k1, wc_base + (w - w0) * (IBDG_WC_WORDS * 4), wc_base + (w - w0) * (IBDG_WC_WORDS * 4) + 16);
+            const int eK = (int)k0.x;
+            const uint32_t kc0 = k0.z, kc1 = k0.w, kb0 = k1.x, kb1 = k1.y;     // (less 8 * 2^22 each, k_win_target_mx)
+            // acc[0] / [1] = C(x) - 2 G(x,t0 / t1), acc[2] / [3] = G(x,t0 / t1) - A(x); v_mad_i32_i24 reads the low 24 bits of the
+            // accumulator's own bits.  Products in the order of the other forms: (t0,x0) (t0,x1) (t1,x0) (t1,x1).
+            uint32_t ad[8];
+            ad[0] = mad24<8>(__float_as_uint(acc0[2]), kb0);   ad[1] = mad24<8>(__float_as_uint(acc0[0]), kc0);
+            ad[2] = mad24<8>(__float_as_uint(acc1[2]), kb0);   ad[3] = mad24<8>(__float_as_uint(acc1[0]), kc0);
+            ad[4] = mad24<8>(__float_as_uint(acc0[3]), kb1);   ad[5] = mad24<8>(__float_as_uint(acc0[1]), kc1);
+            ad[6] = mad24<8>(__float_as_uint(acc1[3]), kb1);   ad[7] = mad24<8>(__float_as_uint(acc1[1]), kc1);
+            uint2 pq[8];
+            lds_read_pow8_b64(pq, ad);
+            double val[4];
+            if (a.rho_shift == 8) {
+                const uint32_t e1 = (uint32_t)eK + tab1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
+                    const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
+                    val[i] = __builtin_ldexp(m1 * m2, (int)(e1 - ad[2 * i]));
+                }
+            } else {
+                const uint32_t e8 = mad24r(tab1, a.rho_shift, (uint32_t)eK << 3);
+                const uint32_t ms = 0u - a.rho_shift;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double m1 = __hiloint2double((int)pq[2 * i].y, (int)pq[2 * i].x);
+                    const double m2 = __hiloint2double((int)pq[2 * i + 1].y, (int)pq[2 * i + 1].x);
+                    val[i] = __builtin_ldexp(m1 * m2, (int)mad24r(ad[2 * i], ms, e8) >> 3);
+                }
+            }
+            return wgt * (((val[0] + val[1]) + val[2]) + val[3]);
+        };
+        // the sum over the wave's 64 individuals in the tree of wave_sum2 (the lane number's bits in turn), by DPP moves alone:
+        // this form has no scratch in LDS -- what that frees is a third ring slot per wave at the same four workgroups a CU
+        for (uint32_t w = w0; s < nseg; ++w) {
+            const double tot = wave_sum_to_lane63(window_sum(w));
+            if (lane == 63)
+                a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + 1] = tot;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     for (uint32_t w = w0; s < nseg; ++w) {               // one window per turn (a run's windows are consecutive)
         uint32_t flags;
         if constexpr (MX) {
@@ -1021,6 +1167,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
 
 #undef IBDG_SEGMENT
 #undef IBDG_SEGMENT_MX
+#undef IBDG_SEGMENT_X1
 
 // ---------------------------------------------------------------------------
 // Several comparison individuals per workgroup (BASELINE.json configs[4]: hundreds of them against
@@ -1383,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
             t1 += v.y;
         }
     }
-    t0 = wave_sum_to_lane63(t0);
+    t0 = a.p2c ? ibd0_from_pass(a.p2c, a.p2w, a.lanes, a.n_chunks, w, a.targets[t], lane) : wave_sum_to_lane63(t0);
     t1 = wave_sum_to_lane63(t1);
     if (lane == 63) {
         const int nref = a.n_refpanel[t];
@@ -1437,6 +1584,8 @@ size_t ld_popcount_rec_bytes(int mx_counts) { return (mx_counts ? IBDG_RECX_WORD
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,
                              int ring_slots, int multi_target)
 {
+    if (multi_target == 3)       // the IBD1 form of 2: no scratch
+        return ld_popcount_lds_bytes(max_seg, win_per_group, tab_len, tab_in_lds, ring_slots, 2) - 8 * 1024;
     // multi_target: 0 = one comparison individual (vector-ALU counts), 1 = groups of IBDG_MT, 2 = one, counts on the matrix cores
     const size_t rec_words = multi_target == 1 ? IBDG_RECM_WORDS : multi_target == 2 ? IBDG_RECX_WORDS : IBDG_REC_WORDS;
     const size_t wc_words = multi_target == 1 ? IBDG_WCM_WORDS : IBDG_WC_WORDS;
@@ -1446,11 +1595,11 @@ size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t 
     return ((head + 1023) & ~(size_t)1023) + 8 * (size_t)ring_slots * 1024 + 8 * 1024;    // rings + wave_sum2 scratch
 }
 
-template <int NS, bool TAB, bool MX>
+template <int NS, bool TAB, bool MX, bool IBD1 = false>
 static int launch_pop(const PopArgs &a, dim3 grid, hipStream_t st, KernelEvents ev)
 {
-    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, MX ? 2 : 0);
-    auto kern = k_ld_popcount<NS, TAB, MX>;
+    const size_t lds = ld_popcount_lds_bytes(a.max_seg, a.win_per_group, a.tab_len, TAB, NS, IBD1 ? 3 : MX ? 2 : 0);
+    auto kern = k_ld_popcount<NS, TAB, MX, IBD1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
@@ -1467,6 +1616,17 @@ int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStre
     if (planes < 1 || planes > 8)
         return 1;
     dim3 grid(a.n_runs * a.n_cgroups + (a.fin_prev ? (a.n_win + a.waves_per_group - 1) / a.waves_per_group : 0), 1, n_targets);
+    if (a.ibd1) {
+        if (!a.mx_counts || !a.tab_in_lds || a.p2_out)
+            return 1;
+        if (a.ring_slots == 2)
+            return launch_pop<2, true, true, true>(a, grid, st, ev);
+        if (a.ring_slots == 3)
+            return launch_pop<3, true, true, true>(a, grid, st, ev);
+        if (a.ring_slots == 4)
+            return launch_pop<4, true, true, true>(a, grid, st, ev);
+        return launch_pop<8, true, true, true>(a, grid, st, ev);
+    }
     if (a.mx_counts) {
         if (a.ring_slots == 2)
             return a.tab_in_lds ? launch_pop<2, true, true>(a, grid, st, ev) : launch_pop<2, false, true>(a, grid, st, ev);

@@ -183,7 +183,8 @@ def test_config3_chr1_2504_individuals(chr1, oracle):
     eng.set_option("async", 1)
     for k in range(30):
         eng.run([t if k & 1 else other], ld=True)
-    assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2 and eng.last_count_unit() == 2
+    # (... and, from the eighth single run on, with the IBD0 terms from one pass over the site list: ibdg_last_count_unit 3)
+    assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2 and eng.last_count_unit() == 3
     assert (bits(eng.window_ll(0)) == bits(win)).all() and (bits(eng.site_ll(0)) == bits(site)).all()
     eng.run([other], ld=True)
     assert (bits(eng.window_ll(0)) == bits(win_other)).all()

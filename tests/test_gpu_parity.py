@@ -667,9 +667,11 @@ def test_matrix_core_counts_give_the_bits_of_the_vector_counts(oracle, N, L, W, 
     nr = (c - na).astype(np.uint8)
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
     out = {}
-    for mx in (0, 1):
+    for mx in (0, 1, 2):
         with E.Engine(0, eps, M) as eng:
-            eng.set_option("mx_counts", mx)
+            eng.set_option("mx_counts", min(mx, 1))
+            # (2: the IBD1 form from the first run on -- the sums ARE the table exponents, IBD0 from one pass over the site list)
+            eng.set_option("ibd0_after", 1 if mx == 2 else 0)
             eng.set_option("compact_tiles", tiles)
             eng.set_option("ld_variant", 2)
             eng.set_option("mfma_targets", 0)            # (T = 2, 3: single runs of k_ld_popcount, blockIdx.z = individual)
@@ -677,11 +679,14 @@ def test_matrix_core_counts_give_the_bits_of_the_vector_counts(oracle, N, L, W, 
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(np.arange(L), nr, na, W)
             eng.run(targets, ld=True, pu_id=targets[0] if T > 1 else -1)
-            assert eng.last_ld_variant() == 2 and eng.last_count_unit() == 1 + mx
+            assert eng.last_ld_variant() == 2 and eng.last_count_unit() in ((1 + mx,) if mx < 2 else (2, 3))
+            if mx == 2 and (N, W) in ((150, 100), (2504, 100), (90, 100)):
+                assert eng.last_count_unit() == 3            # (the others: tables beyond LDS)
             out[mx] = [(eng.site_ll(i), eng.window_ll(i)) for i in range(T)]
     for i, t in enumerate(targets):
         assert_bits(out[1][i][0], out[0][i][0], f"t={t} per-row values")
         assert_bits(out[1][i][1], out[0][i][1], f"t={t} windows")
+        assert_bits(out[2][i][1], out[0][i][1], f"t={t} windows, IBD1 form")
     res = oracle.compare(alle, nr, na, targets[0], window=W, ld=True, eps=eps, max_cov=M, pu_id=targets[0] if T > 1 else -1)
     assert_bits(out[1][0][1][:, 2], res["win"][:, 2], "LIBD2")
     assert_ld_close(out[1][0][1][:, :2], res["win"][:, :2], "matrix-core counts vs oracle")
@@ -803,7 +808,8 @@ def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
         eng.upload_sites(np.arange(L), nr, na, 100)
         for k in range(9):
             eng.run([targets[k % 2]], ld=True)
-            assert eng.ld_layout() == (1 if k < 6 else 2) and eng.last_count_unit() == 2, k
+            # (the eighth single run on one upload also makes the pass for the IBD0 terms, option ibd0_after: count unit 3)
+            assert eng.ld_layout() == (1 if k < 6 else 2) and eng.last_count_unit() == (2 if k < 7 else 3), k
             assert_bits(eng.window_ll(0), per_run[k % 2][1], f"matrix-core counts, run {k}")
         eng.set_option("compact_targets", 200)
         eng.upload_sites(np.arange(L), nr, na, 100)
@@ -923,6 +929,89 @@ def test_a_new_individual_per_queued_run(oracle):
             eng.set_option("finalize_in_next", 1)
         with pytest.raises(E.EngineError, match="the last run had 3"):
             eng.window_ll_all(2)
+
+
+@pytest.mark.parametrize("tiles", [-1, 1])
+def test_ibd0_from_one_pass_over_the_site_list(oracle, tiles):
+    """What a background individual's own genotype contributes to IBD0 (src/ibdgem.c:715, :743) does not depend on the
+    comparison individual, whose only trace in that sum is its own exclusion (:714): once the single runs on an upload and a
+    background have added up (option "ibd0_after"), ONE pass keeps those products, and later runs count the IBD1 sums only
+    (ibdg_last_count_unit 3: the matrix instruction returns the table exponents themselves).  The additions are the same in
+    the same order, so every run returns the BITS of the form that counts everything -- synchronous, queued with the
+    finalising step inside the next launch or behind its own, with a background list and -N, beside groups of 15 and of 4,
+    after a change of background and after new sites; the oracle agrees."""
+    N, L = 300, 5200
+    alle, nr, na = synth(4711, L, N, cov_mean=2.6)       # (some rows with eight reads or more: the rare-plane path)
+    assert (nr.astype(int) + na).max() >= 8
+    bg = np.random.default_rng(8).integers(0, 3, size=N).astype(np.uint8)
+    bg[[3, 64]] = (2, 1)
+    people = [3, 64, 8, 299, 127, 3, 63, 255, 256, 0]
+    kws = ({}, {"bg_count": bg, "pu_id": 8})
+    want = [{}, {}]
+    with E.Engine() as eng:
+        eng.set_option("compact_tiles", tiles)
+        eng.set_option("ibd0_after", 0)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        for j, kw in enumerate(kws):
+            for t in sorted(set(people)):
+                eng.run([t], ld=True, **kw)
+                assert eng.last_count_unit() == 2
+                want[j][t] = eng.window_ll(0)
+            refids = None if not kw else [n for n in range(N) for _ in range(int(bg[n]))]
+            ref = oracle.compare(alle, nr, na, 64, window=100, ld=True, refids=refids, pu_id=kw.get("pu_id", -1))
+            assert_ld_close(want[j][64][:, :2], ref["win"][:, :2], "the form that counts everything vs oracle")
+    with E.Engine() as eng:
+        eng.set_option("compact_tiles", tiles)
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        assert eng.set_option("ibd0_after", 4) is None
+        for j, kw in enumerate(kws):
+            # the first three runs count everything, the fourth makes the pass; a new background starts over
+            for k, t in enumerate(people):
+                eng.run([t], ld=True, **kw)
+                assert eng.last_count_unit() == (2 if k < 3 else 3), (j, k)
+                assert_bits(eng.window_ll(0), want[j][t], f"run {k} of individual {t}, background {j}")
+            eng.set_option("async", 1)
+            for fin_next in (1, 0):
+                eng.set_option("finalize_in_next", fin_next)
+                for n in (1, 2, 5, len(people)):
+                    for t in people[:n]:
+                        eng.run([t], ld=True, **kw)
+                    assert eng.last_count_unit() == 3
+                    assert_bits(eng.window_ll(0), want[j][people[n - 1]], f"{n} queued runs, finalize_in_next {fin_next}")
+            eng.set_option("finalize_in_next", 1)
+            eng.set_option("async", 0)
+            # three per run (one workgroup each), nineteen (a group of 15 on the matrix cores and four single ones), and with the
+            # groups of four of the vector kernel
+            eng.run([3, 64, 8], ld=True, **kw)
+            for i, t in enumerate([3, 64, 8]):
+                assert_bits(eng.window_ll(i), want[j][t], f"three per run, {t}")
+            many = list(range(100, 109)) + [63, 255, 256, 0, 3, 64, 8, 299, 127]     # 15 + 3
+            eng.run(many, ld=True, **kw)
+            for i, t in enumerate(many):
+                if t in want[j]:
+                    got = eng.window_ll(i)
+                    assert_bits(got[:, 0], want[j][t][:, 0], f"IBD0 of {t} beside a group of 15")
+                    assert_bits(got[:, 2], want[j][t][:, 2], f"IBD2 of {t}")
+                    (assert_bits if i >= 15 else assert_ld_close)(got[:, 1], want[j][t][:, 1], f"IBD1 of {t} beside a group of 15")
+            eng.set_option("mfma_targets", 0)
+            eng.run(many[-7:], ld=True, **kw)                 # a group of four of k_ld_popcount_mt + three single ones
+            for i, t in enumerate(many[-7:]):
+                assert_bits(eng.window_ll(i), want[j][t], f"beside a group of four, {t}")
+            eng.set_option("mfma_targets", 1)
+        # new sites: the count starts over, the old pass is not used
+        half = L // 2
+        eng.upload_sites(np.arange(half), nr[:half], na[:half], 100)
+        eng.run([64], ld=True)
+        assert eng.last_count_unit() == 2
+        first = eng.window_ll(0)
+        for _ in range(4):
+            eng.run([64], ld=True)
+        assert eng.last_count_unit() == 3
+        assert_bits(eng.window_ll(0), first, "after new sites")
+        ref = oracle.compare(alle[:half], nr[:half], na[:half], 64, window=100, ld=True)
+        assert_ld_close(first[:, :2], ref["win"][:, :2], "new sites vs oracle")
 
 
 @pytest.mark.parametrize("variant", [1, 3])

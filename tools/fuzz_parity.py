@@ -61,6 +61,8 @@ for case in range(n_cases):
             eng.set_option("compact_tiles", tiles)
             eng.set_option("compact_targets", int(rng.choice([3, 8, 96])))
             eng.set_option("compact_align", int(rng.choice([1, 1, 1, 32, 4, 16])))
+            # single individuals with their IBD0 terms from one pass over the site list: from the first run, after a few, never
+            eng.set_option("ibd0_after", int(rng.choice([1, 1, 2, 3, 8, 0])))
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
             eng.set_background_order(order)
