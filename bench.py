@@ -983,6 +983,19 @@ def main():
         relayout = {"after_runs": k + 2, "run_ms": (time.perf_counter() - t_r) * 1e3}
     if eng.ld_layout() == layout0:
         relayout = {"after_runs": None, "run_ms": None}
+    # ... and once eight single runs on an upload have gone by, ONE pass keeps what the IBD0 terms have in common for every
+    # comparison individual (option ibd0_after; DESIGN s4.1): later runs count the IBD1 sums only.  Also here, untimed and reported.
+    ibd0_pass = {"after_runs": None, "run_ms": None}
+    runs_so_far = 1 + (relayout["after_runs"] - 1 if relayout["after_runs"] else 0)
+    for k in range(12):
+        if eng.last_count_unit() != 2:
+            break
+        t_r = time.perf_counter()
+        eng.run(targets, ld=True)
+        eng.sync()
+        runs_so_far += 1
+        if eng.last_count_unit() == 3:
+            ibd0_pass = {"after_runs": runs_so_far, "run_ms": (time.perf_counter() - t_r) * 1e3}
     # clock settling (untimed, before the W warm-up steps of the contract): queued steps for --prewarm-ms of wall time
     eng.set_option("async", 1)
     t_pw = time.perf_counter()
@@ -1075,6 +1088,7 @@ def main():
     in_place = None
     if layout_timed == 2 and world == 1:
         eng.set_option("compact_tiles", -1)
+        eng.set_option("ibd0_after", 0)       # (... and every run counts the IBD0 terms itself, as a site list's first runs do)
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
         eng.set_option("async", 1)
         t_pw = time.perf_counter()
@@ -1094,6 +1108,7 @@ def main():
                     "sites_per_s": n_cov / (ip_ms * 1e-3),
                     "hbm_frac": algorithmic_bytes_per_site(args.ids, 1) * n_cov / (ip_ld * 1e-3) / 1e9 / HBM_PEAK_GBS}
         eng.set_option("compact_tiles", 0)
+        eng.set_option("ibd0_after", next((int(kv.split("=")[1]) for kv in args.opt if kv.startswith("ibd0_after=")), 8))
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
     up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov, eng2)
@@ -1294,7 +1309,9 @@ def main():
                                  "`in_place_tiles` is the same step before that") if layout_timed == 2 else
                                 "the panel's own tiles (ld_layout 1)" if layout_timed == 1 else "none (strict kernel)",
                        "sharding": f"{world} contiguous window ranges, no collective on the data path"},
-            "roofline": {"bound": "hbm", "kernel": ("k_ld_popcount (a word's weighted sums by one v_mfma_scale_f32_16x16x128_f8f6f4)"
+            "roofline": {"bound": "hbm", "kernel": ("k_ld_popcount, IBD1 form (a word's four table exponents by one v_mfma_scale_f32_16x16x128_f8f6f4; "
+                                                    "IBD0 from one pass per site list)" if count_unit == 3 else
+                                                    "k_ld_popcount (a word's weighted sums by one v_mfma_scale_f32_16x16x128_f8f6f4)"
                                                     if count_unit == 2 else "k_ld_popcount") if ld_variant == 2 else "k_ld_window",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(args, world)[0],
@@ -1323,6 +1340,14 @@ def main():
                              "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 45, an individual "
                              "of the counting kernels as 12 (16 with mx_counts 0), against compact_targets = 256 (DESIGN s3, s4.1) -- "
                              "null: no re-layout happened"),
+            "ibd0_pass": dict(ibd0_pass, count_unit=count_unit,
+                              note="the run on this upload during which the engine made ONE pass of the counting kernel that keeps every "
+                                   "background individual's own IBD0 product per window (src/ibdgem.c:715, :743: it does not depend on the "
+                                   "comparison individual, whose only trace in that sum is its own exclusion, :714), host wall clock of "
+                                   "that run, untimed; the rule: eight single runs on one upload and background (option ibd0_after); "
+                                   "count_unit 3 = the timed steps count the IBD1 sums only and their finalising step takes IBD0 from "
+                                   "the pass, in the additions of a run that counts everything: same bits (tests/test_gpu_parity.py); "
+                                   "`in_place_tiles` is a step that counts everything, on the panel's own tiles"),
             "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},

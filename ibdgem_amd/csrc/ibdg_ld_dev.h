@@ -60,6 +60,19 @@ __device__ __forceinline__ double ibd0_from_pass(const double *__restrict__ p2c,
     return wave_sum_to_lane63(t0);
 }
 
+// The same additions for lane 63 alone: without the row masks of the two row_bcast steps the other rows take sums nobody
+// reads, and the steps need no zeroed destination (four v_mov less per sum).  Lane 63 holds the bits wave_sum_to_lane63 gives.
+__device__ __forceinline__ double wave_sum_lane63_only(double v)
+{
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    v = dpp_add<0x142, 0xf>(v);     // row_bcast:15: every row takes the total of the row before it (row 0: nothing)
+    v = dpp_add<0x143, 0xf>(v);     // row_bcast:31: lane 31 holds rows 0 + 1 by now, row 3 rows 2 + 3
+    return v;
+}
+
 // v + (v of lane ^ X within the 32-lane half) through the LDS crossbar (ds_swizzle, bit mode): no VALU
 // move, no LDS memory -- the exchange is issued on the LDS port beside other waves' arithmetic.
 template <int X>

@@ -301,31 +301,43 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
         const uint32_t sg = i >> 2, sum = i & 3;
         const Seg &S = a.segs[sg];
         const uint2 at = tile_words(tt, S.tile);
-        uint32_t p0, p1, p2;
-        if (sum == 1 && !a.ibd1) {
-            p0 = S.alt[0]; p1 = S.alt[1]; p2 = S.alt[2];
+        // the rows' weights of this thread's sum as three bit planes of the magnitude and one of the sign (bit 5 of the e2m3 code):
+        //   <x,cov> <x,alt> <x & t0,cov> <x & t1,cov>                            -- the form that counts everything
+        //   <x, cov (1 - 2 t0)>  <x, cov (1 - 2 t1)>  <x, t0 cov - alt>  <x, t1 cov - alt>   -- ibd1: C(x) - 2 G(x,t) and G(x,t) - A(x),
+        //   the table exponents of the IBD1 products up to the window's constants; |weight| <= 7
+        uint32_t p0, p1, p2, neg = 0;
+        if (!a.ibd1) {
+            if (sum == 1) {
+                p0 = S.alt[0]; p1 = S.alt[1]; p2 = S.alt[2];
+            } else {
+                const uint32_t m = sum == 0 ? 0xffffffffu : sum == 2 ? at.x : at.y;
+                p0 = S.cov[0] & m; p1 = S.cov[1] & m; p2 = S.cov[2] & m;
+            }
         } else {
-            const uint32_t m = a.ibd1 ? 0xffffffffu : sum == 0 ? 0xffffffffu : sum == 2 ? at.x : at.y;
-            p0 = S.cov[0] & m; p1 = S.cov[1] & m; p2 = S.cov[2] & m;
+            const uint32_t tb = (sum & 1) ? at.y : at.x;
+            if (sum < 2) {
+                p0 = S.cov[0]; p1 = S.cov[1]; p2 = S.cov[2];
+                neg = tb;                                       // (-0 where the row has no reads: adds nothing)
+            } else {
+                // t cov - alt for the 32 rows at once, bit-sliced: a three-bit subtraction, then the magnitude of the negative ones
+                const uint32_t x0 = S.cov[0] & tb, x1 = S.cov[1] & tb, x2 = S.cov[2] & tb;
+                const uint32_t y0 = S.alt[0], y1 = S.alt[1], y2 = S.alt[2];
+                const uint32_t d0 = x0 ^ y0, b0 = ~x0 & y0;
+                const uint32_t e1 = x1 ^ y1, d1 = e1 ^ b0, b1 = (~x1 & y1) | (~e1 & b0);
+                const uint32_t e2 = x2 ^ y2, d2 = e2 ^ b1;
+                neg = (~x2 & y2) | (~e2 & b1);                  // the borrow out of bit 2: the difference is negative
+                const uint32_t r1 = ~d1 ^ ~d0, r2 = ~d2 ^ (~d1 & ~d0);      // -d = ~d + 1 (bit 0 stays)
+                p0 = d0;
+                p1 = (d1 & ~neg) | (r1 & neg);
+                p2 = (d2 & ~neg) | (r2 & neg);
+            }
         }
-        // (ibd1: the four sums are the table exponents of the IBD1 products themselves, up to the window's constants --
-        //  sums 0 / 1: <x, cov (1 - 2 t)> = C(x) - 2 G(x,t) for t = t0 / t1, sums 2 / 3: <x, t cov - alt> = G(x,t) - A(x):
-        //  signed weights of magnitude <= 7, the sign is bit 5 of the e2m3 code)
-        const uint32_t tb = (sum & 1) ? at.y : at.x;
         uint32_t f[6] = {0, 0, 0, 0, 0, 0};   // 32 x 6 bits
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             const int d = k >> 3, r = 4 * (k & 7) + d;
-            uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
-            uint32_t neg = 0;
-            if (a.ibd1) {
-                const int tr = (int)((tb >> r) & 1u);
-                const int av = (int)(((S.alt[0] >> r) & 1u) | (((S.alt[1] >> r) & 1u) << 1) | (((S.alt[2] >> r) & 1u) << 2));
-                const int sv = sum < 2 ? (tr ? -(int)w : (int)w) : (tr ? (int)w : 0) - av;
-                neg = sv < 0 ? 0x20u : 0u;
-                w = (uint32_t)(sv < 0 ? -sv : sv);
-            }
-            const uint32_t code = fp6_weight_code(w, d) | neg;
+            const uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
+            const uint32_t code = fp6_weight_code(w, d) | (((neg >> r) & 1u) << 5);
             const int pos = 6 * k, wd = pos >> 5, sh = pos & 31;
             f[wd] |= code << sh;
             if (sh > 26)
@@ -416,6 +428,25 @@ __device__ __forceinline__ void lds_fetch_mx(uint4 &h0, uint2 &x, mx_u4 &a_lo, m
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(h0), "=&v"(x), "+v"(a_lo), "+v"(a_hi), "=&s"(exec_was)
                  : "v"(rec_addr), "v"(x_addr), "v"(frag_addr), "s"((uint64_t)IBDG_MX_A_LANES)
+                 : "memory", "scc");
+}
+
+// The same for the IBD1 form, from ONE address register: frag_base = record + 24 * (lane & 3) per lane.  The record's first
+// word (its control word) is read by every lane at its own base -- lane 0's is the record itself, and only lane 0's copy is
+// used (v_readfirstlane) --, the fragment of lane 20 kb + sum sits 32 bytes further on.
+__device__ __forceinline__ void lds_fetch_x1(uint32_t &ctl, uint2 &x, mx_u4 &a_lo, mx_u2 &a_hi, uint32_t x_addr, uint32_t frag_base)
+{
+    uint64_t exec_was;
+    asm volatile("ds_read_b32 %0, %6\n\t"
+                 "ds_read_b64 %1, %5\n\t"
+                 "s_mov_b64 %4, exec\n\t"
+                 "s_and_b64 exec, %4, %7\n\t"
+                 "ds_read2_b64 %2, %6 offset0:4 offset1:5\n\t"
+                 "ds_read_b64 %3, %6 offset:48\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(ctl), "=&v"(x), "+v"(a_lo), "+v"(a_hi), "=&s"(exec_was)
+                 : "v"(x_addr), "v"(frag_base), "s"((uint64_t)IBDG_MX_A_LANES)
                  : "memory", "scc");
 }
 
@@ -777,10 +808,10 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
 // segment starts the accumulators from 1.5 * 2^23, so that their BITS hold the (signed) sums.
 #define IBDG_SEGMENT_X1(FIRST)                                                                                     \
     {                                                                                                           \
-        uint4 h0;                                                                                               \
+        uint32_t ctl;                                                                                           \
         uint2 x;                                                                                                \
-        lds_fetch_mx(h0, x, af_lo, af_hi, rec_addr, ring_lane + x_off, frag_addr);                              \
-        flags = __builtin_amdgcn_readfirstlane(h0.x);                                                           \
+        lds_fetch_x1(ctl, x, af_lo, af_hi, ring_lane + x_off, frag_base);                                       \
+        flags = __builtin_amdgcn_readfirstlane(ctl);                                                            \
         const uint32_t adv = flags >> 16;                                                                       \
         if (adv) {                                                                                              \
             for (uint32_t i = 0; i < adv; ++i, ++q_issue)                                                       \
@@ -797,7 +828,7 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
                                                                     0x7f80, 1, 0x7f80);                         \
         }                                                                                                       \
         if (flags & (1u << 14)) {                                                                               \
-            const uint4 h1 = lds_read_b128(rec_addr + 16);                                                      \
+            const uint4 h1 = lds_read_b128((uint32_t)__builtin_amdgcn_readfirstlane((int)frag_base) + 16);      \
             const uint2 at = make_uint2(h1.x, h1.y);                                                            \
             const uint32_t nn = __builtin_amdgcn_readfirstlane(h1.z), ncov = nn & 0xff, nalt = nn >> 8;         \
             for (uint32_t k = 3; k < ncov; ++k) {                                                               \
@@ -824,8 +855,7 @@ __device__ __forceinline__ void count_alt(uint32_t (&A0)[2], uint32_t (&A1)[2], 
                 acc1[3] -= a1;                                                                                  \
             }                                                                                                   \
         }                                                                                                       \
-        rec_addr += IBDG_RECX_WORDS * 4;                                                                        \
-        frag_addr += IBDG_RECX_WORDS * 4;                                                                       \
+        frag_base += IBDG_RECX_WORDS * 4;                                                                       \
         ++s;                                                                                                    \
     }
 
@@ -1007,6 +1037,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         mx_v4f bias4 = {12582912.f, 12582912.f, 12582912.f, 12582912.f};
         asm volatile("" : "+v"(bias4));
         const uint32_t tab1 = (uint32_t)(uintptr_t)(lds_void *)tab_lds;
+        uint32_t frag_base = rec_addr + 24 * (lane & 3);
         // one window: its segments, then the four IBD1 products of the lane's individual (:716-719, :744-745) times its multiplicity
         auto window_sum = [&](uint32_t w) __attribute__((always_inline)) -> double {
             uint32_t flags;
@@ -1050,7 +1081,7 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
         // the sum over the wave's 64 individuals in the tree of wave_sum2 (the lane number's bits in turn), by DPP moves alone:
         // this form has no scratch in LDS -- what that frees is a third ring slot per wave at the same four workgroups a CU
         for (uint32_t w = w0; s < nseg; ++w) {
-            const double tot = wave_sum_to_lane63(window_sum(w));
+            const double tot = wave_sum_lane63_only(window_sum(w));
             if (lane == 63)
                 a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + 1] = tot;
         }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets, ibdg_upload_panel_fd; a run over new comparison individuals queues without a host wait.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets, ibdg_upload_panel_fd; a run over new comparison individuals queues without a host wait; option ibd0_after, ibdg_last_count_unit 3.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
@@ -229,7 +229,11 @@ int ibdg_ld_layout(const ibdg_ctx *ctx);
  * or the one to four left over beside the groups of the other kernels) took the weighted sums of a haplotype word:
  * 2 = one matrix instruction per word (v_mfma_scale_f32_16x16x128_f8f6f4: the rows' weights as FP6, the word's bits as
  * FP4; option "mx_counts", the default), 1 = twelve (mask, count) pairs on the vector ALU, 0 = no such launch in that
- * run.  The sums are exact integers either way: same results, bit for bit. */
+ * run; 3 = form 2 counting the IBD1 sums only (the instruction returns the table exponents of the four IBD1 products
+ * themselves), IBD0 taken from ONE pass over the site list that keeps every background individual's own product per
+ * window -- src/ibdgem.c:715, :743: it does not depend on the comparison individual, whose only trace in that sum is its
+ * own exclusion, :714 -- (option "ibd0_after").  The sums are exact integers and the floating-point additions the same
+ * in the same order in every form: same results, bit for bit. */
 int ibdg_last_count_unit(const ibdg_ctx *ctx);
 
 /* Options: "dispatch_events" (0/1: time the --LD launches through their own
@@ -262,6 +266,10 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * always; -1 = never: sparse or unordered site lists then take the strict kernel);
  * "reserve_compact" (0/1, default 1, set before ibdg_upload_panel: the buffer of the compacted tiles, 1.3 x the
  * panel's, is allocated with the panel so that a re-layout never allocates);
+ * "ibd0_after" (default 8; 0 = never: the single comparison individuals run on one upload and background add up, and
+ * the run that reaches this number makes the pass of ibdg_last_count_unit's form 3 -- about the cost of one run, a fifth
+ * of every later one saved; at once where a run of groups of 15 has made the pass already.  708 MB of device memory at
+ * chr1 x 2504);
  * "mx_counts" (0/1, default 1: see ibdg_last_count_unit; applies where a run's records of 128 bytes per (window, tile)
  * segment fit the workgroup's LDS and the powers rho^n 2^(s n) of a window's table stay normal doubles, always so at the
  * table sizes kept in LDS); "sum_dpp" (0/1, default 1: the wave sums of that form exchange by DPP moves instead of
