@@ -969,33 +969,30 @@ def main():
     # up to what the gather costs (22 runs of one comparison individual; DESIGN s3, s4.1 -- the reference's own loop runs every
     # individual of the panel over the same rows, src/ibdgem.c:522).  That happens here, untimed and reported: the
     # timed steps below are steps of a site list in use, `in_place_tiles` further down is the same step before it.
+    # ... and once eight single runs on an upload have gone by, ONE pass keeps what the IBD0 terms have in common for every
+    # comparison individual (option ibd0_after; DESIGN s4.1): later runs count the IBD1 sums only (the pass is made again on
+    # the new tiles by the run that re-lays out).  Also here, untimed and reported.
     relayout = {"after_runs": None, "run_ms": None}
+    ibd0_pass = {"after_runs": None, "run_ms": None}
     layout0 = eng.ld_layout()
+    t_r = time.perf_counter()
     eng.run(targets, ld=True)
     eng.sync()
+    if eng.last_count_unit() == 3:
+        ibd0_pass = {"after_runs": 1, "run_ms": (time.perf_counter() - t_r) * 1e3}
     # (a single run counts 12 towards compact_targets = 256 -- 16 with option mx_counts 0 --: the 22nd run re-lays out)
     for k in range(40):
-        if eng.ld_layout() != layout0:
+        if (eng.ld_layout() != layout0 or layout0 == 2) and eng.last_count_unit() != 2:
             break
+        was = eng.ld_layout()
         t_r = time.perf_counter()
         eng.run(targets, ld=True)
         eng.sync()
-        relayout = {"after_runs": k + 2, "run_ms": (time.perf_counter() - t_r) * 1e3}
-    if eng.ld_layout() == layout0:
-        relayout = {"after_runs": None, "run_ms": None}
-    # ... and once eight single runs on an upload have gone by, ONE pass keeps what the IBD0 terms have in common for every
-    # comparison individual (option ibd0_after; DESIGN s4.1): later runs count the IBD1 sums only.  Also here, untimed and reported.
-    ibd0_pass = {"after_runs": None, "run_ms": None}
-    runs_so_far = 1 + (relayout["after_runs"] - 1 if relayout["after_runs"] else 0)
-    for k in range(12):
-        if eng.last_count_unit() != 2:
-            break
-        t_r = time.perf_counter()
-        eng.run(targets, ld=True)
-        eng.sync()
-        runs_so_far += 1
-        if eng.last_count_unit() == 3:
-            ibd0_pass = {"after_runs": runs_so_far, "run_ms": (time.perf_counter() - t_r) * 1e3}
+        ms_r = (time.perf_counter() - t_r) * 1e3
+        if eng.ld_layout() != was:
+            relayout = {"after_runs": k + 2, "run_ms": ms_r}
+        if eng.last_count_unit() == 3 and ibd0_pass["after_runs"] is None:
+            ibd0_pass = {"after_runs": k + 2, "run_ms": ms_r}
     # clock settling (untimed, before the W warm-up steps of the contract): queued steps for --prewarm-ms of wall time
     eng.set_option("async", 1)
     t_pw = time.perf_counter()

@@ -16,9 +16,9 @@ src, dst = sys.argv[1], sys.argv[2]
 # windows and segments of the workload: `config.windows_rank0` / `config.segments_rank0` of the bench line
 n_win, n_chunks, n_segs = int(sys.argv[3]), 40, int(sys.argv[4])
 raw = json.load(open(src))
-# (the IBD1 form -- four template arguments -- where the timed steps reached it; else the form that counts everything)
+# (the IBD1 form -- last template argument true -- where the timed steps reached it; else the form that counts everything)
 names = [k for k in raw if "k_ld_popcount<" in k]
-name = next((k for k in names if k.count(",") == 3), names[0])
+name = next((k for k in names if k.rstrip().endswith("true, true, true>")), names[0])
 k = raw[name]
 pairs = n_win * n_chunks
 valu = k["SQ_INSTS_VALU"]

@@ -15,10 +15,10 @@ kernels = {}
 for name, kb in raw["FETCH_SIZE"].items():
     w = raw["WRITE_SIZE"].get(name, 0.0)
     kernels[name.replace("void ", "").strip()] = {"FETCH_SIZE_KB": kb, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": (2 * kb + w) * 1024}
-# the kernel of the timed steps: the IBD1 form (four template arguments) where the run reached it -- the form that counts
+# the kernel of the timed steps: the IBD1 form (last template argument true) where the run reached it -- the form that counts
 # everything is then the site list's first runs and the one pass that writes every individual's IBD0 product
 cands = [k for k in kernels if "k_ld_popcount<" in k]
-dom = next((k for k in cands if k.count(",") == 3), None) or max(cands, key=lambda k: kernels[k]["hbm_bytes_corrected"])
+dom = next((k for k in cands if k.rstrip().endswith("true, true, true>")), None) or max(cands, key=lambda k: kernels[k]["hbm_bytes_corrected"])
 out = {
     "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python bench.py "
               "--timed-only --steps 3 --warmup 1; summarised by tools/traffic_summary.py",
