@@ -1518,7 +1518,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
     bool &need_ready = c->s3_unsettled;   // stream3 holds this run's preparation: the other streams wait for tg_ready before they read it
     hipStream_t ps = c->stream;     // where this run's per-individual preparation is queued
     if (!same_inputs) {
-        if (ensure(c, c->weight, (ahead_cap ? ibdg_ctx::TG_RING : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 4))
+        if (ensure(c, c->weight, (ahead_cap ? ibdg_ctx::TG_RING : 1) * T * lanes * 8) || ensure(c, c->nrefpanel, ibdg_ctx::NREF_SLOTS * T * 8))       // (per slot: T background sizes, T individuals)
             return 1;
         // more than a few individuals: a page-locked slot for the indices (so that the copy is a queued one), grown when a run
         // brings more of them; up to IBDG_TG_INLINE of them travel in the weights kernel's arguments instead
@@ -1963,7 +1963,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             if (ibd1) {                      // (whatever kernel made an individual's IBD1 sums)
                 fa.p2c = (const double *)c->p2c.p;
                 fa.p2w = (const double *)c->p2w.p;
-                fa.targets = pa.targets;
+                fa.targets = (const uint32_t *)(d_nrefpanel + T);      // (this run's individuals, from the longer ring: k_target_weights)
                 fa.lanes = (uint32_t)lanes;
             }
             if (fin_in_next) {

@@ -282,7 +282,8 @@ void launch_prep_seg_flags(const PrepSegArgs &a, const uint32_t *run_begin, uint
                            hipStream_t st, bool redo);
 // wconst[w].{mK, eK} = K * pow_1me[reads of w]
 void launch_prep_win_kp(uint32_t n_win, const WinRaw *raw, const WinRaw *pow_1me, WinConst *wconst, hipStream_t st);
-// weight[t][n] = n == targets[t] ? 0 : base_w[n];  n_refpanel[t] = base_sum - base_w[targets[t]]  (src/ibdgem.c:714, :742-750)
+// weight[t][n] = n == targets[t] ? 0 : base_w[n];  n_refpanel[t] = base_sum - base_w[targets[t]]  (src/ibdgem.c:714, :742-750);
+// n_refpanel[n_targets + t] = targets[t] (n_refpanel holds 2 n_targets entries)
 // (inline_targets != NULL and n_targets <= IBDG_TG_INLINE: the indices travel as kernel arguments and the kernel writes
 // `targets` too; otherwise `targets` must hold them already)
 #define IBDG_TG_INLINE 16

@@ -700,6 +700,9 @@ __global__ __launch_bounds__(256) void k_target_weights(const double *__restrict
         weight[(size_t)t * lanes + n] = n == tgt ? 0.0 : base_w[n];
     if (n == 0) {
         n_refpanel[t] = base_sum - (int)base_w[tgt];
+        // (the individuals again behind the background sizes: a finalising step left to the next run reads both one run later
+        //  than anything else of this run is read, from a ring twice as long as the one `targets` lives in)
+        n_refpanel[gridDim.y + t] = (int)tgt;
         if (n_inline)
             targets[t] = tgt;
     }
