@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void k_alt_count_long(const uint64_t *__restri
 // ---------------------------------------------------------------------------
 // One turn of a window: rows [base, base + 128) below e, two per lane, all their gathers in flight; the rows' values go to
 // site_ll (when kept) and their factors for the window products -- 1.0 for a row without reads or beyond e -- into `buf`.
+#ifndef IBDG_SITE_NT
+#define IBDG_SITE_NT 1
+#endif
 template <bool FULL>
 __device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_t tgt, size_t base, size_t e, unsigned lane,
                                           double *__restrict__ buf)
@@ -204,9 +207,17 @@ __device__ __forceinline__ void rows_turn(const RowsArgs &a, unsigned t, uint32_
             if (live[u]) {
                 if (a.site_ll) {
                     double *d = a.site_ll + ((size_t)t * a.n_sites + s) * 3;
+#if IBDG_SITE_NT
+                    // (written once, read by nobody on the device: past the caches, which the --LD kernel's tables and the
+                    //  targets' tile words live in)
+                    __builtin_nontemporal_store(ibd0, d);
+                    __builtin_nontemporal_store(ibd1, d + 1);
+                    __builtin_nontemporal_store(ibd2, d + 2);
+#else
                     d[0] = ibd0;
                     d[1] = ibd1;
                     d[2] = ibd2;
+#endif
                 }
             }
             if (!a.ld_mode) {                          // (--LD: only the IBD2 products are taken from here, :752)
