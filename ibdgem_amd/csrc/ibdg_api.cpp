@@ -139,6 +139,9 @@ struct ibdg_ctx {
     long opt_ibd0_after = 8;                // 0: never
     uint64_t ibd0_runs = 0, ibd0_bg_gen = 0;
     int wt_ibd1 = -1;                       // form of the images in wtarget / twords
+    DevBuf fragb;                           // [n_segs][3][6 words]: the IBD1 form's fragments that do not depend on the individual (k_frag_base)
+    uint64_t fb_gen = 0;                    // sites_gen they were made for
+    hipEvent_t ev_fb = nullptr;
     // pow1/pow2: rho^n, sigma^n as {f64 mantissa, i32 exponent}; powb: (1-eps)^n in the x87 format
     uint32_t wpg = 0, max_seg = 0;     // most windows per workgroup run and its largest segment count
     uint32_t n_runs = 0;               // runs of consecutive windows (DevBuf runs: n_runs+1 first windows)
@@ -1090,7 +1093,7 @@ void ibdg_destroy(ibdg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->lut, &c->pow_tab, &c->panel, &c->alt_count, &c->rec_all, &c->rec_cov, &c->cov_site,
                       &c->fo, &c->targets, &c->weight, &c->nrefpanel, &c->af, &c->site_ll, &c->win_ll, &c->row_tab, &c->t32, &c->t32c, &c->seg_first,
-                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w, &c->p2w, &c->p2c, &c->p2_tw, &c->p2_wt,
+                      &c->segs, &c->runs, &c->wconst, &c->wtarget, &c->twords, &c->wtarget_mt, &c->twords_mt, &c->vals, &c->order, &c->pow1, &c->pow2, &c->pow3, &c->partial, &c->aimg, &c->wc_slot, &c->partial_h, &c->base_w, &c->p2w, &c->p2c, &c->p2_tw, &c->p2_wt, &c->fragb,
                       &c->in_row, &c->in_ref, &c->in_alt, &c->scan_tmp, &c->info_dev, &c->wraw, &c->nck_dev, &c->powb,
                       &c->win_first, &c->win_last})
         release(*b);
@@ -1119,7 +1122,7 @@ void ibdg_destroy(ibdg_ctx *c)
         if (c->tg_stage_ev[i])
             (void)hipEventDestroy(c->tg_stage_ev[i]);
     }
-    for (hipEvent_t ev : {c->tg_ready, c->ev_s3sync})
+    for (hipEvent_t ev : {c->tg_ready, c->ev_s3sync, c->ev_fb})
         if (ev)
             (void)hipEventDestroy(ev);
     if (c->stream3)
@@ -1930,6 +1933,21 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
                 HIP_TRY(c, hipEventRecord(c->ev_s3sync, c->stream));
                 HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_s3sync, 0));
                 c->s3_gen = c->sites_gen;
+            }
+            if (ibd1) {
+                if (c->fb_gen != c->sites_gen) {
+                    // once per site list (and layout): the three fragments per segment an individual's images select between
+                    if (ensure(c, c->fragb, (size_t)c->n_segs * 72))
+                        return 1;
+                    if (!c->ev_fb)
+                        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fb, hipEventDisableTiming));
+                    hipStream_t fs = wt_ahead ? c->stream3 : c->stream;
+                    ibdg::launch_frag_base(pa, (uint32_t *)c->fragb.p, fs);
+                    HIP_TRY(c, hipEventRecord(c->ev_fb, fs));
+                    HIP_TRY(c, hipStreamWaitEvent(fs == c->stream ? c->stream3 : c->stream, c->ev_fb, 0));   // (whichever makes the next images)
+                    c->fb_gen = c->sites_gen;
+                }
+                pa.frag_base = (const uint32_t *)c->fragb.p;
             }
             if (!wt_cached)
                 ibdg::launch_win_target(pa, (unsigned)T_one, wt_ahead ? c->stream3 : c->stream, first);

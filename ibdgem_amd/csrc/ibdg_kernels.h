@@ -136,6 +136,7 @@ struct PopArgs {
     uint32_t ibd1 = 0;          // 1: images (k_win_target_mx) and kernel of that form; needs mx_counts and tab_in_lds
     const double *fin_p2c = nullptr, *fin_p2w = nullptr;   // fin_prev's run was of that form: the pass's sums per chunk / per individual
     const uint32_t *fin_targets = nullptr;                 // ... and its comparison individuals (that run's entry of the ring)
+    const uint32_t *frag_base = nullptr;   // ibd1: [n_segs][3][6] the fragments COV, F0, F1 of the site list (k_frag_base); null: k_win_target_mx builds everything
 };
 
 // events a dispatch updates with its own start / stop time (either may be null)
@@ -203,6 +204,7 @@ void launch_gather_transpose32(const uint64_t *panel, uint32_t stride, const uin
                                uint32_t window, uint32_t win_rows, uint32_t n_chunks, uint32_t n_pairs, uint32_t *t32,
                                hipStream_t st);
 void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, KernelEvents ev = {});
+void launch_frag_base(const PopArgs &a, uint32_t *frag_base, hipStream_t st);      // PopArgs::frag_base of a site list
 size_t ld_popcount_rec_bytes(int mx_counts);      // bytes of one segment record in rec_ready
 int launch_ld_popcount(const PopArgs &a, unsigned n_targets, int planes, hipStream_t st, KernelEvents ev = {});
 size_t ld_popcount_lds_bytes(uint32_t max_seg, uint32_t win_per_group, uint32_t tab_len, int tab_in_lds,

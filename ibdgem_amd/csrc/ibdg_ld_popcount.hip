@@ -396,6 +396,173 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
     }
 }
 
+// ---------------------------------------------------------------------------
+// The IBD1 form's images in two steps (round 5).  What k_win_target_mx builds per comparison individual and segment -- four
+// fragments of 32 signed FP6 weights -- depends on the individual only through WHICH of two values a row's weight takes:
+//     sums 0 / 1  cov (1 - 2 t):   +cov or -cov   = the code of cov with the sign bit of the rows where t is set
+//     sums 2 / 3  t cov - alt:     -alt or cov - alt
+// so the three fragments COV, F0 = code(-alt), F1 = code(cov - alt) are made ONCE per site list (k_frag_base, 72 bytes per
+// segment), and an individual's images are bit selections between them: its tile word's 32 bits spread into 32 six-bit
+// fields (M: 0x3f where the row's t is set), by a 256-entry table a byte at a time --
+//     sum 0 / 1 = COV | (M & SIGN)        sum 2 / 3 = (F1 & M) | (F0 & ~M)
+// -- ~100 instructions for a segment's two fragments of one target haplotype word instead of ~500 per fragment: the kernel
+// that runs beside the previous step's --LD kernel for every NEW individual costs that kernel a third of what it did.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void fp6_fragment(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t neg, uint32_t (&f)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        f[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int d = k >> 3, r = 4 * (k & 7) + d;
+        const uint32_t w = ((p0 >> r) & 1u) | (((p1 >> r) & 1u) << 1) | (((p2 >> r) & 1u) << 2);
+        const uint32_t code = fp6_weight_code(w, d) | (((neg >> r) & 1u) << 5);
+        const int pos = 6 * k, wd = pos >> 5, sh = pos & 31;
+        f[wd] |= code << sh;
+        if (sh > 26)
+            f[wd + 1] |= code >> (32 - sh);
+    }
+}
+
+// t cov - alt for 32 rows at once, bit-sliced (cov planes x, alt planes y): a three-bit subtraction, then the magnitude of
+// the negative ones
+__device__ __forceinline__ void sliced_diff(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t y0, uint32_t y1, uint32_t y2,
+                                            uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &neg)
+{
+    const uint32_t d0 = x0 ^ y0, b0 = ~x0 & y0;
+    const uint32_t e1 = x1 ^ y1, d1 = e1 ^ b0, b1 = (~x1 & y1) | (~e1 & b0);
+    const uint32_t e2 = x2 ^ y2, d2 = e2 ^ b1;
+    neg = (~x2 & y2) | (~e2 & b1);                  // the borrow out of bit 2: the difference is negative
+    const uint32_t r1 = ~d1 ^ ~d0, r2 = ~d2 ^ (~d1 & ~d0);      // -d = ~d + 1 (bit 0 stays)
+    p0 = d0;
+    p1 = (d1 & ~neg) | (r1 & neg);
+    p2 = (d2 & ~neg) | (r2 & neg);
+}
+
+// once per site list: [segment][COV, F0, F1][6 words]
+__global__ __launch_bounds__(256) void k_frag_base(PopArgs a, uint32_t *__restrict__ frag_base)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sg = i / 3, which = i - 3 * sg;
+    if (sg >= a.n_segs)
+        return;
+    const Seg &S = a.segs[sg];
+    uint32_t p0, p1, p2, neg;
+    if (which == 0) {
+        p0 = S.cov[0]; p1 = S.cov[1]; p2 = S.cov[2]; neg = 0;
+    } else if (which == 1) {
+        p0 = S.alt[0]; p1 = S.alt[1]; p2 = S.alt[2]; neg = 0xffffffffu;          // (-0 where the row has no alt read)
+    } else {
+        sliced_diff(S.cov[0], S.cov[1], S.cov[2], S.alt[0], S.alt[1], S.alt[2], p0, p1, p2, neg);
+    }
+    uint32_t f[6];
+    fp6_fragment(p0, p1, p2, neg, f);
+    uint2 *o = reinterpret_cast<uint2 *>(frag_base + ((size_t)sg * 3 + which) * 6);
+    o[0] = make_uint2(f[0], f[1]);
+    o[1] = make_uint2(f[2], f[3]);
+    o[2] = make_uint2(f[4], f[5]);
+}
+
+// per comparison individual: two threads per segment (one per haplotype word of the individual), eight per window
+__global__ __launch_bounds__(256) void k_win_target_x1(PopArgs a, const uint32_t *__restrict__ frag_base,
+                                                       uint32_t *__restrict__ rec_ready, uint32_t *__restrict__ wc_ready)
+{
+    // eight rows' bits -> eight six-bit fields of ones (48 bits), one entry per thread of the workgroup
+    __shared__ uint2 spread8[256];
+    {
+        const uint32_t b = threadIdx.x;
+        uint64_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            m |= (b >> j) & 1u ? (uint64_t)0x3f << (6 * j) : 0;
+        spread8[b] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = blockIdx.y;
+    const uint32_t tgt = a.targets[a.t_base + t];
+    const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
+    if ((i >> 1) < a.n_segs) {
+        const uint32_t sg = i >> 1, ts = i & 1;
+        const Seg &S = a.segs[sg];
+        const uint2 at = tile_words(tt, S.tile);
+        const uint32_t tw = ts ? at.y : at.x;
+        // M: element k = 8 d + j of the fragment is row 4 j + d of the tile
+        uint32_t m[6];
+        {
+            uint2 e[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t x = (tw >> d) & 0x11111111u;           // rows d, 4 + d, ..., 28 + d at bits 0, 4, ..., 28
+                x = (x | (x >> 3)) & 0x03030303u;
+                x = (x | (x >> 6)) & 0x000f000fu;
+                x = (x | (x >> 12)) & 0xffu;
+                e[d] = spread8[x];
+            }
+            m[0] = e[0].x;
+            m[1] = e[0].y | (e[1].x << 16);
+            m[2] = (e[1].x >> 16) | (e[1].y << 16);
+            m[3] = e[2].x;
+            m[4] = e[2].y | (e[3].x << 16);
+            m[5] = (e[3].x >> 16) | (e[3].y << 16);
+        }
+        const uint2 *fb = reinterpret_cast<const uint2 *>(frag_base + (size_t)sg * 18);
+        const uint2 c0 = fb[0], c1 = fb[1], c2 = fb[2];         // COV
+        const uint2 u0 = fb[3], u1 = fb[4], u2 = fb[5];         // F0
+        const uint2 v0 = fb[6], v1 = fb[7], v2 = fb[8];         // F1
+        // bit 5 of every six-bit field: the pattern repeats after 96 bits
+        constexpr uint32_t SG0 = 0x20820820u, SG1 = 0x08208208u, SG2 = 0x82082082u;
+        uint32_t *o = rec_ready + ((size_t)t * a.n_segs + sg) * IBDG_RECX_WORDS;
+        uint2 *fa = reinterpret_cast<uint2 *>(o + 8 + 6 * ts), *fd = reinterpret_cast<uint2 *>(o + 8 + 6 * (2 + ts));
+        fa[0] = make_uint2(c0.x | (m[0] & SG0), c0.y | (m[1] & SG1));
+        fa[1] = make_uint2(c1.x | (m[2] & SG2), c1.y | (m[3] & SG0));
+        fa[2] = make_uint2(c2.x | (m[4] & SG1), c2.y | (m[5] & SG2));
+        fd[0] = make_uint2((v0.x & m[0]) | (u0.x & ~m[0]), (v0.y & m[1]) | (u0.y & ~m[1]));
+        fd[1] = make_uint2((v1.x & m[2]) | (u1.x & ~m[2]), (v1.y & m[3]) | (u1.y & ~m[3]));
+        fd[2] = make_uint2((v2.x & m[4]) | (u2.x & ~m[4]), (v2.y & m[5]) | (u2.y & ~m[5]));
+        if (ts == 0) {
+            const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24;
+            const uint32_t fl = ((S.flags & 7) * 1024 + ((S.flags >> 3) & 1) * 8) | ((ncov > 3 || nalt > 3) ? 1u << 14 : 0u) |
+                                (((S.flags >> 13) & 1) << 15) | (((S.flags >> 4) & 0xff) << 16);
+            uint4 *oh = reinterpret_cast<uint4 *>(o);
+            oh[0] = make_uint4(fl, S.cov[0], S.cov[1], S.cov[2]);
+            oh[1] = make_uint4(at.x, at.y, ncov | (nalt << 8), 0);
+        }
+    }
+    if ((i >> 3) < a.n_win) {                // threads 8w..8w+7: the constants of window w (as k_win_target_mx, ibd1)
+        const uint32_t w = i >> 3;
+        uint32_t a0cov = 0, a1cov = 0, a0alt = 0, a1alt = 0;
+        const uint32_t s1 = a.wconst[w + 1].seg_begin;
+        for (uint32_t s = a.wconst[w].seg_begin + (i & 7); s < s1; s += 8) {
+            const Seg &S = a.segs[s];
+            const uint2 at = tile_words(tt, S.tile);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a0cov += (uint32_t)__popc(at.x & S.cov[k]) << k;
+                a1cov += (uint32_t)__popc(at.y & S.cov[k]) << k;
+                a0alt += (uint32_t)__popc(at.x & S.alt[k]) << k;
+                a1alt += (uint32_t)__popc(at.y & S.alt[k]) << k;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            a0cov += __shfl_xor(a0cov, m);
+            a1cov += __shfl_xor(a1cov, m);
+            a0alt += __shfl_xor(a0alt, m);
+            a1alt += __shfl_xor(a1alt, m);
+        }
+        if ((i & 7) == 0) {
+            const uint32_t *wcs = reinterpret_cast<const uint32_t *>(a.wconst + w);
+            uint4 *o = reinterpret_cast<uint4 *>(wc_ready + ((size_t)t * a.n_win + w) * IBDG_WC_WORDS);
+            const uint32_t AT = wcs[4];
+            const uint32_t bias = 1u << 25;              // (see k_win_target_mx)
+            o[0] = make_uint4(wcs[2], 8 * AT, 8 * a0cov - bias, 8 * a1cov - bias);
+            o[1] = make_uint4(8 * (AT - a0alt) - bias, 8 * (AT - a1alt) - bias, 0, 0);
+        }
+    }
+}
+
 // the bits of a tile word as 32 FP4 numbers (0 or 0.5 / 1 / 2 / 0.5 by dword, see above)
 __device__ __forceinline__ mx_v8i bits_to_fp4(uint32_t x)
 {
@@ -1598,6 +1765,12 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, Ker
 {
     if (a.n_win == 0)
         return;
+    if (a.mx_counts && a.ibd1 && a.frag_base && a.tab_in_lds) {
+        const uint32_t n = a.n_segs * 2 > a.n_win * 8 ? a.n_segs * 2 : a.n_win * 8;
+        hipExtLaunchKernelGGL(k_win_target_x1, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a, a.frag_base,
+                              const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+        return;
+    }
     if (a.mx_counts) {
         const uint32_t n = a.n_segs * 4 > a.n_win * 8 ? a.n_segs * 4 : a.n_win * 8;
         hipExtLaunchKernelGGL(k_win_target_mx, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a,
@@ -1607,6 +1780,14 @@ void launch_win_target(const PopArgs &a, unsigned n_targets, hipStream_t st, Ker
     const uint32_t n = a.n_segs > a.n_win * 8 ? a.n_segs : a.n_win * 8;
     hipExtLaunchKernelGGL(k_win_target, dim3((n + 255) / 256, n_targets), dim3(256), 0, st, ev.start, ev.stop, 0, a,
                           const_cast<uint32_t *>(a.rec_ready), const_cast<uint32_t *>(a.wc_ready));
+}
+
+// the IBD1 form's three fragments per segment that do not depend on the comparison individual (72 bytes per segment)
+void launch_frag_base(const PopArgs &a, uint32_t *frag_base, hipStream_t st)
+{
+    if (a.n_segs == 0)
+        return;
+    hipLaunchKernelGGL(k_frag_base, dim3((a.n_segs * 3 + 255) / 256), dim3(256), 0, st, a, frag_base);
 }
 
 size_t ld_popcount_rec_bytes(int mx_counts) { return (mx_counts ? IBDG_RECX_WORDS : IBDG_REC_WORDS) * 4; }
