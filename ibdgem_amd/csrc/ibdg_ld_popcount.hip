@@ -38,6 +38,16 @@
 // of k_ld_popcount; DESIGN.md s4.1, docs/DESIGN_rounds_1-4.md s4.1c); only <x0 & x1,cov> is still three (mask, count) pairs.  The sums are the same
 // integers, the results the same bits.  The pairs described above remain the form of option mx_counts 0 and of the kernel
 // for groups of four comparison individuals (k_ld_popcount_mt).
+//
+// Round 5, the IBD1 form (k_ld_popcount<.., IBD1 = true>; PopArgs::ibd1): the product of an individual's OWN
+// genotype factors (pDg[x0+x1] above) does not depend on the comparison individual, so ONE launch per site list and background
+// keeps it for every individual and window (PopArgs::p2_out) and later launches count the four pDg[t+x] products only: the
+// rows' weights become cov (1 - 2 t) and t cov - alt (signed FP6), the instruction's four sums per word are
+//     C(x) - 2 G(x,t0)   C(x) - 2 G(x,t1)   G(x,t0) - A(x)   G(x,t1) - A(x)
+// -- E3 and E2 above up to the window's constants --, the accumulators start from 1.5 * 2^23 so that their bits ARE the sums,
+// and the finalising step takes IBD0 from the kept products in the additions of a launch that counts everything
+// (ibd0_from_pass, ibdg_ld_dev.h): the same bits from either form.  A new individual's images are bit selections between
+// three fragments made once per site list (k_frag_base, k_win_target_x1).
 #include "ibdg_kernels.h"
 #include "ibdg_ld_dev.h"
 
@@ -1246,11 +1256,13 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
             return wgt * (((val[0] + val[1]) + val[2]) + val[3]);
         };
         // the sum over the wave's 64 individuals in the tree of wave_sum2 (the lane number's bits in turn), by DPP moves alone:
-        // this form has no scratch in LDS -- what that frees is a third ring slot per wave at the same four workgroups a CU
-        for (uint32_t w = w0; s < nseg; ++w) {
+        // this form has no scratch in LDS (a third ring slot per wave at the same four workgroups a CU measured 3 % slower)
+        uint32_t w = w0;
+        while (s < nseg) {                                    // (window_sum advances s)
             const double tot = wave_sum_lane63_only(window_sum(w));
             if (lane == 63)
                 a.partial[(((size_t)(a.t_base + t) * a.n_win + w) * a.n_chunks + c) * 2 + 1] = tot;
+            ++w;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
