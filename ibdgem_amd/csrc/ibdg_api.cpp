@@ -137,6 +137,8 @@ struct ibdg_ctx {
     // single comparison individuals take their IBD0 terms from that pass too once their runs on one upload and background
     // have added up to "ibd0_after" individuals (the pass costs about one run and saves a fifth of every later one)
     long opt_ibd0_after = 8;                // 0: never
+    long opt_mfma_batch = 36;               // groups of 15 per launch of the matrix-core kernel (540 individuals)
+    size_t dev_mem_bytes = 0;               // the device's memory (hipMemGetInfo at ibdg_create)
     uint64_t ibd0_runs = 0, ibd0_bg_gen = 0;
     int wt_ibd1 = -1;                       // form of the images in wtarget / twords
     DevBuf fragb;                           // [n_segs][3][6 words]: the IBD1 form's fragments that do not depend on the individual (k_frag_base)
@@ -1061,6 +1063,9 @@ ibdg_ctx *ibdg_create(int device, double epsilon, unsigned max_cov)
         int n_cu = 0;
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
             c->n_cu = n_cu;
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+            c->dev_mem_bytes = mem_total;
     }
     const size_t d = (size_t)max_cov + 1;
     c->lut_h.resize(d * d * 3);
@@ -1715,11 +1720,15 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // exist for one batch of groups at a time: about 1 GiB of operands, eight groups at most
         size_t gg_batch = n_gg;
         if (n_gg) {
+            // (option "mfma_batch_groups": at most that many groups per launch, within 1/16 of the device's memory for each of
+            //  the two buffers)
             const size_t per_group = (size_t)c->n_segs * 1024;
-            size_t fit = per_group ? ((size_t)1 << 30) / per_group : n_gg;
-            const size_t fit_p = ((size_t)4 << 30) / ((size_t)c->n_win * (c->n_chunks * 2 * 136 + 128) + 1);     // partial sums
+            const size_t mem_cap = std::max<size_t>((size_t)1 << 30, c->dev_mem_bytes / 16);
+            size_t fit = per_group ? mem_cap / per_group : n_gg;
+            const size_t fit_p = mem_cap / ((size_t)c->n_win * (c->n_chunks * 2 * 136 + 128) + 1);     // partial sums
             fit = fit < fit_p ? fit : fit_p;
-            fit = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
+            const size_t cap_g = (size_t)std::max<long>(1, c->opt_mfma_batch);
+            fit = fit < 1 ? 1 : (fit > cap_g ? cap_g : fit);
             gg_batch = fit < n_gg ? fit : n_gg;
         }
         // one comparison individual per workgroup: the counts of a haplotype word on the matrix cores where the larger
@@ -2281,6 +2290,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_compact_align = value;
         return 0;
     }
+    if (!strcmp(name, "mfma_batch_groups")) { c->opt_mfma_batch = value < 1 ? 1 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ibd0_after")) { c->opt_ibd0_after = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "end_in_dispatch")) { c->opt_end_in_dispatch = value != 0; return 0; }
     if (!strcmp(name, "prep_ahead")) { c->opt_prep_ahead = value != 0; return 0; }

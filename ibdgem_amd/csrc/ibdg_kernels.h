@@ -185,6 +185,7 @@ struct MfmaArgs {
     double *part_t1;            // [groups][n_win][2 * n_chunks][16 slots]  IBD1 sums
     // IBD0 does not depend on the comparison individual except for its own exclusion: the products and their sums per chunk of
     // 64 individuals come from ONE pass of k_ld_popcount per site list and background (PopArgs::p2_out and its partial sums)
+    uint32_t n_groups = 1;      // groups of the launch (set by launch_ld_mfma: the kernel deals its workgroups itself)
     const double *p2w;          // [n_win][lanes] weight x product of every background individual
     const double *p2c;          // [n_win][n_chunks][2]: [0] = the chunk's sum of p2w
     uint32_t lanes;

@@ -424,6 +424,9 @@ __device__ __forceinline__ double strip_sum(uint32_t get_addr)
 #ifndef IBDG_MFMA_XCD
 #define IBDG_MFMA_XCD 1             /* the workgroups of a run on one XCD (0: in launch order round the XCDs) */
 #endif
+#ifndef IBDG_MFMA_GRP_MAJOR
+#define IBDG_MFMA_GRP_MAJOR 0       /* 1: within a run the groups of individuals in turn, within those the half-chunk groups */
+#endif
 #ifndef IBDG_MFMA_WAVES
 #define IBDG_MFMA_WAVES 8           /* waves = half chunks per workgroup: 8 share one copy of the tables (4: the strips'
                                        LDS leaves room for 3 waves per SIMD only, 12 % slower) */
@@ -445,18 +448,27 @@ void k_ld_mfma(MfmaArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
-    const unsigned grp = blockIdx.z;
     const uint32_t n_half = 2 * a.n_chunks, n_hgroups = (n_half + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
 #if IBDG_MFMA_XCD
-    // The workgroups of ONE run (its n_hgroups groups of half chunks) read the same target image, 1 KiB per segment: they are
-    // dealt to ONE XCD, so that its L2 serves the image to all but the first of them.  Consecutive workgroup ids go round
-    // the 8 XCDs: workgroup b runs on XCD b % 8 as its (b / 8)-th; XCD x takes the runs x, x + 8, x + 16, ... in that order
-    // (the launch holds 8 * n_hgroups * ceil(n_runs / 8) workgroups; those past the last run leave at once).
-    const uint32_t xcd = blockIdx.x & 7, nth = blockIdx.x >> 3;
-    const uint32_t run = xcd + 8 * (nth / n_hgroups), hgroup = nth % n_hgroups;
+    // The workgroups of ONE run (its n_hgroups groups of half chunks, times the launch's groups of comparison individuals)
+    // are dealt to ONE XCD, next to each other: those of one group read the same target image, 1 KiB per segment, and the
+    // same half chunks' workgroups of the launch's OTHER groups read the same tile words -- the XCD's L2 serves all but the
+    // first of them.  Consecutive workgroup ids go round the 8 XCDs: workgroup b runs on XCD b % 8 as its (b / 8)-th; XCD x
+    // takes the runs x, x + 8, x + 16, ... in that order, within a run the half-chunk groups in turn, within those the groups
+    // of individuals (the launch holds 8 * n_hgroups * n_groups * ceil(n_runs / 8) workgroups; those past the last run leave).
+    const uint32_t xcd = blockIdx.x & 7, nth = blockIdx.x >> 3, per_run = n_hgroups * a.n_groups;
+    const uint32_t run = xcd + 8 * (nth / per_run), in_run = nth % per_run;
+#if IBDG_MFMA_GRP_MAJOR
+    const uint32_t hgroup = in_run % n_hgroups;
+    const unsigned grp = in_run / n_hgroups;
+#else
+    const uint32_t hgroup = in_run / a.n_groups;
+    const unsigned grp = in_run % a.n_groups;
+#endif
     if (run >= a.n_runs)
         return;
 #else
+    const unsigned grp = blockIdx.z;
     const uint32_t run = blockIdx.x / n_hgroups, hgroup = blockIdx.x - run * n_hgroups;
 #endif
     const uint32_t w0 = a.run_begin[run], w1 = a.run_begin[run + 1];
@@ -878,13 +890,14 @@ int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelE
                             (int)lds) != hipSuccess)
         return 1;
     const uint32_t n_hgroups = (2 * a.n_chunks + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES;
+    MfmaArgs b = a;
+    b.n_groups = n_groups;
 #if IBDG_MFMA_XCD
-    const uint32_t n_blocks = 8 * n_hgroups * ((a.n_runs + 7) / 8);
+    const dim3 grid(8 * n_hgroups * n_groups * ((a.n_runs + 7) / 8), 1, 1);
 #else
-    const uint32_t n_blocks = a.n_runs * n_hgroups;
+    const dim3 grid(a.n_runs * n_hgroups, 1, n_groups);
 #endif
-    hipExtLaunchKernelGGL(k_ld_mfma, dim3(n_blocks, 1, n_groups), dim3(64 * IBDG_MFMA_WAVES), (uint32_t)lds, st, ev.start,
-                          ev.stop, 0, a);
+    hipExtLaunchKernelGGL(k_ld_mfma, grid, dim3(64 * IBDG_MFMA_WAVES), (uint32_t)lds, st, ev.start, ev.stop, 0, b);
     return 0;
 }
 
