@@ -137,6 +137,7 @@ struct ibdg_ctx {
     // single comparison individuals take their IBD0 terms from that pass too once their runs on one upload and background
     // have added up to "ibd0_after" individuals (the pass costs about one run and saves a fifth of every later one)
     long opt_ibd0_after = 8;                // 0: never
+    long opt_mfma_wg_sum = 1;               // the matrix-core kernel's workgroups add their eight waves' sums up themselves (where LDS allows)
     long opt_mfma_batch = 36;               // groups of 15 per launch of the matrix-core kernel (540 individuals)
     size_t dev_mem_bytes = 0;               // the device's memory (hipMemGetInfo at ibdg_create)
     uint64_t ibd0_runs = 0, ibd0_bg_gen = 0;
@@ -1886,6 +1887,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.p2w = (const double *)c->p2w.p;
             ma.p2c = (const double *)c->p2c.p;
             ma.lanes = (uint32_t)lanes;
+            ma.wg_sum = c->opt_mfma_wg_sum && ibdg::ld_mfma_wg_sum(c->wpg, c->ct_max + 1, c->max_seg) ? 1u : 0u;
             {
                 // one batch's partial sums: t1 [groups][windows][half chunks][16], t0 [groups][windows][half chunks], ov [groups][windows][16]
                 const size_t nh = (size_t)c->n_chunks * 2;
@@ -2290,6 +2292,7 @@ int ibdg_set_option(ibdg_ctx *c, const char *name, long value)
         c->opt_compact_align = value;
         return 0;
     }
+    if (!strcmp(name, "mfma_wg_sum")) { c->opt_mfma_wg_sum = value != 0; return 0; }
     if (!strcmp(name, "mfma_batch_groups")) { c->opt_mfma_batch = value < 1 ? 1 : (value > 64 ? 64 : value); return 0; }
     if (!strcmp(name, "ibd0_after")) { c->opt_ibd0_after = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "end_in_dispatch")) { c->opt_end_in_dispatch = value != 0; return 0; }

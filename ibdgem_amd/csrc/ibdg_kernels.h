@@ -185,12 +185,14 @@ struct MfmaArgs {
     double *part_t1;            // [groups][n_win][2 * n_chunks][16 slots]  IBD1 sums
     // IBD0 does not depend on the comparison individual except for its own exclusion: the products and their sums per chunk of
     // 64 individuals come from ONE pass of k_ld_popcount per site list and background (PopArgs::p2_out and its partial sums)
+    uint32_t wg_sum = 0;        // 1: part_t1 is [groups][n_win][groups of eight half chunks][16]: a workgroup adds its waves' sums up (ld_mfma_wg_sum)
     uint32_t n_groups = 1;      // groups of the launch (set by launch_ld_mfma: the kernel deals its workgroups itself)
     const double *p2w;          // [n_win][lanes] weight x product of every background individual
     const double *p2c;          // [n_win][n_chunks][2]: [0] = the chunk's sum of p2w
     uint32_t lanes;
 };
 size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
+int ld_mfma_wg_sum(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg);
 void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st);
 int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelEvents ev);
 // win_ll[t][w][0..1] of the launch's comparison individuals from those partial sums (src/ibdgem.c:751-752)

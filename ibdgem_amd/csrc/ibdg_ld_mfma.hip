@@ -226,6 +226,19 @@ __device__ __forceinline__ void store_f64_lanes(uint64_t mask, double *p, double
                  : "memory", "scc");
 }
 
+// the same into LDS (the workgroup's sums of a window, MfmaArgs::wg_sum)
+__device__ __forceinline__ void lds_store_f64_lanes(uint64_t mask, uint32_t addr, double v)
+{
+    uint64_t exec_was;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, %0, %3\n\t"
+                 "ds_write_b64 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(exec_was)
+                 : "v"(addr), "v"(v), "s"(mask)
+                 : "memory", "scc");
+}
+
 constexpr uint32_t SS = 36;          // doubles per row of the reduction strip: 32 lanes + 4 of padding (reads two-way at most)
 
 // (a << 4) + b with b in a scalar register (the tau table's LDS address is the same for the whole workgroup)
@@ -439,6 +452,19 @@ size_t ld_mfma_lds_bytes(uint32_t win_per_group, uint32_t tab_len, uint32_t max_
            (size_t)IBDG_MFMA_WAVES * 16 * SS * 8;
 }
 
+// MfmaArgs::wg_sum: the eight waves of a workgroup leave a window's sums in LDS and the workgroup adds them up when its run is
+// done -- one partial sum per (window, group of eight half chunks, slot) instead of one per half chunk: an eighth of the
+// bytes the kernel writes and k_ld_finalize_g reads (354 MB per group of 15 at chr1).  1 KiB of LDS per window of the run:
+// taken where two workgroups still fit a CU.
+int ld_mfma_wg_sum(uint32_t win_per_group, uint32_t tab_len, uint32_t max_seg)
+{
+#if IBDG_MFMA_WAVES == 8
+    return ld_mfma_lds_bytes(win_per_group, tab_len, max_seg) + (size_t)win_per_group * 1024 <= 80 * 1024;
+#else
+    return 0;
+#endif
+}
+
 #ifndef IBDG_MFMA_WAVES_PER_EU
 #define IBDG_MFMA_WAVES_PER_EU 4
 #endif
@@ -524,8 +550,13 @@ void k_ld_mfma(MfmaArgs a)
     __syncthreads();
 
     const uint32_t hc = hgroup * IBDG_MFMA_WAVES + wave;                          // half chunk of this wave
-    if (hc >= n_half)
+    const bool wg_sum = a.wg_sum != 0;
+    // (wg_sum) [window of the run][wave][16 slots]: the waves' sums, behind the strips
+    const uint32_t wsum_base = (uint32_t)(uintptr_t)(lds_void *)(reinterpret_cast<double *>(rec + 2 * ((size_t)a.max_seg + 1)) +
+                                                                 (size_t)IBDG_MFMA_WAVES * 16 * SS);
+    if (hc >= n_half && !wg_sum)
         return;
+    auto run_wave = [&]() {
     const uint32_t c = hc >> 1, n = lane & 31, h = lane >> 5;
     const uint32_t indiv = 64 * c + 32 * (hc & 1) + n;               // the lane's background individual
     const double wgt = a.base_weight[indiv];
@@ -563,6 +594,7 @@ void k_ld_mfma(MfmaArgs a)
     //   t1[group][window][hc][16 slots]  the IBD1 sums -- the eight storing lanes of a turn write 64 consecutive bytes.
     // (The IBD0 sums are not this kernel's: MfmaArgs::p2w / p2c.)
     double *const t1_row = a.part_t1 + (((size_t)grp * a.n_win) * n_half + hc) * 16 + st_q;          // + window * n_half * 16 (+ 8 per turn)
+    const uint32_t wsum_lane = wsum_base + wave * 128 + st_q * 8;                                     // + window of the run * 1024 (+ 64 per turn)
     const bool any_excl = __builtin_amdgcn_ballot_w64(excl != 0) != 0;
     const uint32_t n_quads = (cnt + 3) / 4;                          // groups of four slots that hold comparison individuals
     const uint32_t wcs_base = (uint32_t)(uintptr_t)(lds_void *)wcs;
@@ -727,7 +759,11 @@ void k_ld_mfma(MfmaArgs a)
                 const double part = __builtin_ldexp(mu * S, plain ? eRef + er : 0);                          \
                 const uint32_t plo = from_upper_half((uint32_t)__double2loint(part));                        \
                 const uint32_t phi = from_upper_half((uint32_t)__double2hiint(part));                        \
-                store_f64_lanes(OK, t1_row + ((size_t)w * n_half * 16 + 8 * TURN), part + __hiloint2double((int)phi, (int)plo)); \
+                const double both = part + __hiloint2double((int)phi, (int)plo);                             \
+                if (wg_sum)                                                                                  \
+                    lds_store_f64_lanes(OK, wsum_lane + (w - w0) * 1024 + 64 * TURN, both);                  \
+                else                                                                                         \
+                    store_f64_lanes(OK, t1_row + ((size_t)w * n_half * 16 + 8 * TURN), both);                \
             }
             if (n_quads > 2) {
                 IBDG_QUAD(8, eu_addr)
@@ -815,6 +851,23 @@ void k_ld_mfma(MfmaArgs a)
     (void)xq2;
     (void)aq2;
 #endif
+    };
+    if (hc < n_half)
+        run_wave();
+    if (wg_sum) {
+        // the workgroup's sums: its waves' in the order of their half chunks
+        __syncthreads();
+        const double *ws = reinterpret_cast<const double *>(reinterpret_cast<double *>(rec + 2 * ((size_t)a.max_seg + 1)) +
+                                                            (size_t)IBDG_MFMA_WAVES * 16 * SS);
+        const uint32_t left_h = n_half - hgroup * IBDG_MFMA_WAVES, nw = left_h < IBDG_MFMA_WAVES ? left_h : IBDG_MFMA_WAVES;
+        for (uint32_t i = threadIdx.x; i < (w1 - w0) * 16; i += blockDim.x) {
+            const uint32_t wi = i >> 4, q = i & 15;
+            double sum = 0.0;
+            for (uint32_t v = 0; v < nw; ++v)
+                sum += ws[((size_t)wi * IBDG_MFMA_WAVES + v) * 16 + q];
+            a.part_t1[(((size_t)grp * a.n_win + w0 + wi) * n_hgroups + hgroup) * 16 + q] = sum;
+        }
+    }
 }
 
 // The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group), four windows
@@ -829,7 +882,8 @@ __global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), grp = blockIdx.y, lane = threadIdx.x & 63;
     if (w >= a.n_win)
         return;
-    const uint32_t n_half = 2 * a.n_chunks, q = lane & 15, j = lane >> 4;
+    // (partial sums per half chunk, or per workgroup of eight of them: MfmaArgs::wg_sum)
+    const uint32_t n_half = a.wg_sum ? (2 * a.n_chunks + IBDG_MFMA_WAVES - 1) / IBDG_MFMA_WAVES : 2 * a.n_chunks, q = lane & 15, j = lane >> 4;
     const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
     const double *t1 = a.part_t1 + (((size_t)grp * a.n_win + w) * n_half) * 16;
     double acc = 0.0;
@@ -885,7 +939,7 @@ int launch_ld_mfma(const MfmaArgs &a, unsigned n_groups, hipStream_t st, KernelE
 {
     if (a.n_win == 0 || n_groups == 0)
         return 0;
-    const size_t lds = ld_mfma_lds_bytes(a.win_per_group, a.tab_len, a.max_seg);
+    const size_t lds = ld_mfma_lds_bytes(a.win_per_group, a.tab_len, a.max_seg) + (a.wg_sum ? (size_t)a.win_per_group * 1024 : 0);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ld_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 1;
