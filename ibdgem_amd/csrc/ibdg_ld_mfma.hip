@@ -110,11 +110,19 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
         // the kernel shifts every bit to the value 8 (seg_wide).
         const bool wide = np > 4;
         uint32_t out[4] = {0, 0, 0, 0};
-        for (uint32_t k = 0; k < np; ++k) {
-            const uint32_t f = ((use_alt ? S.alt[k] : S.cov[k]) >> (4 * kb)) & sel;
+        // (all sixteen masks at once, wave-uniform: loaded inside the loop over the planes they cost a memory round trip each)
+        uint32_t pl[8];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                out[d] += ((f >> d) & 0x01010101u) << (wide ? k : k + 3 - d);       // weights <= 127 (<= 120): no carry between bytes
+        for (int k = 0; k < 8; ++k)
+            pl[k] = use_alt ? S.alt[k] : S.cov[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((uint32_t)k < np) {
+                const uint32_t f = (pl[k] >> (4 * kb)) & sel;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    out[d] += ((f >> d) & 0x01010101u) << (wide ? k : k + 3 - d);       // weights <= 127 (<= 120): no carry between bytes
+            }
         }
         a.aimg[((size_t)grp * a.n_segs + s) * 64 + l] = make_uint4(out[0], out[1], out[2], out[3]);
     }
