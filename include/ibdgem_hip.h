@@ -297,7 +297,11 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * groups of 15 go through the matrix-core kernel -- the sums that depend on the comparison
  * individual as integer matrix products; same results, ~2.5x the throughput of single runs; "mfma_plain_tau"
  * (0/1, default 1: that kernel looks the powers tau^G of a window up as plain doubles where none of them leaves the
- * double range -- the same bits as the {mantissa, exponent} table it uses otherwise, half the LDS traffic)).
+ * double range -- the same bits as the {mantissa, exponent} table it uses otherwise, half the LDS traffic);
+ * "mfma_batch_groups" (1..64, default 36: groups of 15 per launch of that kernel -- the groups' workgroups of one run sit
+ * next to each other on one XCD, whose L2 then serves the panel's tile words to all but the first of them; bounded by a
+ * sixteenth of the device's memory for the groups' operands and partial sums); "mfma_wg_sum" (0/1, default 1: a workgroup of
+ * that kernel adds its eight waves' window sums up itself where its LDS allows: an eighth of the partial sums written)).
  * Returns non-zero for an unknown name or a value out of range. */
 int ibdg_set_option(ibdg_ctx *ctx, const char *name, long value);
 
