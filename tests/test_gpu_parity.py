@@ -343,6 +343,41 @@ def test_many_comparison_individuals_through_the_matrix_cores(oracle, N, L, W, M
     print(f"N={N} T={T}: max rel err vs the oracle {worst:.2e}")
 
 
+@pytest.mark.parametrize("N,L,W,T", [(150, 2600, 100, 70), (70, 900, 33, 47), (2504, 700, 100, 40), (520, 1300, 100, 31)])
+def test_groups_per_launch_and_workgroup_sums_of_the_matrix_core_kernel(oracle, N, L, W, T):
+    """How k_ld_mfma's groups of 15 are dealt to launches (option mfma_batch_groups: one group a launch, two, all of them --
+    the groups of one run then sit next to each other on an XCD and share the tile words through its L2) changes no
+    arithmetic: the same bits.  Whether a workgroup adds its eight waves' window sums up itself (mfma_wg_sum 1, the default:
+    one partial sum per group of eight half chunks) or k_ld_finalize_g adds the half chunks' (0) changes the association of
+    the IBD1 sums only: IBD0 and LIBD2 the same bits, IBD1 within 1e-13, and every individual within the bar of the oracle
+    either way -- also where the last group of half chunks is short (N = 70: 3 half chunks; 520: 17; 2504: 79)."""
+    alle, nr, na = synth(5150 + N + T, L, N)
+    rng = np.random.default_rng(N + T)
+    targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
+    got = {}
+    for key, opts in {"one": {"mfma_batch_groups": 1}, "two": {"mfma_batch_groups": 2}, "all": {},
+                      "per_half_chunk": {"mfma_wg_sum": 0}}.items():
+        with E.Engine() as eng:
+            eng.set_option("ld_variant", 2)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.upload_panel(E.pack_alleles_fast(alle), N)
+            eng.upload_sites(np.arange(L), nr, na, W)
+            eng.run(targets, ld=True, pu_id=targets[3])
+            got[key] = eng.window_ll_all(T)
+    assert_bits(got["one"], got["all"], "one group a launch vs all of them")
+    assert_bits(got["two"], got["all"], "two groups a launch vs all of them")
+    assert_bits(got["per_half_chunk"][:, :, 0], got["all"][:, :, 0], "IBD0")
+    assert_bits(got["per_half_chunk"][:, :, 2], got["all"][:, :, 2], "LIBD2")
+    a, b = got["per_half_chunk"][:, :, 1], got["all"][:, :, 1]
+    ok = np.isfinite(b) & (b != 0)
+    assert (np.isnan(a) == np.isnan(b)).all() and (np.abs(a[ok] - b[ok]) <= 1e-13 * np.abs(b[ok])).all()
+    for i in (0, 3, T - 1):
+        res = oracle.compare(alle, nr, na, targets[i], window=W, ld=True, pu_id=targets[3])
+        for key in ("all", "per_half_chunk"):
+            assert_ld_close(got[key][i][:, :2], res["win"][:, :2], f"{key}, individual #{i}")
+
+
 @pytest.mark.parametrize("N,L,W,M,cov", [(70, 900, 100, 20, 2.0), (200, 500, 7, 40, 9.0), (131, 400, 64, 3, 1.0), (3, 60, 2, 20, 2.0)])
 def test_reference_order_mode_is_bit_identical_to_the_oracle(oracle, N, L, W, M, cov):
     """ld_variant 3: strict per-individual products, then the background sums taken serially in the
