@@ -1334,7 +1334,7 @@ def main():
             "new_individual_per_step": len(turn) > 1,
             "relayout": dict(relayout, note="the run on this site list during which the engine gathered its rows with reads into compacted "
                              "tiles (k_gather_transpose32 + the segments again), host wall clock of that run, "
-                             "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 45, an individual "
+                             "untimed; the rule: the runs on one upload add up, a group of the matrix-core kernel as 20, an individual "
                              "of the counting kernels as 12 (16 with mx_counts 0), against compact_targets = 256 (DESIGN s3, s4.1) -- "
                              "null: no re-layout happened"),
             "ibd0_pass": dict(ibd0_pass, count_unit=count_unit,

@@ -1613,10 +1613,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         // 0.58-0.59, profiles/r05_layouts.txt: a single run saves 0.058 ms of the 1.3 ms the gather and the new segments
         // cost, i.e. 22 runs pay for them -- an individual counts as 12; with (mask, count) pairs, option mx_counts 0, as 16)
         const bool to_mfma = c->opt_mfma_targets && c->tab_in_lds && T >= (size_t)c->opt_mfma_min;
-        // (a group of the matrix-core kernel saves 0.18 ms of 2.5 on the rows back to back -- 10.16 against 9.43 ms per 60 individuals,
-        // profiles/r05_multi_target*.txt --, i.e. six groups pay for the re-layout: a group counts as 45; 15 until round 5, when the
-        // window-aligned tiles saved it 0.1 ms)
-        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * 45u : (uint64_t)T * (c->opt_mx_counts ? 12u : 16u);
+        // (a group of the matrix-core kernel saves 0.085 ms of 2.2 on the rows back to back -- 8.90 against 8.57 ms per 60 individuals,
+        // `many_comparison_individuals` of the bench's detail file, since the launch's groups share the tile words through an
+        // XCD's L2 --, i.e. fifteen groups pay for the re-layout: a group counts as 20; 45 earlier in round 5, when a group saved
+        // 0.18 ms, 15 until round 5)
+        c->relayout_credit += to_mfma ? (uint64_t)((T + IBDG_TG - 1) / IBDG_TG) * 20u : (uint64_t)T * (c->opt_mx_counts ? 12u : 16u);
         if (c->relayout_credit >= (uint64_t)std::max<long>(1, c->opt_compact_targets)) {
             if (quiesce(c)) return 1;
             if (build_segments(c, true)) return 1;

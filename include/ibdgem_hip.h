@@ -260,7 +260,7 @@ int ibdg_last_count_unit(const ibdg_ctx *ctx);
  * one panel row in "compact_density" (default 4) between the first and the last site carries reads, when the rows
  * are not in file order, or once the runs on one upload have added up to "compact_targets" (default 256) comparison
  * individuals -- the site list belongs to the pileup, src/ibdgem.c:522 runs every individual over the same rows; a
- * group of the matrix-core kernel counts as 45, an individual of the counting kernels as 12 (16 with "mx_counts" 0): what
+ * group of the matrix-core kernel counts as 20, an individual of the counting kernels as 12 (16 with "mx_counts" 0): what
  * each saves on the compacted tiles -- a single run 0.058 of 0.606 ms at chr1 x 2504 -- against the 1.3 ms of the gather
  * and the new segments, i.e. the 22nd single run on an upload re-lays it out -- the panel's own tiles otherwise; 1 =
  * always; -1 = never: sparse or unordered site lists then take the strict kernel);

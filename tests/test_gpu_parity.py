@@ -798,7 +798,7 @@ def test_plain_double_powers_in_the_matrix_core_kernel(oracle, eps, M, cov):
 
 def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
     """The runs on one upload add up: once they hold "compact_targets" comparison individuals (a group of the matrix-core
-    kernel counts as 45; an individual of the counting kernels as 16 when it counts by (mask, count) pairs, option
+    kernel counts as 20; an individual of the counting kernels as 16 when it counts by (mask, count) pairs, option
     mx_counts 0, and as 12 with its sums on the matrix cores) the site
     list is re-laid out once (the site list belongs to the pileup, src/ibdgem.c:522); later runs on the same upload keep
     the compacted tiles; results unchanged."""
@@ -814,7 +814,7 @@ def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
         eng.run(targets[:4], ld=True)                    # 4 x 16 = 64
         assert eng.ld_layout() == 1
         four = [eng.window_ll(i) for i in range(4)]
-        eng.run(targets, ld=True)                        # + two groups, 45 each = 154
+        eng.run(targets, ld=True)                        # + two groups, 20 each = 104
         assert eng.ld_layout() == 2 and eng.last_ld_variant() == 2
         many = [eng.window_ll(i) for i in range(len(targets))]
         for i in (0, 7, 19):
@@ -846,10 +846,10 @@ def test_many_comparison_individuals_switch_to_the_compacted_tiles(oracle):
             # (the eighth single run on one upload also makes the pass for the IBD0 terms, option ibd0_after: count unit 3)
             assert eng.ld_layout() == (1 if k < 6 else 2) and eng.last_count_unit() == (2 if k < 7 else 3), k
             assert_bits(eng.window_ll(0), per_run[k % 2][1], f"matrix-core counts, run {k}")
-        eng.set_option("compact_targets", 200)
+        eng.set_option("compact_targets", 100)
         eng.upload_sites(np.arange(L), nr, na, 100)
         for k in range(3):
-            eng.run(targets, ld=True)                    # two groups, 45 each: 90, 180, 270
+            eng.run(targets, ld=True)                    # two groups, 20 each: 40, 80, 120
             assert eng.ld_layout() == (1 if k < 2 else 2), k
         # ... and one run of many individuals on a fresh upload does so at once
         eng.set_option("compact_targets", 16)
