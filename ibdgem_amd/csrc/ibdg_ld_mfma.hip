@@ -82,27 +82,46 @@ __device__ __forceinline__ uint32_t row_hap(uint32_t m) { return (m >> 2) & 1; }
 // (2) per window and slot the four table offsets 16<t0,cov> 16<t1,cov> 16(AT-<t0,alt>) 16(AT-<t1,alt>)
 //     (k_win_target's window constants).
 // ---------------------------------------------------------------------------
+// (a wave takes IBDG_WTG_SEGS consecutive segments: the slots' individuals and their tile pointers once, the segments'
+//  tile words all requested before the first is used)
+#ifndef IBDG_WTG_SEGS
+#define IBDG_WTG_SEGS 4
+#endif
 __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
 {
+    constexpr uint32_t NSEG = IBDG_WTG_SEGS;
     const unsigned grp = blockIdx.y;
     const uint32_t left = a.n_targets - grp * TG, cnt = left < TG ? left : TG;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)a.n_segs * 64) {
-        // a wave per segment: the segment's masks are wave-uniform (scalar loads)
-        const uint32_t s = __builtin_amdgcn_readfirstlane((uint32_t)(i >> 6));
-        const uint32_t l = (uint32_t)i & 63, m = l & 31, kb = l >> 5, q = row_slot(m), th = row_hap(m);
-        const Seg &S = a.segs[s];
-        uint32_t sel = 0;                       // rows of the tile that count in this row of the operand
-        const bool use_alt = q == PSEUDO && th;
-        if (q == PSEUDO) {
-            sel = 0xffffffffu;
-        } else if (q < cnt) {
-            const uint32_t tgt = a.targets[a.t_base + grp * TG + q];
-            const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
-            const uint2 w = tile_words(tt, S.tile);
+    const size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane((uint32_t)(wv * NSEG));
+    if (s0 >= a.n_segs)
+        return;
+    const uint32_t l = threadIdx.x & 63, m = l & 31, kb = l >> 5, q = row_slot(m), th = row_hap(m);
+    const bool use_alt = q == PSEUDO && th;
+    const bool real = q != PSEUDO && q < cnt;
+    const uint4 *tt = nullptr;
+    if (real) {
+        const uint32_t tgt = a.targets[a.t_base + grp * TG + q];
+        tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
+    }
+    uint32_t selw[NSEG];
+#pragma unroll
+    for (uint32_t j = 0; j < NSEG; ++j) {
+        const uint32_t s = s0 + j < a.n_segs ? s0 + j : a.n_segs - 1;
+        uint32_t sel = q == PSEUDO ? 0xffffffffu : 0u;     // rows of the tile that count in this row of the operand
+        if (real) {
+            const uint2 w = tile_words(tt, a.segs[s].tile);
             sel = th ? w.y : w.x;
         }
-        sel >>= 4 * kb;
+        selw[j] = sel >> (4 * kb);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < NSEG; ++j) {
+        const uint32_t s = s0 + j;
+        if (s >= a.n_segs)
+            break;
+        const Seg &S = a.segs[s];
+        const uint32_t sel = selw[j];
         const uint32_t ncov = (S.flags >> 16) & 0xff, nalt = S.flags >> 24, np = ncov > nalt ? ncov : nalt;
         // Where no row of the tile has 16 reads or more (nearly every segment) dword d of the image carries the weights times
         // 8 >> d: the kernel then takes the background bits of its B operand with four masks and no shifts -- values 1, 2, 4, 8
@@ -939,7 +958,8 @@ void launch_win_target_g(const MfmaArgs &a, unsigned n_groups, hipStream_t st)
 {
     if (a.n_win == 0 || n_groups == 0)
         return;
-    hipLaunchKernelGGL(k_win_target_g, dim3((unsigned)(((size_t)a.n_segs * 64 + 255) / 256), n_groups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_win_target_g, dim3((unsigned)((((size_t)a.n_segs + IBDG_WTG_SEGS - 1) / IBDG_WTG_SEGS * 64 + 255) / 256), n_groups),
+                       dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_win_slot_g, dim3((a.n_win + 3) / 4, n_groups), dim3(256), 0, st, a);
 }
 
