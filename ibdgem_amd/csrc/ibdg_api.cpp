@@ -1580,6 +1580,13 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         }
         ibdg::launch_target_weights((const double *)c->base_w.p, d_tg, inline_tg ? targets : nullptr, (uint32_t)T, (uint32_t)lanes,
                                     c->base_sum, d_w, d_nref, ps);
+        if (ps == c->stream) {
+            // prepared on the main stream (more than AHEAD_MAX_T individuals, "prep_ahead" 0, no queue): the second stream reads
+            // the individuals' indices too (k_rows_windows, k_row_table) and, in a queue of runs, starts behind the PREVIOUS
+            // run's end only -- it must not overtake this copy / kernel
+            HIP_TRY(c, hipEventRecord(c->tg_ready, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->tg_ready, 0));
+        }
         c->prev_targets.assign(targets, targets + T);
         c->wt_gen = 0;             // the images in wtarget / twords are another individual's
     }

@@ -12,6 +12,7 @@
 //   lut     [(M+1)^2][3] f64 = P(D|G) for G=00,01,11, index n_ref*(M+1)+n_alt
 //   rec     {row_index u32, lut byte offset u32}; offset 0 <=> zero coverage
 #include "ibdg_kernels.h"
+#include "ibdg_ld_dev.h"
 
 #include <hip/hip_runtime.h>
 
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // (the wave's number as a scalar: the windows' bounds then come through scalar loads and live in SGPRs)
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const unsigned t = blockIdx.y;
-    const uint32_t tgt = a.targets[t];
+    uint32_t tgt = a.targets[t];
+    IBDG_CHECK_TGT(tgt, a.n_ids, __func__);
     const uint32_t n_w = a.n_win ? a.n_win : 1;      // no covered row at all: the rows still get their values
     const uint32_t n_groups = (n_w + WPW - 1) / WPW;
     const unsigned cq = lane / NV, cc = lane % NV;   // the chain a lane multiplies up: window cq of the group, value cc
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(512) void k_ld_window(LdArgs a)
 
     const uint32_t begin = w * a.window;
     const uint32_t end = min(begin + a.window, a.n_cov);
-    const uint32_t tgt = a.targets[t];
+    uint32_t tgt = a.targets[t];
+    IBDG_CHECK_TGT(tgt, (64u * a.n_groups * 8u), __func__);
     const uint32_t tw = 2 * (tgt >> 6), tb = tgt & 63;
     const double *wt = a.weight + (size_t)t * a.n_groups * CPW * 64;
 

@@ -38,6 +38,20 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     return v;
 }
 
+#ifdef IBDG_DEBUG_TGT
+#include <cstdio>
+#define IBDG_CHECK_TGT(tgt, bound, where)                                                          \
+    do {                                                                                           \
+        if ((tgt) >= (bound)) {                                                                    \
+            if ((threadIdx.x & 63) == 0)                                                           \
+                printf("BAD TARGET %u (bound %u) in %s block %u,%u,%u\n", (unsigned)(tgt), (unsigned)(bound), where, blockIdx.x, blockIdx.y, blockIdx.z); \
+            (tgt) = 0;                                                                             \
+        }                                                                                          \
+    } while (0)
+#else
+#define IBDG_CHECK_TGT(tgt, bound, where) do { } while (0)
+#endif
+
 // IBD0 of window w for comparison individual tgt from the ONE pass over the site list that keeps what does not depend on the
 // comparison individual (src/ibdgem.c:714-715, :743: its own exclusion is all that does): the chunks' sums p2c[w][chunk][2]
 // with, in place of the chunk the individual sits in, that chunk's 63 other weighted products p2w[w][lanes] -- masked, not

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void k_win_target(PopArgs a, uint32_t *__restr
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned t = blockIdx.y;
-    const uint32_t tgt = a.targets[a.t_base + t];
+    uint32_t tgt = a.targets[a.t_base + t];
+    IBDG_CHECK_TGT(tgt, a.lanes, __func__);
     const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
     if (i < a.n_segs) {                      // thread i: the record of segment i
         const Seg S = a.segs[i];
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned t = blockIdx.y;
-    const uint32_t tgt = a.targets[a.t_base + t];
+    uint32_t tgt = a.targets[a.t_base + t];
+    IBDG_CHECK_TGT(tgt, a.lanes, __func__);
     const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
     if ((i >> 2) < a.n_segs) {               // threads 4s .. 4s+3: the four A fragments of segment s
         const uint32_t sg = i >> 2, sum = i & 3;
@@ -491,7 +493,8 @@ __global__ __launch_bounds__(256) void k_win_target_x1(PopArgs a, const uint32_t
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned t = blockIdx.y;
-    const uint32_t tgt = a.targets[a.t_base + t];
+    uint32_t tgt = a.targets[a.t_base + t];
+    IBDG_CHECK_TGT(tgt, a.lanes, __func__);
     const uint4 *tt = reinterpret_cast<const uint4 *>(a.t32) + (size_t)(tgt >> 6) * a.n_pairs * 64 + (tgt & 63);
     if ((i >> 1) < a.n_segs) {
         const uint32_t sg = i >> 1, ts = i & 1;
@@ -1088,7 +1091,9 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
                     t0 += v.x;
                     t1 += v.y;
                 }
-                t0 = a.fin_p2c ? ibd0_from_pass(a.fin_p2c, a.fin_p2w, a.lanes, a.n_chunks, w, a.fin_targets[tt], lane)
+                uint32_t tgt_own = a.fin_p2c ? a.fin_targets[tt] : 0u;
+                IBDG_CHECK_TGT(tgt_own, a.fin_p2c ? a.lanes : 1u, "fused finalize");
+                t0 = a.fin_p2c ? ibd0_from_pass(a.fin_p2c, a.fin_p2w, a.lanes, a.n_chunks, w, tgt_own, lane)
                                : wave_sum_to_lane63(t0);
                 t1 = wave_sum_to_lane63(t1);
                 if (lane == 63) {
@@ -1740,7 +1745,9 @@ __global__ __launch_bounds__(256) void k_ld_finalize(PopFinalArgs a)
             t1 += v.y;
         }
     }
-    t0 = a.p2c ? ibd0_from_pass(a.p2c, a.p2w, a.lanes, a.n_chunks, w, a.targets[t], lane) : wave_sum_to_lane63(t0);
+    uint32_t tgt_own = a.p2c ? a.targets[t] : 0u;
+    IBDG_CHECK_TGT(tgt_own, a.p2c ? a.lanes : 1u, "k_ld_finalize");
+    t0 = a.p2c ? ibd0_from_pass(a.p2c, a.p2w, a.lanes, a.n_chunks, w, tgt_own, lane) : wave_sum_to_lane63(t0);
     t1 = wave_sum_to_lane63(t1);
     if (lane == 63) {
         const int nref = a.n_refpanel[t];

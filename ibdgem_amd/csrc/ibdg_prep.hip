@@ -695,7 +695,14 @@ __global__ __launch_bounds__(256) void k_target_weights(const double *__restrict
 {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = blockIdx.y;
-    const uint32_t tgt = n_inline ? inl.v[t] : targets[t];
+    uint32_t tgt = n_inline ? inl.v[t] : targets[t];
+#ifdef IBDG_DEBUG_TGT
+    if (tgt >= lanes) {
+        if (n == 0)
+            printf("BAD TARGET %u (lanes %u) in k_target_weights t %u inline %u\n", tgt, lanes, t, n_inline);
+        tgt = 0;
+    }
+#endif
     if (n < lanes)
         weight[(size_t)t * lanes + n] = n == tgt ? 0.0 : base_w[n];
     if (n == 0) {

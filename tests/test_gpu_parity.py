@@ -966,6 +966,43 @@ def test_a_new_individual_per_queued_run(oracle):
             eng.window_ll_all(2)
 
 
+def test_the_second_stream_never_overtakes_a_run_s_individuals():
+    """Where a run's individuals are prepared on the MAIN stream (option prep_ahead 0, or more than 64 of them) in a queue of
+    runs, the second stream -- per-row values and LIBD2 of the windows, which read the individuals' indices too -- starts
+    behind the previous run's end: it must wait for this run's indices as well (found by the fuzzer as a memory fault: a
+    fresh ring slot's garbage read as an individual).  Queued runs over other individuals each, then the per-row values and
+    windows of the last one against its synchronous run, bit for bit."""
+    N, L = 200, 20000
+    alle, nr, na = synth(97531, L, N)
+    with E.Engine() as eng:
+        eng.upload_panel(E.pack_alleles_fast(alle), N)
+        eng.upload_sites(np.arange(L), nr, na, 100)
+        want = {}
+        for t in (3, 150):
+            eng.run([t], ld=True)
+            want[t] = (eng.site_ll(0), eng.window_ll(0))
+        many = list(range(10, 80))                          # 70 > 64: prepared on the main stream whatever the option
+        eng.run(many, ld=True)
+        want_many = (eng.site_ll(69), eng.window_ll(69))
+        eng.set_option("async", 1)
+        for prep_ahead in (0, 1):
+            eng.set_option("prep_ahead", prep_ahead)
+            for rounds in range(6):
+                for k in range(9):
+                    eng.run([(7 * k + rounds) % N], ld=True)
+                last = (3, 150)[rounds & 1]
+                eng.run([last], ld=True)
+                assert_bits(eng.site_ll(0), want[last][0], f"per-row values, prep_ahead {prep_ahead}, round {rounds}")
+                assert_bits(eng.window_ll(0), want[last][1], f"windows, prep_ahead {prep_ahead}, round {rounds}")
+            for rounds in range(3):
+                eng.run([(11 * rounds) % N], ld=True)
+                eng.run(list(range(100 + rounds, 170 + rounds)), ld=True)
+                eng.run(many, ld=True)
+                assert_bits(eng.site_ll(69), want_many[0], f"70 individuals, per-row values, round {rounds}")
+                assert_bits(eng.window_ll(69), want_many[1], f"70 individuals, windows, round {rounds}")
+        eng.set_option("async", 0)
+
+
 @pytest.mark.parametrize("tiles", [-1, 1])
 def test_ibd0_from_one_pass_over_the_site_list(oracle, tiles):
     """What a background individual's own genotype contributes to IBD0 (src/ibdgem.c:715, :743) does not depend on the

@@ -53,16 +53,21 @@ for case in range(n_cases):
                 "mfma_targets": int(rng.choice([0, 1, 1])), "mfma_min": int(rng.choice([1, 2, 8, 15])),
                 "mx_counts": int(rng.choice([0, 1, 1]))}
     desc = f"case {case}: N={N} L={L} keep={len(keep)} W={W} eps={eps} M={M} cov={cov} T={T} bg={'y' if bg is not None else 'n'} pu={pu} variant={variant} tiles={tiles} {opts}"
+    if case >= int(os.environ.get("FUZZ_PRINT_FROM", "1000000000")):     # (to name the case a GPU fault ends the process in)
+        print("RUNNING", desc, flush=True)
     try:
         with E.Engine(0, eps, M) as eng:
             for k, v in opts.items():
                 eng.set_option(k, v)
             eng.set_option("ld_variant", variant)
             eng.set_option("compact_tiles", tiles)
-            eng.set_option("compact_targets", int(rng.choice([3, 8, 96])))
-            eng.set_option("compact_align", int(rng.choice([1, 1, 1, 32, 4, 16])))
-            # single individuals with their IBD0 terms from one pass over the site list: from the first run, after a few, never
-            eng.set_option("ibd0_after", int(rng.choice([1, 1, 2, 3, 8, 0])))
+            more = {"compact_targets": int(rng.choice([3, 8, 96])), "compact_align": int(rng.choice([1, 1, 1, 32, 4, 16])),
+                    # single individuals with their IBD0 terms from one pass over the site list: from the first run, after a few, never
+                    "ibd0_after": int(rng.choice([1, 1, 2, 3, 8, 0]))}
+            for k, v in more.items():
+                eng.set_option(k, v)
+            if case >= int(os.environ.get("FUZZ_PRINT_FROM", "1000000000")):
+                print("   ", more, flush=True)
             eng.upload_panel(E.pack_alleles_fast(alle), N)
             eng.upload_sites(keep, nr[keep], na[keep], W)
             eng.set_background_order(order)
@@ -75,8 +80,13 @@ for case in range(n_cases):
                 eng.set_option("end_in_dispatch", int(rng.choice([1, 1, 0])))
                 for _ in range(queued):
                     other = [int(t) for t in rng.choice(N, size=int(rng.choice([1, 1, 1, T, min(N, T + 1)])), replace=False)]
+                    if case >= int(os.environ.get("FUZZ_PRINT_FROM", "1000000000")):
+                        print("    queued run of", len(other), "individuals", flush=True)
                     try:
                         eng.run(other, ld=bool(rng.random() < 0.9), bg_count=bg if order is not None or rng.random() < 0.8 else None, pu_id=pu)
+                        if os.environ.get("FUZZ_SYNC") and case >= int(os.environ.get("FUZZ_PRINT_FROM", "1000000000")):
+                            eng.sync()
+                            print("      ... done, count unit", eng.last_count_unit(), "layout", eng.ld_layout(), flush=True)
                     except E.EngineError as e:
                         if variant == 2 and "not applicable" in str(e):
                             break
