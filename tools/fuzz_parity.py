@@ -36,7 +36,7 @@ for case in range(n_cases):
     keep = np.sort(rng.choice(L, size=max(1, int(L * rng.choice([1.0, 1.0, 0.5, 0.2, 0.05, 0.02, 0.005]))), replace=False))
     if rng.random() < 0.1:
         keep = rng.permutation(keep)                # rows out of file order: the compacted tiles (or the strict kernel)
-    T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40]))     # 5 and more: the matrix-core kernel (k_ld_mfma)
+    T = int(rng.choice([1, 1, 2, 4, 5, 9, 8, 15, 16, 23, 31, 40, 70]))     # 5 and more: the matrix-core kernel (k_ld_mfma); 70: more than the runs that prepare ahead hold
     T = min(T, N)
     targets = [int(t) for t in rng.choice(N, size=T, replace=False)]
     bg = None if rng.random() < 0.5 else rng.integers(0, 3, size=N).astype(np.uint8)
