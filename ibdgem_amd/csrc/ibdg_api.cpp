@@ -1712,7 +1712,11 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
         const size_t TGs = IBDG_TG;
         size_t n_gg = 0, T_g = 0;
         // (one group's partial sums and operands must stay modest: tiny windows over millions of rows go the old way)
-        const size_t group_bytes = (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128) + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
+        // (a group's partial sums: 16 doubles per window and half chunk -- per group of eight half chunks where the kernel's
+        //  workgroups add their waves' sums up themselves, MfmaArgs::wg_sum)
+        const bool mfma_wg_sum = c->opt_mfma_wg_sum && ibdg::ld_mfma_wg_sum(c->wpg, c->ct_max + 1, c->max_seg);
+        const size_t ph_group = (size_t)c->n_win * (mfma_wg_sum ? (size_t)((2 * c->n_chunks + 7) / 8) * 128 : (size_t)c->n_chunks * 2 * 128) + 128;
+        const size_t group_bytes = ph_group + (size_t)c->n_segs * 1024 + (size_t)c->n_win * 512;
         if (c->opt_mfma_targets && c->tab_in_lds && !dispatch_events && T >= (size_t)c->opt_mfma_min && (c->compact ? c->n_pairs_c : c->n_pairs) < (1u << 21) && c->n_segs < (1u << 21) &&     // (32-bit byte offsets of its buffer loads)
             group_bytes <= ((size_t)4 << 30) &&
             ibdg::ld_mfma_lds_bytes(c->wpg, c->ct_max + 1, c->max_seg) <= 64 * 1024) {
@@ -1734,7 +1738,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             const size_t per_group = (size_t)c->n_segs * 1024;
             const size_t mem_cap = std::max<size_t>((size_t)1 << 30, c->dev_mem_bytes / 16);
             size_t fit = per_group ? mem_cap / per_group : n_gg;
-            const size_t fit_p = mem_cap / ((size_t)c->n_win * (c->n_chunks * 2 * 136 + 128) + 1);     // partial sums
+            const size_t fit_p = mem_cap / ph_group;     // partial sums
             fit = fit < fit_p ? fit : fit_p;
             const size_t cap_g = (size_t)std::max<long>(1, c->opt_mfma_batch);
             fit = fit < 1 ? 1 : (fit > cap_g ? cap_g : fit);
@@ -1763,7 +1767,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ensure(c, c->partial, T_cnt ? 2 * part_bytes : 0) ||
             ensure(c, c->aimg, gg_batch * (size_t)c->n_segs * 1024) ||
             ensure(c, c->wc_slot, gg_batch * (size_t)c->n_win * 512) ||
-            ensure(c, c->partial_h, gg_batch * (size_t)c->n_win * ((size_t)c->n_chunks * 2 * 136 + 128)))
+            ensure(c, c->partial_h, gg_batch * ph_group))
             return 1;
         ibdg::PopArgs pa;
         pa.t32 = (const uint32_t *)(c->compact ? c->t32c.p : c->t32.p);
@@ -1895,7 +1899,7 @@ int ibdg_run(ibdg_ctx *c, const uint32_t *targets, size_t T, const uint8_t *bg_c
             ma.p2w = (const double *)c->p2w.p;
             ma.p2c = (const double *)c->p2c.p;
             ma.lanes = (uint32_t)lanes;
-            ma.wg_sum = c->opt_mfma_wg_sum && ibdg::ld_mfma_wg_sum(c->wpg, c->ct_max + 1, c->max_seg) ? 1u : 0u;
+            ma.wg_sum = mfma_wg_sum ? 1u : 0u;
             {
                 // one batch's partial sums: t1 [groups][windows][half chunks][16], t0 [groups][windows][half chunks], ov [groups][windows][16]
                 const size_t nh = (size_t)c->n_chunks * 2;
