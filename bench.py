@@ -768,6 +768,9 @@ def compact_line(out, detail_file):
     line["engine_sites_per_s"] = ec.get("sites_per_s")
     line["engine_clock_ms"] = ec.get("ms")
     line["new_individual_per_step"] = out.get("new_individual_per_step")
+    # (the step without the engine's once-per-site-list pass for the IBD0 terms, same queue and tiles: beside `value`'s step)
+    at = out.get("all_terms_in_every_step") or {}
+    line["all_terms_in_every_step_ms"] = at.get("ms_per_step")
     many = out.get("many_comparison_individuals") or {}
     line["many_individuals"] = _pick(many, ("comparison_individuals", "ms_per_individual", "site_individual_pairs_per_s")) if many else None
     for k in ("step_vs_reference_end_to_end", "engine_clock_vs_reference_end_to_end", "ld_kernels_vs_reference_ld_stage"):
@@ -777,7 +780,7 @@ def compact_line(out, detail_file):
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:                       # (cannot happen at <= 8 ranks; drop the optional parts rather than the contract's)
         for k in ("parity", "many_individuals", "ld_kernels_vs_reference_ld_stage", "engine_clock_vs_reference_end_to_end",
-                  "step_vs_reference_end_to_end", "engine_clock_ms", "new_individual_per_step"):
+                  "step_vs_reference_end_to_end", "engine_clock_ms", "new_individual_per_step", "all_terms_in_every_step_ms"):
             line.pop(k, None)
         line["per_rank"] = [_pick(r, ("rank", "windowed_sites", "ms_per_step", "ld_launch_ms")) for r in line["per_rank"]]
         text = json.dumps(line, separators=(",", ":"))
@@ -1080,6 +1083,32 @@ def main():
         pass                                 # strict kernel: no such figure
     eng.set_option("async", 0)
     eng.set_option("dispatch_events", 0)
+    # the same step with every term counted in it (option ibd0_after 0: no pass over the site list is used), same tiles, same queue:
+    # what the timed steps would cost without the engine's use of what a site list's comparisons have in common
+    all_terms = None
+    if count_unit == 3:
+        eng.set_option("ibd0_after", 0)
+        eng.set_option("async", 1)
+        for _ in range(16):
+            step()
+        eng.sync()
+        n_at = max(32, min(args.steps, 200))
+        t_at = time.perf_counter()
+        for _ in range(n_at):
+            step()
+        eng.sync()
+        at_ms = (time.perf_counter() - t_at) / n_at * 1e3
+        eng.set_option("async", 0)
+        at_ld = float(np.mean([eng.run_ms(b)["ld"] for b in range(32)]))
+        all_terms = {"ms_per_step": at_ms, "ld_launch_ms": at_ld, "count_unit": eng.last_count_unit(), "steps": n_at,
+                     "sites_per_s": n_cov / (at_ms * 1e-3),
+                     "hbm_frac": algorithmic_bytes_per_site(args.ids, 1) * n_cov / (at_ld * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "the timed steps' queue with option ibd0_after 0: k_ld_popcount counts the IBD0 terms of every background "
+                             "individual in every step again (ibdg_last_count_unit 2); same tiles, a new individual per step"}
+        eng.set_option("ibd0_after", next((int(kv.split("=")[1]) for kv in args.opt if kv.startswith("ibd0_after=")), 8))
+        for _ in range(2):
+            step()
+        eng.sync()
     # the same step on the panel's own tiles (what the first 15 runs on a site list cost; the timed steps of rounds 1-3):
     # compacted tiles forbidden, a fresh upload, queued steps after the same clock settling
     in_place = None
@@ -1345,6 +1374,7 @@ def main():
                                    "count_unit 3 = the timed steps count the IBD1 sums only and their finalising step takes IBD0 from "
                                    "the pass, in the additions of a run that counts everything: same bits (tests/test_gpu_parity.py); "
                                    "`in_place_tiles` is a step that counts everything, on the panel's own tiles"),
+            "all_terms_in_every_step": all_terms,
             "in_place_tiles": in_place,
             "prewarm": {"ms": args.prewarm_ms, "steps": n_prewarm,
                         "note": "untimed steps before the warm-up steps so that the clocks have settled when they start"},
