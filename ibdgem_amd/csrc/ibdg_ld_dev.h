@@ -48,8 +48,14 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
             (tgt) = 0;                                                                             \
         }                                                                                          \
     } while (0)
+#define IBDG_CHECK_IDX(idx, bound, where)                                                          \
+    do {                                                                                           \
+        if ((idx) >= (bound))                                                                      \
+            printf("BAD INDEX %u (bound %u) in %s block %u,%u,%u\n", (unsigned)(idx), (unsigned)(bound), where, blockIdx.x, blockIdx.y, blockIdx.z); \
+    } while (0)
 #else
 #define IBDG_CHECK_TGT(tgt, bound, where) do { } while (0)
+#define IBDG_CHECK_IDX(idx, bound, where) do { } while (0)
 #endif
 
 // IBD0 of window w for comparison individual tgt from the ONE pass over the site list that keeps what does not depend on the

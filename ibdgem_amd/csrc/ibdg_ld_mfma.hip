@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_win_target_g(MfmaArgs a)
 #pragma unroll
     for (uint32_t j = 0; j < NSEG; ++j) {
         const uint32_t s = s0 + j < a.n_segs ? s0 + j : a.n_segs - 1;
+        IBDG_CHECK_IDX(a.segs[s].tile, 2 * a.n_pairs, "k_win_target_g tile");
         uint32_t sel = q == PSEUDO ? 0xffffffffu : 0u;     // rows of the tile that count in this row of the operand
         if (real) {
             const uint2 w = tile_words(tt, a.segs[s].tile);

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void k_win_target_mx(PopArgs a, uint32_t *__re
     if ((i >> 2) < a.n_segs) {               // threads 4s .. 4s+3: the four A fragments of segment s
         const uint32_t sg = i >> 2, sum = i & 3;
         const Seg &S = a.segs[sg];
+        IBDG_CHECK_IDX(S.tile, 2 * a.n_pairs, "k_win_target_mx tile");
         const uint2 at = tile_words(tt, S.tile);
         // the rows' weights of this thread's sum as three bit planes of the magnitude and one of the sign (bit 5 of the e2m3 code):
         //   <x,cov> <x,alt> <x & t0,cov> <x & t1,cov>                            -- the form that counts everything
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256) void k_win_target_x1(PopArgs a, const uint32_t
     if ((i >> 1) < a.n_segs) {
         const uint32_t sg = i >> 1, ts = i & 1;
         const Seg &S = a.segs[sg];
+        IBDG_CHECK_IDX(S.tile, 2 * a.n_pairs, "k_win_target_x1 tile");
         const uint2 at = tile_words(tt, S.tile);
         const uint32_t tw = ts ? at.y : at.x;
         // M: element k = 8 d + j of the fragment is row 4 j + d of the tile
@@ -1135,6 +1137,8 @@ __global__ __launch_bounds__(512) void k_ld_popcount(const uint4 *__restrict__ t
     const uint4 *xt = t32 + (size_t)c * a.n_pairs * 64 + lane;      // + pair*64
     const uint32_t tile0 = segs[seg0].tile;
     const uint32_t q0 = tile0 >> 1, q_last = segs[seg1 - 1].tile >> 1;
+    IBDG_CHECK_IDX(q_last, a.n_pairs, "k_ld_popcount last pair");
+    IBDG_CHECK_IDX(q0, q_last + 1, "k_ld_popcount first pair");
     uint32_t q_issue = q0;                           // next pair to request (nominal: runs past q_last)
     if (has_chunk) {
 #pragma unroll
