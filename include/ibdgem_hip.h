@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets, ibdg_upload_panel_fd; a run over new comparison individuals queues without a host wait; option ibd0_after, ibdg_last_count_unit 3.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
+#define IBDG_ABI_VERSION 5   /* 5: ibdg_num_targets, ibdg_upload_panel_fd; a run over new comparison individuals queues without a host wait; options ibd0_after, mfma_batch_groups, mfma_wg_sum; ibdg_last_count_unit 3.  4: ibdg_ld_layout, ibdg_last_count_unit, ibdg_get_window_ll_all; options compact_tiles, compact_density, compact_targets; the strict kernel is no
                               * longer what a sparse pileup gets.  3: options site_results, stage_workers; ibdg_get_site_af
                               * computes on demand; ibdg_last_run_ms out[4] is 0 */
 
