@@ -898,6 +898,57 @@ void k_ld_mfma(MfmaArgs a)
     }
 }
 
+// The value of lane ^ X: within the quad by a DPP move, beyond it through the LDS crossbar, across the halves by
+// v_permlane32_swap (valid in the upper half only: what is read there).
+template <int X>
+__device__ __forceinline__ double lane_xor_get(double v)
+{
+    if (X == 32) {
+        const uint32_t lo = __builtin_amdgcn_permlane32_swap((uint32_t)__double2loint(v), (uint32_t)__double2loint(v), false, false)[0];
+        const uint32_t hi = __builtin_amdgcn_permlane32_swap((uint32_t)__double2hiint(v), (uint32_t)__double2hiint(v), false, false)[0];
+        return __hiloint2double((int)hi, (int)lo);            // lanes 32..63: the value of lane l - 32
+    }
+    if (X == 1 || X == 2) {
+        constexpr int ctrl = X == 1 ? 0xB1 : 0x4E;            // quad_perm [1,0,3,2] / [2,3,0,1]
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true));
+    }
+    constexpr int pat = ((X & 31) << 10) | 0x1f;              // ds_swizzle, bit mode: and 0x1f, or 0, xor X
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pat), __builtin_amdgcn_ds_swizzle(__double2loint(v), pat));
+}
+
+// One level of sixteen wave sums at once: the lanes whose bit X is clear go on with sum a, the others with sum b -- each adds
+// its partner's (lane ^ X) addend of the sum it keeps.
+template <int X>
+__device__ __forceinline__ double tree_merge(double a, double b, uint32_t lane)
+{
+    const bool up = (lane & X) != 0;
+    const double keep = up ? b : a, give = up ? a : b;
+    return keep + lane_xor_get<X>(give);
+}
+
+// The sums over the wave's 64 lanes of SIXTEEN addends per lane, v[0..15], in the additions of wave_sum_to_lane63 -- the
+// balanced tree over the lane number's bits 0, 1, ..., 5 -- for all sixteen at once: after the levels of bits 0..3 lane l
+// holds the sum of its row of 16 lanes for addend l & 15 (8 + 4 + 2 + 1 merges instead of 16 x 4 steps), bits 4 and 5 add the
+// rows.  Lanes 48 + q hold the total of v[q], the same bits as wave_sum_to_lane63(v[q]) leaves in lane 63.
+__device__ __forceinline__ double wave_sums16(const double (&v)[16], uint32_t lane)
+{
+    double r[8], s[4], t[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        r[j] = tree_merge<1>(v[2 * j], v[2 * j + 1], lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        s[j] = tree_merge<2>(r[2 * j], r[2 * j + 1], lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        t[j] = tree_merge<4>(s[2 * j], s[2 * j + 1], lane);
+    double u = tree_merge<8>(t[0], t[1], lane);
+    u = u + lane_xor_get<16>(u);
+    u = u + lane_xor_get<32>(u);
+    return u;
+}
+
 // The window averages of a group's comparison individuals (src/ibdgem.c:736-753): a wave per (window, group), four windows
 // a workgroup.  IBD1: lane 16 j + q adds t1[hc][q] of half chunks hc = j, j + 4, ... in that order, the four part sums of a
 // slot meet as ((j0 + j1) + j2) + j3.  IBD0 does not depend on the comparison individual except for its own exclusion
@@ -917,12 +968,37 @@ __global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__
     double acc = 0.0;
     for (uint32_t hc = j; hc < n_half; hc += 4)
         acc += t1[(size_t)hc * 16 + q];
-    const double a1 = __shfl(acc, q + 16), a2 = __shfl(acc, q + 32), a3 = __shfl(acc, q + 48);
-    const double s1 = ((acc + a1) + a2) + a3;                  // (lanes 0..15 hold the totals)
+    const double a0 = __shfl(acc, q), a1 = __shfl(acc, q + 16), a2 = __shfl(acc, q + 32), a3 = __shfl(acc, q + 48);
+    const double s1 = ((a0 + a1) + a2) + a3;                   // (every lane: the total of slot lane & 15)
     const double *pc = a.p2c + (size_t)w * a.n_chunks * 2;
     const double *pw = a.p2w + (size_t)w * a.lanes;
     const double pc_lane = lane < a.n_chunks ? pc[2 * lane] : 0.0;
-    double s0 = 0.0;                                           // lane qq: slot qq's sum
+    double s0 = 0.0;                                           // slot lane & 15's sum (in the lanes 48..63 at least)
+    if (a.n_chunks <= 64) {
+        // all slots at once (wave_sums16): first every slot's own chunk without its own individual, one lane an individual;
+        // then, one lane a chunk, that sum in place of the chunk's -- the additions of ibd0_from_pass, slot by slot
+        uint32_t c_own[16];
+        double v[16];
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            c_own[qq] = 0xffffffffu;
+            v[qq] = 0.0;
+            if ((uint32_t)qq < cnt) {
+                const uint32_t tgt = a.targets[a.t_base + grp * TG + qq];      // (the same for the whole wave)
+                c_own[qq] = tgt >> 6;
+                const double x = pw[64 * (size_t)c_own[qq] + lane];
+                v[qq] = lane == (tgt & 63) ? 0.0 : x;
+            }
+        }
+        const double own_all = wave_sums16(v, lane);
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const double own = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(own_all), 48 + qq),
+                                                __builtin_amdgcn_readlane(__double2loint(own_all), 48 + qq));
+            v[qq] = lane == c_own[qq] ? own : pc_lane;
+        }
+        s0 = wave_sums16(v, lane);
+    } else
     for (uint32_t qq = 0; qq < cnt; ++qq) {
         const uint32_t tgt = a.targets[a.t_base + grp * TG + qq];      // (the same for the whole wave)
         const uint32_t c_own = tgt >> 6;                       // the chunk (64 individuals) the slot's own individual sits in
@@ -936,10 +1012,10 @@ __global__ __launch_bounds__(256) void k_ld_finalize_g(MfmaArgs a, const int *__
         const double tot = wave_sum_to_lane63(t0);
         const double all = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 63),
                                             __builtin_amdgcn_readlane(__double2loint(tot), 63));
-        s0 = lane == qq ? all : s0;
+        s0 = q == qq ? all : s0;
     }
-    if (lane < cnt) {
-        const uint32_t t = a.t_base + grp * TG + lane;
+    if (lane >= 48 && q < cnt) {                               // (the lanes 48 + slot hold both totals)
+        const uint32_t t = a.t_base + grp * TG + q;
         const int nref = n_refpanel[t];
         const double mK = a.wconst[w].mK;             // mantissa of K' (its exponent went into every term)
         double *o = win_ll + ((size_t)t * a.n_win + w) * 3;
