@@ -773,6 +773,16 @@ def compact_line(out, detail_file):
     line["all_terms_in_every_step_ms"] = at.get("ms_per_step")
     many = out.get("many_comparison_individuals") or {}
     line["many_individuals"] = _pick(many, ("comparison_individuals", "ms_per_individual", "site_individual_pairs_per_s")) if many else None
+    # (like `value`: the cost on a site list in use -- its rows re-laid out back to back, which runs of many individuals bring about
+    #  by themselves after thirteen groups of 15 -- beside the first runs' on the panel's own tiles)
+    fc = many.get("from_compacted_tiles") if isinstance(many, dict) else None
+    if line["many_individuals"] and isinstance(fc, dict) and fc.get("ms_per_individual"):
+        line["many_individuals"]["ms_per_individual_first_runs"] = line["many_individuals"]["ms_per_individual"]
+        line["many_individuals"]["ms_per_individual"] = fc["ms_per_individual"]
+        line["many_individuals"]["tiles"] = "compacted"
+        if many.get("site_individual_pairs_per_s") and many.get("ms_per_individual"):
+            line["many_individuals"]["site_individual_pairs_per_s"] = (many["site_individual_pairs_per_s"] * many["ms_per_individual"]
+                                                                     / fc["ms_per_individual"])
     for k in ("step_vs_reference_end_to_end", "engine_clock_vs_reference_end_to_end", "ld_kernels_vs_reference_ld_stage"):
         line[k] = out.get(k)
     line["detail_file"] = detail_file
