@@ -927,16 +927,22 @@ def main():
         eng.set_option(k, int(v))
     eng.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
     eng2 = None
-    if world == 1 and not args.no_many and not args.timed_only:
-        # a second context with the same panel, for engine_clock.two_contexts_alternating_ms (idle until then)
-        eng2 = ibdgem_amd.Engine(local, 0.02, 20)
+    want_second = world == 1 and not args.no_many and not args.timed_only
+
+    def second_context(panel_t):
+        # a second context with the same panel, for engine_clock.two_contexts_alternating_ms.  Made when that leg begins, not
+        # before the timed steps: two contexts hold six streams, more than the runtime's hardware queues (4 by default), so
+        # that the first context's three streams would share queues while `value` is measured -- the step came out 2-5 %
+        # slower than `--timed-only`'s in the same call (0.511 against 0.487 ms in the round's last evidence call)
+        e2 = ibdgem_amd.Engine(local, 0.02, 20)
         for name, val in (("ld_variant", args.variant), ("chunks_per_wave", args.cpw), ("waves_per_block", args.waves)):
             if val is not None:
-                eng2.set_option(name, val)
+                e2.set_option(name, val)
         for kv in args.opt:
             k, v = kv.split("=")
-            eng2.set_option(k, int(v))
-        eng2.upload_panel_dev(panel.data_ptr(), panel.shape[0], args.ids)
+            e2.set_option(k, int(v))
+        e2.upload_panel_dev(panel_t.data_ptr(), panel_t.shape[0], args.ids)
+        return e2
     sample_rows = min(args.cpu_sample_rows, panel.shape[0])
     sample_words = panel[:sample_rows].cpu().numpy().view(np.uint64) if rank == 0 else None
     words_all = None
@@ -944,6 +950,7 @@ def main():
         words_all = np.empty((panel.shape[0], panel.shape[1]), dtype=np.uint64)
         for a in range(0, panel.shape[0], 500_000):
             words_all[a:a + 500_000] = panel[a:a + 500_000].cpu().numpy().view(np.uint64)
+    panel_kept = panel if want_second else None      # (2.56 GB held until the second context has copied it)
     del panel
     torch.cuda.empty_cache()
     n_rows = row1 - row0
@@ -1147,6 +1154,10 @@ def main():
         eng.set_option("ibd0_after", next((int(kv.split("=")[1]) for kv in args.opt if kv.startswith("ibd0_after=")), 8))
         eng.upload_sites(np.arange(n_rows, dtype=np.uint32), n_ref, n_alt, args.window)
     # the other clocks of one comparison (not `value`): upload of its rows, the survey's engine clock, results to host
+    if want_second:
+        eng2 = second_context(panel_kept)
+        del panel_kept
+        torch.cuda.empty_cache()
     up, engine_clock, d2h = upload_and_engine_clocks(torch, eng, ibdgem_amd, n_ref, n_alt, args.window, targets, n_cov, eng2)
     if eng2 is not None:
         eng2.close()
